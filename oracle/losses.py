@@ -1,0 +1,97 @@
+"""Oracle for the DCCA correlation loss.  TEST INFRASTRUCTURE ONLY.
+
+``*_autograd`` functions restate ``cca_zoo/deep/objectives.py`` as the reference
+structures it (CPU torch ``linalg.eigh`` + autograd); ``cca_loss_closed_form``
+is the NumPy float64 specification of what the HIP path computes
+(``loss = -tr(S11^-1 S12 S22^-1 S21)`` and its analytic gradient, SURVEY.md
+section 8(a) rows 8-9).  Pinned by ``tests/golden/loss_*.npz``.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+__all__ = [
+    "inv_sqrtm_eigh",
+    "cca_loss_autograd",
+    "mcca_loss_autograd",
+    "cca_loss_closed_form",
+    "mcca_loss_closed_form",
+]
+
+
+def inv_sqrtm_eigh(A: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """objectives.py:9-21 -- eigh, clamp eigenvalues at eps, V diag(l^-1/2) V'."""
+    lam, V = torch.linalg.eigh(A)
+    lam = torch.clamp(lam, min=eps)
+    return V @ torch.diag(lam.rsqrt()) @ V.T
+
+
+def cca_loss_autograd(z1: torch.Tensor, z2: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """objectives.py:61-102 -- two-view loss exactly as the reference orders it."""
+    n = z1.shape[0]
+    a = z1 - z1.mean(dim=0)
+    b = z2 - z2.mean(dim=0)
+    eye1 = torch.eye(a.shape[1], dtype=a.dtype, device=a.device)
+    eye2 = torch.eye(b.shape[1], dtype=b.dtype, device=b.device)
+    s11 = a.T @ a / (n - 1) + eps * eye1
+    s22 = b.T @ b / (n - 1) + eps * eye2
+    s12 = a.T @ b / (n - 1)
+    t = inv_sqrtm_eigh(s11, eps) @ s12 @ inv_sqrtm_eigh(s22, eps)
+    ev = torch.linalg.eigvalsh(t.T @ t)
+    return -torch.clamp(ev, min=0.0).sum()
+
+
+def mcca_loss_autograd(zs, eps: float = 1e-5) -> torch.Tensor:
+    """objectives.py:138-153 -- sum over i<j of the two-view loss (fp32 accumulator)."""
+    total = torch.tensor(0.0, device=zs[0].device)
+    for i in range(len(zs)):
+        for j in range(i + 1, len(zs)):
+            total = total + cca_loss_autograd(zs[i], zs[j], eps)
+    return total
+
+
+def cca_loss_closed_form(z1, z2, eps=1e-5):
+    """float64 value and gradients from second moments + Cholesky solves.
+
+    With a, b the centred inputs, ``S11 = a'a/(n-1) + eps I`` (same for S22),
+    ``S12 = a'b/(n-1)``, ``P = S11^-1 S12``, ``Q = S22^-1 S12'``:
+
+    * loss = -tr(P Q)
+    * dL/dS12 = -2 S11^-1 S12 S22^-1 ;  dL/dS11 = P Q S11^-1 ;  dL/dS22 = Q P S22^-1
+    * dz1 = center( (a (G11 + G11') + b G12') / (n-1) ), dz2 likewise.
+    """
+    z1 = np.asarray(z1, dtype=np.float64)
+    z2 = np.asarray(z2, dtype=np.float64)
+    n = z1.shape[0]
+    a = z1 - z1.mean(axis=0)
+    b = z2 - z2.mean(axis=0)
+    s11 = a.T @ a / (n - 1) + eps * np.eye(a.shape[1])
+    s22 = b.T @ b / (n - 1) + eps * np.eye(b.shape[1])
+    s12 = a.T @ b / (n - 1)
+    P = np.linalg.solve(s11, s12)            # d1 x d2
+    Q = np.linalg.solve(s22, s12.T)          # d2 x d1
+    loss = -np.trace(P @ Q)
+    G12 = -2.0 * np.linalg.solve(s22, P.T).T       # -2 S11^-1 S12 S22^-1
+    G11 = np.linalg.solve(s11, (P @ Q).T).T        # P Q S11^-1
+    G22 = np.linalg.solve(s22, (Q @ P).T).T        # Q P S22^-1
+    g1 = (a @ (G11 + G11.T) + b @ G12.T) / (n - 1)
+    g2 = (b @ (G22 + G22.T) + a @ G12) / (n - 1)
+    g1 -= g1.mean(axis=0)
+    g2 -= g2.mean(axis=0)
+    return loss, g1, g2
+
+
+def mcca_loss_closed_form(zs, eps=1e-5):
+    """Sum of pairwise closed-form losses and the summed gradients."""
+    zs = [np.asarray(z, dtype=np.float64) for z in zs]
+    grads = [np.zeros_like(z) for z in zs]
+    total = 0.0
+    for i in range(len(zs)):
+        for j in range(i + 1, len(zs)):
+            l, gi, gj = cca_loss_closed_form(zs[i], zs[j], eps)
+            total += l
+            grads[i] += gi
+            grads[j] += gj
+    return total, grads
