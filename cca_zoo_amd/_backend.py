@@ -1,0 +1,308 @@
+"""ctypes binding of ``libccz`` (include/ccz.h) -- the only door to the device.
+
+There is deliberately no CPU fallback: if the HIP library has not been built or
+no GPU is visible, every entry point raises.  ``bind`` is also used by the CPU
+test-suite to attach the *test double* ``tests/hostsim/libccz_hostsim.so`` (the
+product solver drivers compiled against host loops) -- the package itself only
+ever loads ``cca_zoo_amd/lib/libccz.so``.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+__all__ = ["CCZError", "Handle", "bind", "library", "library_path", "default_handle"]
+
+F32, F64 = 0, 1
+_ERRORS = {
+    -1: ValueError,
+    -2: MemoryError,
+    -3: RuntimeError,
+    -4: np.linalg.LinAlgError,
+    -5: np.linalg.LinAlgError,
+    -6: ValueError,
+}
+
+
+class CCZError(RuntimeError):
+    """Raised when libccz itself cannot be loaded."""
+
+
+class View(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("cols", C.c_int64), ("ld", C.c_int64)]
+
+
+class DevInfo(C.Structure):
+    _fields_ = [
+        ("name", C.c_char * 128),
+        ("arch", C.c_char * 32),
+        ("compute_units", C.c_int),
+        ("wavefront", C.c_int),
+        ("hbm_bytes", C.c_int64),
+        ("lds_bytes_per_cu", C.c_int64),
+    ]
+
+
+_vp, _i64, _int, _dbl = C.c_void_p, C.c_int64, C.c_int, C.c_double
+_pi64, _pdbl, _pint = C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int)
+
+#: every symbol include/ccz.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "ccz_version": (_int, []),
+    "ccz_create": (_int, [C.POINTER(_vp), _int]),
+    "ccz_destroy": (_int, [_vp]),
+    "ccz_last_error": (C.c_char_p, [_vp]),
+    "ccz_set_stream": (_int, [_vp, _vp]),
+    "ccz_sync": (_int, [_vp]),
+    "ccz_device_info": (_int, [_vp, C.POINTER(DevInfo)]),
+    "ccz_dev_alloc": (_int, [_vp, C.POINTER(_vp), C.c_size_t]),
+    "ccz_dev_free": (_int, [_vp, _vp]),
+    "ccz_memcpy_h2d": (_int, [_vp, _vp, _vp, C.c_size_t]),
+    "ccz_memcpy_d2h": (_int, [_vp, _vp, _vp, C.c_size_t]),
+    "ccz_memset0": (_int, [_vp, _vp, C.c_size_t]),
+    "ccz_moments": (_int, [_vp, _int, C.POINTER(View), _int, _i64, _int, _vp, _int]),
+    "ccz_moments_symmetrize": (_int, [_vp, _vp, _i64]),
+    "ccz_moments_last_ms": (_int, [_vp, _pdbl, _pdbl]),
+    "ccz_rcca_solve": (_int, [_vp, _vp, _i64, _pi64, _pdbl, _int, _int, _vp, _vp, _vp, _pint]),
+    "ccz_mcca_solve": (_int, [_vp, _vp, _i64, _pi64, _int, _pdbl, _dbl, _int, _int, _vp, _vp, _vp, _pint]),
+    "ccz_gcca_solve": (_int, [_vp, _vp, _i64, _pi64, _int, _pdbl, _pdbl, _dbl, _int, _int, _vp, _vp, _vp, _pint]),
+    "ccz_syevj": (_int, [_vp, _vp, _i64, _vp, _vp, _pint]),
+    "ccz_gesvj": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _pint]),
+    "ccz_gevp_topk": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _vp]),
+    "ccz_svd_topk": (_int, [_vp, _vp, _i64, _i64, _int, _vp, _vp, _vp]),
+    "ccz_whitener": (_int, [_vp, _vp, _i64, _i64, _dbl, _vp, _vp, _pi64]),
+    "ccz_inv_sqrtm": (_int, [_vp, _vp, _i64, _dbl, _vp]),
+    "ccz_potrf_lower": (_int, [_vp, _vp, _i64, _i64]),
+    "ccz_trsm_right_lower": (_int, [_vp, _int, _i64, _i64, _vp, _i64, _vp, _i64]),
+    "ccz_gemm_f64": (_int, [_vp, _int, _int, _i64, _i64, _i64, _dbl, _vp, _i64, _vp, _i64, _dbl, _vp, _i64]),
+    "ccz_cca_loss": (_int, [_vp, _int, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _dbl, _vp, _vp, _vp, _i64, _i64]),
+    "ccz_transform": (_int, [_vp, _int, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _i64]),
+}
+
+
+def bind(cdll, strict=True):
+    """Attach argtypes/restype for every declared symbol; ``strict`` demands all of them."""
+    missing = []
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(cdll, name)
+        except AttributeError:
+            missing.append(name)
+            continue
+        fn.restype = res
+        fn.argtypes = args
+    if strict and missing:
+        raise CCZError(f"libccz is missing symbols: {missing}")
+    return cdll
+
+
+def library_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libccz.so")
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def library():
+    """Load (once) the HIP library.  Fails loudly -- there is no fallback path."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            path = library_path()
+            if not os.path.exists(path):
+                raise CCZError(
+                    f"{path} not found: build it with `python -m cca_zoo_amd.csrc.build` "
+                    "(hipcc --offload-arch=gfx950).  cca_zoo_amd has no CPU fallback."
+                )
+            try:
+                _lib = bind(C.CDLL(path), strict=True)
+            except OSError as e:  # pragma: no cover - depends on the box
+                raise CCZError(f"cannot load {path}: {e}") from e
+    return _lib
+
+
+def _ptr(x):
+    """void* of a numpy array / int / None."""
+    if x is None:
+        return None
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data_as(C.c_void_p)
+    return C.c_void_p(int(x))
+
+
+class Handle:
+    """One device + one stream + scratch pool.  Not thread-safe."""
+
+    def __init__(self, device=0, lib=None):
+        self.lib = lib if lib is not None else library()
+        h = C.c_void_p()
+        rc = self.lib.ccz_create(C.byref(h), int(device))
+        if rc != 0:
+            raise _ERRORS.get(rc, RuntimeError)(
+                f"ccz_create(device={device}) failed with code {rc} "
+                "(is an MI355X visible? cca_zoo_amd has no CPU fallback)"
+            )
+        self._h = h
+        self.device = int(device)
+
+    # -- plumbing --------------------------------------------------------------
+    def check(self, rc):
+        if rc != 0:
+            msg = self.lib.ccz_last_error(self._h)
+            msg = msg.decode("utf-8", "replace") if msg else ""
+            raise _ERRORS.get(rc, RuntimeError)(f"libccz: {msg} (code {rc})")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.ccz_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def raw(self):
+        return self._h
+
+    def set_stream(self, stream_ptr):
+        self.check(self.lib.ccz_set_stream(self._h, _ptr(stream_ptr)))
+
+    def sync(self):
+        self.check(self.lib.ccz_sync(self._h))
+
+    def device_info(self):
+        info = DevInfo()
+        self.check(self.lib.ccz_device_info(self._h, C.byref(info)))
+        return {
+            "name": info.name.decode(), "arch": info.arch.decode(),
+            "compute_units": info.compute_units, "wavefront": info.wavefront,
+            "hbm_bytes": info.hbm_bytes, "lds_bytes_per_cu": info.lds_bytes_per_cu,
+        }
+
+    # -- device memory ------------------------------------------------------------
+    def alloc(self, nbytes):
+        p = C.c_void_p()
+        self.check(self.lib.ccz_dev_alloc(self._h, C.byref(p), int(nbytes)))
+        return DeviceBuffer(self, p.value, int(nbytes))
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        buf = self.alloc(max(arr.nbytes, 8))
+        self.check(self.lib.ccz_memcpy_h2d(self._h, _ptr(buf.ptr), _ptr(arr), arr.nbytes))
+        buf.shape, buf.dtype = arr.shape, arr.dtype
+        return buf
+
+    def to_host(self, buf, shape, dtype=np.float64, offset_bytes=0):
+        out = np.empty(shape, dtype=dtype)
+        self.check(self.lib.ccz_memcpy_d2h(self._h, _ptr(out), _ptr(buf.ptr + offset_bytes if isinstance(buf, DeviceBuffer) else int(buf) + offset_bytes), out.nbytes))
+        return out
+
+    # -- K1 ---------------------------------------------------------------------------
+    def moments(self, views, n_rows, dtype, on_device, moments_ptr, accumulate=False):
+        """views: list of (ptr_or_ndarray, cols, ld)."""
+        arr = (View * len(views))()
+        keep = []
+        for i, (data, cols, ld) in enumerate(views):
+            if isinstance(data, np.ndarray):
+                keep.append(data)
+                arr[i].data = data.ctypes.data
+            else:
+                arr[i].data = int(data)
+            arr[i].cols, arr[i].ld = int(cols), int(ld)
+        self.check(self.lib.ccz_moments(self._h, int(dtype), arr, len(views), int(n_rows),
+                                        1 if on_device else 0, _ptr(moments_ptr), 1 if accumulate else 0))
+
+    def moments_symmetrize(self, moments_ptr, D):
+        self.check(self.lib.ccz_moments_symmetrize(self._h, _ptr(moments_ptr), int(D)))
+
+    def moments_last_ms(self):
+        g, s = C.c_double(), C.c_double()
+        self.check(self.lib.ccz_moments_last_ms(self._h, C.byref(g), C.byref(s)))
+        return g.value, s.value
+
+    # -- fused solves ----------------------------------------------------------------------
+    def _solve_out(self, dims, k):
+        D = int(sum(dims))
+        kk = int(min(k, D))
+        return np.zeros(D * kk), np.zeros(D), np.zeros(kk), C.c_int(0)
+
+    @staticmethod
+    def _split(W, dims, kk):
+        out, o = [], 0
+        for d in dims:
+            out.append(W[o:o + d * kk].reshape(d, kk).copy())
+            o += d * kk
+        return out
+
+    def rcca_solve(self, moments_ptr, n, dims, c, center, k):
+        dims_a = (C.c_int64 * 2)(*[int(d) for d in dims])
+        c_a = (C.c_double * 2)(*[float(v) for v in c])
+        W, mu, vals, kout = self._solve_out(dims, k)
+        self.check(self.lib.ccz_rcca_solve(self._h, _ptr(moments_ptr), int(n), dims_a, c_a, int(bool(center)),
+                                           int(k), _ptr(W), _ptr(mu), _ptr(vals), C.byref(kout)))
+        kk = kout.value
+        return self._split(W, dims, kk), np.split(mu, np.cumsum(dims)[:-1]), vals[:kk]
+
+    def mcca_solve(self, moments_ptr, n, dims, c, eps, center, k):
+        m = len(dims)
+        dims_a = (C.c_int64 * m)(*[int(d) for d in dims])
+        c_a = (C.c_double * m)(*[float(v) for v in c])
+        W, mu, vals, kout = self._solve_out(dims, k)
+        self.check(self.lib.ccz_mcca_solve(self._h, _ptr(moments_ptr), int(n), dims_a, m, c_a, float(eps),
+                                           int(bool(center)), int(k), _ptr(W), _ptr(mu), _ptr(vals), C.byref(kout)))
+        kk = kout.value
+        return self._split(W, dims, kk), np.split(mu, np.cumsum(dims)[:-1]), vals[:kk]
+
+    def gcca_solve(self, moments_ptr, n, dims, c, view_weights, eps, center, k):
+        m = len(dims)
+        dims_a = (C.c_int64 * m)(*[int(d) for d in dims])
+        c_a = (C.c_double * m)(*[float(v) for v in c])
+        w_a = (C.c_double * m)(*[float(v) for v in view_weights])
+        W, mu, vals, kout = self._solve_out(dims, k)
+        self.check(self.lib.ccz_gcca_solve(self._h, _ptr(moments_ptr), int(n), dims_a, m, c_a, w_a, float(eps),
+                                           int(bool(center)), int(k), _ptr(W), _ptr(mu), _ptr(vals), C.byref(kout)))
+        kk = kout.value
+        return self._split(W, dims, kk), np.split(mu, np.cumsum(dims)[:-1]), vals[:kk]
+
+
+class DeviceBuffer:
+    """Owning wrapper of a ``ccz_dev_alloc`` allocation."""
+
+    def __init__(self, handle, ptr, nbytes):
+        self.handle, self.ptr, self.nbytes = handle, ptr, nbytes
+        self.shape, self.dtype = None, None
+
+    def free(self):
+        if self.ptr and self.handle is not None and getattr(self.handle, "_h", None):
+            self.handle.lib.ccz_dev_free(self.handle._h, C.c_void_p(self.ptr))
+        self.ptr = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def __int__(self):
+        return int(self.ptr)
+
+
+_default = {}
+
+
+def default_handle(device=None):
+    """Process-wide handle per device (created on first use)."""
+    if device is None:
+        device = int(os.environ.get("CCZ_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    h = _default.get(device)
+    if h is None:
+        h = _default[device] = Handle(device)
+    return h

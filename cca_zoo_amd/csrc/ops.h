@@ -1,0 +1,130 @@
+// Internal device-op interface of libccz.
+//
+// The solver drivers (solve.cpp: Cholesky whitening, Chebyshev-filtered
+// subspace iteration, rCCA/MCCA/GCCA assembly) are plain C++ written against
+// this header only.  The product implementation is ops_hip.hip (HIP kernels on
+// gfx950).  tests/hostsim/ops_host.cpp implements the same interface with
+// host loops so that the driver LOGIC can be unit-tested in a container
+// without a GPU; that library is test infrastructure and is never loaded by
+// the cca_zoo_amd package.
+//
+// All matrices: row-major float64 in device memory, leading dimension in
+// elements.  Functions throw ccz::Error; the C ABI layer converts to codes.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/ccz.h"
+
+struct ccz_ctx {
+  int device = 0;
+  void* stream = nullptr;  // hipStream_t
+  std::string err;
+  double last_gram_ms = 0.0;
+  double last_colsum_ms = 0.0;
+  void* impl = nullptr;    // backend-private (memory pool, events, device props)
+};
+
+namespace ccz {
+
+struct Error {
+  int code;
+  std::string msg;
+};
+[[noreturn]] void fail(int code, const char* fmt, ...);
+
+// ---- memory (pooled in the handle) ----------------------------------------
+void* dev_alloc(ccz_ctx* c, size_t bytes);
+void dev_free(ccz_ctx* c, void* p);
+void h2d(ccz_ctx* c, void* dst, const void* src, size_t bytes);
+void d2h(ccz_ctx* c, void* dst, const void* src, size_t bytes);  // synchronises the stream
+void d2d(ccz_ctx* c, void* dst, const void* src, size_t bytes);
+void zero(ccz_ctx* c, void* dst, size_t bytes);
+void sync(ccz_ctx* c);
+
+// RAII device buffer of doubles
+class DBuf {
+ public:
+  DBuf() = default;
+  DBuf(ccz_ctx* c, int64_t n) : c_(c), n_(n) { p_ = n > 0 ? static_cast<double*>(dev_alloc(c, size_t(n) * 8)) : nullptr; }
+  DBuf(const DBuf&) = delete;
+  DBuf& operator=(const DBuf&) = delete;
+  DBuf(DBuf&& o) noexcept : c_(o.c_), p_(o.p_), n_(o.n_) { o.p_ = nullptr; o.n_ = 0; }
+  DBuf& operator=(DBuf&& o) noexcept {
+    if (this != &o) { reset(); c_ = o.c_; p_ = o.p_; n_ = o.n_; o.p_ = nullptr; o.n_ = 0; }
+    return *this;
+  }
+  ~DBuf() { reset(); }
+  void reset() { if (p_) dev_free(c_, p_); p_ = nullptr; n_ = 0; }
+  double* get() const { return p_; }
+  operator double*() const { return p_; }
+  int64_t size() const { return n_; }
+ private:
+  ccz_ctx* c_ = nullptr;
+  double* p_ = nullptr;
+  int64_t n_ = 0;
+};
+
+// ---- dense float64 ops ------------------------------------------------------
+// C (M x N) = alpha * op(A) * op(B) + beta * C
+void gemm(ccz_ctx* c, bool tA, bool tB, int64_t M, int64_t N, int64_t K, double alpha,
+          const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C,
+          int64_t ldc);
+// in-place lower Cholesky of the d x d leading block (upper part left untouched).
+// returns 0, or j+1 if pivot j was not positive (matrix content then undefined).
+int potrf_lower(ccz_ctx* c, double* A, int64_t d, int64_t lda);
+// X (r x d) <- X L^-T (trans) or X L^-1 (!trans); L lower triangular d x d
+void trsm_right_lower(ccz_ctx* c, bool trans, int64_t r, int64_t d, const double* L, int64_t ldl,
+                      double* X, int64_t ldx);
+// out (cols x rows) = in (rows x cols)'
+void transpose(ccz_ctx* c, int64_t rows, int64_t cols, const double* in, int64_t ldi, double* out,
+               int64_t ldo);
+void copy2d(ccz_ctx* c, int64_t rows, int64_t cols, const double* in, int64_t ldi, double* out,
+            int64_t ldo);
+// A = alpha * A + beta * B   (elementwise, rows x cols); B may be null when beta == 0
+void axpby2d(ccz_ctx* c, int64_t rows, int64_t cols, double alpha, double* A, int64_t lda,
+             double beta, const double* B, int64_t ldb);
+void fill2d(ccz_ctx* c, int64_t rows, int64_t cols, double* A, int64_t lda, double value);
+void add_diag(ccz_ctx* c, int64_t d, double* A, int64_t lda, double value);
+// A[:, j] *= v[j]  (mode 0) ;  A[:, j] /= v[j] (mode 1) ; A[:, j] /= sqrt(v[j]) (mode 2)
+void scale_cols(ccz_ctx* c, int64_t rows, int64_t cols, double* A, int64_t lda, const double* v,
+                int mode);
+// make the lower triangle equal to the upper one: A[i][j] = A[j][i] for i > j
+void mirror_upper(ccz_ctx* c, int64_t d, double* A, int64_t lda);
+// out (rows x cols) = alpha * ( G[r0+i][c0+j] - (centre ? s[r0+i] s[c0+j] / n : 0) );
+// G is D x D (ld D) SYMMETRIC-COMPLETE, s has D entries
+void cov_block(ccz_ctx* c, const double* G, int64_t D, const double* s, int64_t n, bool centre,
+               double alpha, int64_t r0, int64_t rows, int64_t c0, int64_t cols, double* out,
+               int64_t ldo);
+// deterministic pseudo-normal fill (counter-based hash; identical on every backend)
+void randn_fill(ccz_ctx* c, int64_t rows, int64_t cols, double* A, int64_t lda, uint64_t seed);
+// out[j] = sum_i A[i][j]^2   (column squared norms), out has `cols` entries
+void col_sqnorms(ccz_ctx* c, int64_t rows, int64_t cols, const double* A, int64_t lda, double* out);
+// max_i sum_j |A[i][j]|  (infinity norm) -> host value
+double norm_inf(ccz_ctx* c, int64_t rows, int64_t cols, const double* A, int64_t lda);
+
+// One-sided (Hestenes) Jacobi on the ROWS of W (p x q): finds the orthogonal
+// rotation sequence J with J W having mutually orthogonal rows, applies the
+// same rotations to the rows of Q (p x qc) when Q != null.  Returns sweeps
+// used; throws ENOCONV beyond max_sweeps.
+int jacobi_rows(ccz_ctx* c, int64_t p, int64_t q, double* W, int64_t ldw, double* Q, int64_t qc,
+                int64_t ldq, int max_sweeps);
+// out[i] = dot(A[i,:], B[i,:]) for i < rows
+void row_dots(ccz_ctx* c, int64_t rows, int64_t cols, const double* A, int64_t lda,
+              const double* B, int64_t ldb, double* out);
+// out[i,:] = in[perm[i],:] * scale[i]   (perm, scale are HOST arrays; scale may be null)
+void gather_rows(ccz_ctx* c, int64_t rows, int64_t cols, const double* in, int64_t ldi,
+                 const int64_t* perm_host, const double* scale_host, double* out, int64_t ldo);
+
+// ---- solver drivers (solve.cpp) used by other translation units -------------
+// full symmetric EVD of A (d x d, destroyed): w_host (d, descending), V rows = eigenvectors
+int syev_full(ccz_ctx* c, double* A, int64_t d, std::vector<double>& w_host, double* Vrows,
+              int64_t ldv);
+// SPD solve helpers: given lower Cholesky factor L (d x d), X (d x r) <- (L L')^-1 X
+void chol_solve_inplace(ccz_ctx* c, int64_t d, int64_t r, const double* L, int64_t ldl, double* X,
+                        int64_t ldx);
+
+}  // namespace ccz

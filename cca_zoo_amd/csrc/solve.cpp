@@ -1,0 +1,888 @@
+// libccz solver drivers: everything after the second moments exist.
+//
+//   moments (G | s)  ->  covariance blocks  ->  Cholesky whitening (ridge / eps floor)
+//                    ->  top-k eigen / singular problem in whitened coordinates
+//                        (Chebyshev-filtered subspace iteration + Jacobi Rayleigh-Ritz,
+//                         full one-sided Jacobi as the robust fallback)
+//                    ->  back-projection to weights
+//
+// Plain C++ over the device-op interface in ops.h (HIP kernels in the product
+// build).  Reference semantics (file:line relative to the reference root) are
+// cited per driver; the dense NumPy statement of the same maths is
+// oracle/gram_form.py.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <numeric>
+#include <vector>
+
+#include "ops.h"
+
+namespace ccz {
+
+void fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  throw Error{code, std::string(buf)};
+}
+
+namespace {
+
+constexpr double kRankTol = 64.0 * 2.220446049250313e-16;  // relative eigenvalue floor (fallbacks)
+constexpr int64_t kDirectMax = 192;                        // full Jacobi below this size
+constexpr int kMaxSweeps = 60;
+
+std::vector<int64_t> offsets(const int64_t* dims, int m) {
+  std::vector<int64_t> off(m + 1, 0);
+  for (int i = 0; i < m; ++i) off[i + 1] = off[i] + dims[i];
+  return off;
+}
+
+// ---------------------------------------------------------------------------
+// full decompositions by one-sided Jacobi
+// ---------------------------------------------------------------------------
+}  // namespace
+
+// Symmetric EVD.  The rows of (A + shift I) are orthogonalised; the accumulated
+// rotations are the eigenvectors.  shift = ||A||_inf makes the matrix positive
+// definite so that +lam / -lam pairs (MCCA with two views has them exactly)
+// cannot mix; pass psd=true to skip it and keep relative accuracy of small
+// eigenvalues of a covariance / Gram matrix.
+static int syev_full_impl(ccz_ctx* c, double* A, int64_t d, bool psd, std::vector<double>& w,
+                          double* Vrows, int64_t ldv) {
+  double shift = 0.0;
+  if (!psd) {
+    shift = norm_inf(c, d, d, A, d);
+    if (!(shift >= 0.0) || !std::isfinite(shift)) fail(CCZ_EINVAL, "syev: matrix has non-finite entries");
+    shift *= 1.0 + 1e-3;
+    if (shift > 0.0) add_diag(c, d, A, d, shift);
+  }
+  DBuf Q(c, d * d);
+  fill2d(c, d, d, Q, d, 0.0);
+  add_diag(c, d, Q, d, 1.0);
+  int sweeps = jacobi_rows(c, d, d, A, d, Q, d, d, kMaxSweeps);
+  DBuf lam(c, d);
+  row_dots(c, d, d, A, d, Q, d, lam);
+  std::vector<double> lh(d);
+  d2h(c, lh.data(), lam, size_t(d) * 8);
+  for (auto& v : lh) v -= shift;
+  std::vector<int64_t> perm(d);
+  std::iota(perm.begin(), perm.end(), 0);
+  std::stable_sort(perm.begin(), perm.end(), [&](int64_t a, int64_t b) { return lh[a] > lh[b]; });
+  w.resize(d);
+  for (int64_t i = 0; i < d; ++i) w[i] = lh[perm[i]];
+  if (Vrows) gather_rows(c, d, d, Q, d, perm.data(), nullptr, Vrows, ldv);
+  return sweeps;
+}
+
+int syev_full(ccz_ctx* c, double* A, int64_t d, std::vector<double>& w, double* Vrows, int64_t ldv) {
+  return syev_full_impl(c, A, d, false, w, Vrows, ldv);
+}
+
+namespace {
+
+// Thin SVD of A (p x q) by one-sided Jacobi.  Returns row-form factors:
+// Ut (r x p) rows = left vectors, s (r, descending, host), Vt (r x q).
+int gesvj_rows(ccz_ctx* c, const double* A, int64_t p, int64_t q, int64_t lda, double* Ut,
+               std::vector<double>& s, double* Vt) {
+  const bool tall = p > q;
+  const int64_t r = tall ? q : p, l = tall ? p : q;
+  DBuf W(c, r * l);
+  if (tall) transpose(c, p, q, A, lda, W, l); else copy2d(c, p, q, A, lda, W, l);
+  DBuf Q(c, r * r);
+  fill2d(c, r, r, Q, r, 0.0);
+  add_diag(c, r, Q, r, 1.0);
+  int sweeps = jacobi_rows(c, r, l, W, l, Q, r, r, kMaxSweeps);
+  DBuf nn(c, r);
+  row_dots(c, r, l, W, l, W, l, nn);
+  std::vector<double> nh(r);
+  d2h(c, nh.data(), nn, size_t(r) * 8);
+  std::vector<int64_t> perm(r);
+  std::iota(perm.begin(), perm.end(), 0);
+  std::stable_sort(perm.begin(), perm.end(), [&](int64_t a, int64_t b) { return nh[a] > nh[b]; });
+  s.resize(r);
+  std::vector<double> inv(r);
+  const double tiny = nh.empty() ? 0.0 : std::max(nh[perm[0]], 0.0) * 1e-300;
+  for (int64_t i = 0; i < r; ++i) {
+    double v = std::sqrt(std::max(nh[perm[i]], 0.0));
+    s[i] = v;
+    inv[i] = (v > tiny && v > 0.0) ? 1.0 / v : 0.0;
+  }
+  // long side: normalised rows of W; short side: rows of Q
+  double* longf = tall ? Ut : Vt;
+  double* shortf = tall ? Vt : Ut;
+  if (longf) gather_rows(c, r, l, W, l, perm.data(), inv.data(), longf, l);
+  if (shortf) gather_rows(c, r, r, Q, r, perm.data(), nullptr, shortf, r);
+  return sweeps;
+}
+
+// ---------------------------------------------------------------------------
+// orthonormalisation of the columns of X (p x b): Cholesky-QR, two passes
+// ---------------------------------------------------------------------------
+bool cholqr_pass(ccz_ctx* c, int64_t p, int64_t b, double* X, int64_t ldx, double rel_shift) {
+  DBuf Gm(c, b * b);
+  gemm(c, true, false, b, b, p, 1.0, X, ldx, X, ldx, 0.0, Gm, b);
+  if (rel_shift > 0.0) {
+    std::vector<double> gh(size_t(b) * b);
+    d2h(c, gh.data(), Gm, gh.size() * 8);
+    double tr = 0.0;
+    for (int64_t i = 0; i < b; ++i) tr += gh[i * b + i];
+    add_diag(c, b, Gm, b, rel_shift * tr / double(b));
+  }
+  if (potrf_lower(c, Gm, b, b) != 0) return false;
+  trsm_right_lower(c, true, p, b, Gm, b, X, ldx);
+  return true;
+}
+
+void orthonormalize(ccz_ctx* c, int64_t p, int64_t b, double* X, int64_t ldx) {
+  // pass 1 may meet a numerically singular Gram (filtered block nearly rank deficient):
+  // retry with a growing diagonal shift; pass 2/3 restore orthogonality.
+  double shift = 0.0;
+  for (int attempt = 0; attempt < 6; ++attempt) {
+    if (cholqr_pass(c, p, b, X, ldx, shift)) {
+      if (!cholqr_pass(c, p, b, X, ldx, 0.0)) { shift = shift > 0 ? shift * 100 : 1e-14; continue; }
+      if (shift > 0.0 && !cholqr_pass(c, p, b, X, ldx, 0.0)) { shift *= 100; continue; }
+      return;
+    }
+    shift = shift > 0 ? shift * 100 : 1e-14;
+  }
+  fail(CCZ_ENOCONV, "orthonormalisation failed (block of %lld vectors is rank deficient)", (long long)b);
+}
+
+// ---------------------------------------------------------------------------
+// top-k eigenpairs (largest algebraic) of a symmetric operator
+// ---------------------------------------------------------------------------
+struct SymOp {
+  int64_t p;
+  double lower;  // a proven lower bound of the spectrum
+  std::function<void(const double* X, int64_t ldx, int64_t b, double* Y, int64_t ldy)> apply;
+};
+
+struct RitzState {
+  std::vector<double> theta;   // b Ritz values, descending
+  std::vector<double> resid;   // b residual norms
+};
+
+// Rayleigh-Ritz on span(X): X <- X C, Y <- (S X) C, theta, residual norms.
+void rayleigh_ritz(ccz_ctx* c, const SymOp& op, int64_t b, double* X, double* Y, double* tmp,
+                   RitzState& st) {
+  const int64_t p = op.p;
+  op.apply(X, b, b, Y, b);
+  DBuf H(c, b * b), Hs(c, b * b), Vr(c, b * b);
+  gemm(c, true, false, b, b, p, 1.0, X, b, Y, b, 0.0, H, b);
+  transpose(c, b, b, H, b, Hs, b);
+  axpby2d(c, b, b, 0.5, H, b, 0.5, Hs, b);            // symmetrise
+  syev_full_impl(c, H, b, false, st.theta, Vr, b);      // rows of Vr = Ritz coefficient vectors
+  gemm(c, false, true, p, b, b, 1.0, X, b, Vr, b, 0.0, tmp, b);
+  d2d(c, X, tmp, size_t(p) * b * 8);
+  gemm(c, false, true, p, b, b, 1.0, Y, b, Vr, b, 0.0, tmp, b);
+  d2d(c, Y, tmp, size_t(p) * b * 8);
+  // residual R = Y - X diag(theta)
+  DBuf th(c, b), rn(c, b);
+  h2d(c, th, st.theta.data(), size_t(b) * 8);
+  d2d(c, tmp, X, size_t(p) * b * 8);
+  scale_cols(c, p, b, tmp, b, th, 0);
+  axpby2d(c, p, b, -1.0, tmp, b, 1.0, Y, b);          // tmp = Y - X theta
+  col_sqnorms(c, p, b, tmp, b, rn);
+  st.resid.resize(b);
+  d2h(c, st.resid.data(), rn, size_t(b) * 8);
+  for (auto& v : st.resid) v = std::sqrt(std::max(v, 0.0));
+}
+
+// Degree-m Chebyshev filter damping [a, cut], scaled at aL (Zhou & Saad).
+// In: X (p x b).  Out: result left in X.  Y, Z are work blocks.
+void chebyshev_filter(ccz_ctx* c, const SymOp& op, int64_t b, int m, double a, double cut,
+                      double aL, double* X, double* Y, double* Z) {
+  const int64_t p = op.p;
+  const double e = 0.5 * (cut - a), c0 = 0.5 * (cut + a);
+  double sigma1 = e / (aL - c0);
+  double sigma = sigma1;
+  const double tau = 2.0 / sigma1;
+  op.apply(X, b, b, Y, b);
+  axpby2d(c, p, b, sigma1 / e, Y, b, -c0 * sigma1 / e, X, b);   // Y = (S X - c0 X) sigma1/e
+  for (int i = 2; i <= m; ++i) {
+    const double sn = 1.0 / (tau - sigma);
+    op.apply(Y, b, b, Z, b);
+    axpby2d(c, p, b, 2.0 * sn / e, Z, b, -c0 * 2.0 * sn / e, Y, b);
+    axpby2d(c, p, b, 1.0, Z, b, -sigma * sn, X, b);              // Z -= sigma sn X
+    d2d(c, X, Y, size_t(p) * b * 8);
+    d2d(c, Y, Z, size_t(p) * b * 8);
+    sigma = sn;
+  }
+  d2d(c, X, Y, size_t(p) * b * 8);
+}
+
+// Returns theta (k, descending) on the host and the eigenvectors as the first k
+// COLUMNS of Xout (p x k, ld k).
+void topk_symmetric(ccz_ctx* c, const SymOp& op, int k, std::vector<double>& theta, double* Xout) {
+  const int64_t p = op.p;
+  if (k > p) k = int(p);
+  int64_t b = std::min<int64_t>(p, k + std::max(8, k / 4));
+  DBuf X(c, p * b), Y(c, p * b), Z(c, p * b);
+  randn_fill(c, p, b, X, b, 0x9E3779B97F4A7C15ull);
+  orthonormalize(c, p, b, X, b);
+  RitzState st;
+  rayleigh_ritz(c, op, b, X, Y, Z, st);
+  const double tol = 1e-11;
+  const int max_cycles = 200;
+  int degree = 8;
+  double prev_worst = 1e300;
+  for (int cycle = 0; cycle < max_cycles; ++cycle) {
+    const double scale = std::max({std::fabs(st.theta.front()), std::fabs(st.theta.back()), 1e-300});
+    double worst = 0.0;
+    for (int i = 0; i < k; ++i) worst = std::max(worst, st.resid[i]);
+    if (worst <= tol * scale) {
+      theta.assign(st.theta.begin(), st.theta.begin() + k);
+      copy2d(c, p, k, X, b, Xout, k);
+      return;
+    }
+    if (b == p) break;  // the block spans everything: Rayleigh-Ritz was already exact
+    // slow progress -> raise the filter degree
+    if (worst > 0.1 * prev_worst && degree < 40) degree += 4;
+    prev_worst = worst;
+    double aL = st.theta.front();
+    double cut = st.theta.back();
+    double a = std::min(op.lower, cut - 1e-3 * std::max(aL - cut, 1e-12 * scale));
+    if (!(aL > cut)) aL = cut + 1e-8 * scale;
+    if (!(cut > a)) cut = a + 1e-8 * scale;
+    chebyshev_filter(c, op, b, degree, a, cut, aL, X, Y, Z);
+    orthonormalize(c, p, b, X, b);
+    rayleigh_ritz(c, op, b, X, Y, Z, st);
+  }
+  double worst = 0.0;
+  for (int i = 0; i < k; ++i) worst = std::max(worst, st.resid[i]);
+  const double scale = std::max({std::fabs(st.theta.front()), std::fabs(st.theta.back()), 1e-300});
+  if (b == p || worst <= 1e-8 * scale) {
+    theta.assign(st.theta.begin(), st.theta.begin() + k);
+    copy2d(c, p, k, X, b, Xout, k);
+    return;
+  }
+  fail(CCZ_ENOCONV, "subspace iteration stalled (residual %.3e, scale %.3e)", worst, scale);
+}
+
+// top-k eigenpairs of a dense symmetric S (p x p): rows-form output Vt (k x p).
+void eig_topk_dense(ccz_ctx* c, const double* S, int64_t p, int k, std::vector<double>& lam,
+                    double* Vt, int64_t ldvt) {
+  k = int(std::min<int64_t>(k, p));
+  bool direct = p <= kDirectMax || int64_t(k) * 3 >= p;
+  if (!direct) {
+    SymOp op;
+    op.p = p;
+    op.lower = -norm_inf(c, p, p, S, p);
+    op.apply = [c, S, p](const double* X, int64_t ldx, int64_t b, double* Y, int64_t ldy) {
+      gemm(c, false, false, p, b, p, 1.0, S, p, X, ldx, 0.0, Y, ldy);
+    };
+    try {
+      DBuf Xk(c, p * k);
+      topk_symmetric(c, op, k, lam, Xk);
+      transpose(c, p, k, Xk, k, Vt, ldvt);
+      return;
+    } catch (const Error& e) {
+      if (e.code != CCZ_ENOCONV) throw;
+      direct = true;  // robust fallback below
+    }
+  }
+  DBuf A(c, p * p), V(c, p * p);
+  d2d(c, A, S, size_t(p) * p * 8);
+  std::vector<double> w;
+  syev_full_impl(c, A, p, false, w, V, p);
+  lam.assign(w.begin(), w.begin() + k);
+  copy2d(c, k, p, V, p, Vt, ldvt);
+}
+
+// top-k singular triplets of T given as Tt = T' (q x p, row-major, ld p) -- i.e. T is p x q.
+// Row-form outputs: Ut (k x p), Vt (k x q), s (k, host).
+void svd_topk_dense(ccz_ctx* c, const double* Tt, int64_t p, int64_t q, int k,
+                    std::vector<double>& s, double* Ut, double* Vt) {
+  const int64_t r = std::min(p, q);
+  k = int(std::min<int64_t>(k, r));
+  bool direct = r <= kDirectMax || int64_t(k) * 3 >= r;
+  if (!direct) {
+    // eigenproblem of T T' (p x p) if p <= q else T' T (q x q); M = matrix whose rows index the
+    // small side: small side p: S = T T' = Tt' Tt ; small side q: S = T' T = Tt Tt'
+    const bool small_p = p <= q;
+    const int64_t ns = small_p ? p : q, nl = small_p ? q : p;
+    SymOp op;
+    op.p = ns;
+    op.lower = 0.0;
+    DBuf work(c, nl * (k + std::max(8, k / 4)));
+    double* wk = work;
+    op.apply = [c, Tt, p, q, small_p, nl, ns, wk](const double* X, int64_t ldx, int64_t b, double* Y, int64_t ldy) {
+      if (small_p) {  // Y = Tt' (Tt X):  Tt is q x p
+        gemm(c, false, false, q, b, p, 1.0, Tt, p, X, ldx, 0.0, wk, b);
+        gemm(c, true, false, p, b, q, 1.0, Tt, p, wk, b, 0.0, Y, ldy);
+      } else {        // Y = Tt (Tt' X)
+        gemm(c, true, false, p, b, q, 1.0, Tt, p, X, ldx, 0.0, wk, b);
+        gemm(c, false, false, q, b, p, 1.0, Tt, p, wk, b, 0.0, Y, ldy);
+      }
+      (void)nl; (void)ns;
+    };
+    try {
+      std::vector<double> lam;
+      DBuf Xk(c, ns * k);
+      topk_symmetric(c, op, k, lam, Xk);
+      s.resize(k);
+      std::vector<double> inv(k);
+      for (int i = 0; i < k; ++i) {
+        s[i] = std::sqrt(std::max(lam[i], 0.0));
+        inv[i] = s[i] > 0.0 ? 1.0 / s[i] : 0.0;
+      }
+      DBuf other(c, nl * k), invd(c, k);
+      h2d(c, invd, inv.data(), size_t(k) * 8);
+      if (small_p) {  // Xk = U (p x k); V = T' U / s = Tt U / s  (q x k)
+        gemm(c, false, false, q, k, p, 1.0, Tt, p, Xk, k, 0.0, other, k);
+        scale_cols(c, q, k, other, k, invd, 0);
+        transpose(c, p, k, Xk, k, Ut, p);
+        transpose(c, q, k, other, k, Vt, q);
+      } else {        // Xk = V (q x k); U = T V / s = Tt' V / s (p x k)
+        gemm(c, true, false, p, k, q, 1.0, Tt, p, Xk, k, 0.0, other, k);
+        scale_cols(c, p, k, other, k, invd, 0);
+        transpose(c, q, k, Xk, k, Vt, q);
+        transpose(c, p, k, other, k, Ut, p);
+      }
+      return;
+    } catch (const Error& e) {
+      if (e.code != CCZ_ENOCONV) throw;
+      direct = true;
+    }
+  }
+  // full Jacobi SVD of Tt (q x p):  Tt = A B' with left (q-side) = V of T, right (p-side) = U of T
+  const int64_t rr = std::min(p, q);
+  DBuf Lq(c, rr * q), Rp(c, rr * p);
+  std::vector<double> sv;
+  gesvj_rows(c, Tt, q, p, p, Lq, sv, Rp);
+  s.assign(sv.begin(), sv.begin() + k);
+  copy2d(c, k, q, Lq, q, Vt, q);
+  copy2d(c, k, p, Rp, p, Ut, p);
+}
+
+// ---------------------------------------------------------------------------
+// whitening factors  F (d x r),  F' R F = I
+// ---------------------------------------------------------------------------
+struct Whitener {
+  int64_t d = 0, r = 0;
+  bool chol = true;
+  DBuf L;  // chol: lower factor (d x d) ; else explicit F (d x r)
+
+  // X (m x d, ld ldx)  ->  X F   in place for chol (r == d); explicit: into out (m x r)
+  void right_apply(ccz_ctx* c, int64_t m, double* X, int64_t ldx, double* out, int64_t ldo) const {
+    if (chol) {
+      trsm_right_lower(c, true, m, d, L, d, X, ldx);
+      if (out != X) copy2d(c, m, d, X, ldx, out, ldo);
+    } else {
+      gemm(c, false, false, m, r, d, 1.0, X, ldx, L, r, 0.0, out, ldo);
+    }
+  }
+  // Ut (k x r) -> (F U)' = Ut F'  (k x d)
+  void back_project_rows(ccz_ctx* c, int64_t k, double* Ut, int64_t ldu, double* out, int64_t ldo) const {
+    if (chol) {
+      trsm_right_lower(c, false, k, d, L, d, Ut, ldu);
+      if (out != Ut) copy2d(c, k, d, Ut, ldu, out, ldo);
+    } else {
+      gemm(c, false, true, k, d, r, 1.0, Ut, ldu, L, r, 0.0, out, ldo);
+    }
+  }
+};
+
+// R (d x d, destroyed) -> Whitener.  allow_floor: on a failed Cholesky fall back to the
+// eigen-floored explicit factor (rCCA c = 0 on rank-deficient data); otherwise ENOTSPD.
+Whitener make_whitener(ccz_ctx* c, double* R, int64_t d, bool allow_floor) {
+  Whitener w;
+  w.d = d;
+  DBuf keep;
+  if (allow_floor) { keep = DBuf(c, d * d); d2d(c, keep, R, size_t(d) * d * 8); }
+  if (potrf_lower(c, R, d, d) == 0) {
+    w.chol = true;
+    w.r = d;
+    w.L = DBuf(c, d * d);
+    d2d(c, w.L, R, size_t(d) * d * 8);
+    return w;
+  }
+  if (!allow_floor) fail(CCZ_ENOTSPD, "regularised covariance block (%lld x %lld) is not positive definite", (long long)d, (long long)d);
+  std::vector<double> lam;
+  DBuf V(c, d * d);
+  syev_full_impl(c, keep, d, true, lam, V, d);
+  const double floor_ = kRankTol * double(d) * std::max(lam.empty() ? 0.0 : lam[0], 0.0);
+  int64_t r = 0;
+  while (r < d && lam[r] > floor_) ++r;
+  if (r == 0) fail(CCZ_ENOTSPD, "covariance block is numerically zero");
+  std::vector<int64_t> perm(r);
+  std::vector<double> sc(r);
+  for (int64_t i = 0; i < r; ++i) { perm[i] = i; sc[i] = 1.0 / std::sqrt(lam[i]); }
+  DBuf Ft(c, r * d);
+  gather_rows(c, r, d, V, d, perm.data(), sc.data(), Ft, d);
+  w.chol = false;
+  w.r = r;
+  w.L = DBuf(c, d * r);
+  transpose(c, r, d, Ft, d, w.L, r);
+  return w;
+}
+
+// eps-floor rule of the reference (linear/_mcca.py:170-172, linear/_gcca.py:102-104):
+// returns min eigenvalue info for a set of SPD-ish blocks R_i: shift = eps - min_eig if < eps.
+// Cheap certificate first: R - eps I positive definite  =>  min_eig >= eps  => no shift.
+double min_eig_if_below(ccz_ctx* c, const double* R, int64_t d, double cval, double eps) {
+  if (cval >= eps) return eps;  // (1-c) C + c I with C >= 0  =>  min eig >= c >= eps
+  DBuf T(c, d * d);
+  d2d(c, T, R, size_t(d) * d * 8);
+  add_diag(c, d, T, d, -eps);
+  if (potrf_lower(c, T, d, d) == 0) return eps;  // certified >= eps
+  d2d(c, T, R, size_t(d) * d * 8);
+  std::vector<double> lam;
+  syev_full_impl(c, T, d, true, lam, nullptr, 0);
+  return lam.back();
+}
+
+void means_out(ccz_ctx* c, const double* s_dev, int64_t D, int64_t n, bool center, double* means_host) {
+  if (!means_host) return;
+  if (center) {
+    d2h(c, means_host, s_dev, size_t(D) * 8);
+    for (int64_t i = 0; i < D; ++i) means_host[i] /= double(n);
+  } else {
+    std::fill(means_host, means_host + D, 0.0);
+  }
+}
+
+// rows-form device block Wt (k x d, ld ldw) -> host (d x k) row-major
+void rows_to_host_cols(ccz_ctx* c, const double* Wt, int64_t k, int64_t d, int64_t ldw, double scale,
+                       double* out_host) {
+  DBuf tmp(c, k * d);
+  copy2d(c, k, d, Wt, ldw, tmp, d);
+  std::vector<double> h(size_t(k) * d);
+  d2h(c, h.data(), tmp, h.size() * 8);
+  for (int64_t i = 0; i < d; ++i)
+    for (int64_t j = 0; j < k; ++j) out_host[i * k + j] = scale * h[j * d + i];
+}
+
+void check_common(const double* moments, int64_t n, const int64_t* dims, int m, int k) {
+  if (!moments || !dims) fail(CCZ_EINVAL, "null argument");
+  if (m < 2) fail(CCZ_EINVAL, "at least 2 views are required, got %d", m);
+  if (n < 2) fail(CCZ_EINVAL, "at least 2 samples are required, got %lld", (long long)n);
+  if (k < 1) fail(CCZ_EINVAL, "latent dimensions must be >= 1, got %d", k);
+  for (int i = 0; i < m; ++i)
+    if (dims[i] < 1) fail(CCZ_EINVAL, "view %d has no features", i);
+}
+
+}  // namespace
+
+void chol_solve_inplace(ccz_ctx* c, int64_t d, int64_t r, const double* L, int64_t ldl, double* X, int64_t ldx) {
+  DBuf Xt(c, r * d);
+  transpose(c, d, r, X, ldx, Xt, d);
+  trsm_right_lower(c, true, r, d, L, ldl, Xt, d);    // X' L^-T
+  trsm_right_lower(c, false, r, d, L, ldl, Xt, d);   // X' L^-T L^-1 = ((L L')^-1 X)'
+  transpose(c, r, d, Xt, d, X, ldx);
+}
+
+// ===========================================================================
+// rCCA / CCA / PLS      reference: cca_zoo/linear/_rcca.py:69-101
+// ===========================================================================
+static void rcca_solve_impl(ccz_ctx* c, const double* mom, int64_t n, const int64_t dims[2],
+                            const double cc[2], int center, int k, double* W_host, double* means_host,
+                            double* vals_host, int* k_out) {
+  check_common(mom, n, dims, 2, k);
+  for (int i = 0; i < 2; ++i)
+    if (!(cc[i] >= 0.0 && cc[i] <= 1.0)) fail(CCZ_EINVAL, "ridge parameter c[%d]=%g outside [0, 1]", i, cc[i]);
+  const int64_t d1 = dims[0], d2 = dims[1], D = d1 + d2;
+  const double* G = mom;
+  const double* s = mom + D * D;
+  const double inv = 1.0 / double(n - 1);
+  const bool ctr = center != 0;
+  // reference: k = min(latent, rank1, rank2); ranks are at most min(n, d)
+  int kk = int(std::min<int64_t>({int64_t(k), d1, d2, n}));
+
+  DBuf R1(c, d1 * d1), R2(c, d2 * d2), M12(c, d1 * d2);
+  cov_block(c, G, D, s, n, ctr, (1.0 - cc[0]) * inv, 0, d1, 0, d1, R1, d1);
+  add_diag(c, d1, R1, d1, cc[0]);
+  cov_block(c, G, D, s, n, ctr, (1.0 - cc[1]) * inv, d1, d2, d1, d2, R2, d2);
+  add_diag(c, d2, R2, d2, cc[1]);
+  cov_block(c, G, D, s, n, ctr, inv, 0, d1, d1, d2, M12, d2);
+
+  Whitener F1 = make_whitener(c, R1, d1, true);
+  Whitener F2 = make_whitener(c, R2, d2, true);
+  R1.reset();
+  R2.reset();
+  const int64_t r1 = F1.r, r2 = F2.r;
+  kk = int(std::min<int64_t>({int64_t(kk), r1, r2}));
+
+  // Y = M12 F2 (d1 x r2);  Tt = Y' F1 = (F1' M12 F2)'  (r2 x r1)
+  DBuf Y(c, d1 * r2);
+  F2.right_apply(c, d1, M12, d2, Y, r2);
+  DBuf Yt(c, r2 * d1);
+  transpose(c, d1, r2, Y, r2, Yt, d1);
+  Y.reset();
+  M12.reset();
+  DBuf Tt(c, r2 * r1);
+  F1.right_apply(c, r2, Yt, d1, Tt, r1);
+  Yt.reset();
+
+  std::vector<double> sv;
+  DBuf Ut(c, int64_t(kk) * r1), Vt(c, int64_t(kk) * r2);
+  svd_topk_dense(c, Tt, r1, r2, kk, sv, Ut, Vt);
+
+  DBuf W1t(c, int64_t(kk) * d1), W2t(c, int64_t(kk) * d2);
+  F1.back_project_rows(c, kk, Ut, r1, W1t, d1);
+  F2.back_project_rows(c, kk, Vt, r2, W2t, d2);
+  rows_to_host_cols(c, W1t, kk, d1, d1, 1.0, W_host);
+  rows_to_host_cols(c, W2t, kk, d2, d2, 1.0, W_host + d1 * kk);
+  means_out(c, s, D, n, ctr, means_host);
+  if (vals_host) std::copy(sv.begin(), sv.begin() + kk, vals_host);
+  if (k_out) *k_out = kk;
+}
+
+// ===========================================================================
+// MCCA      reference: cca_zoo/linear/_mcca.py:99-197
+// ===========================================================================
+static void mcca_solve_impl(ccz_ctx* c, const double* mom, int64_t n, const int64_t* dims, int m,
+                            const double* cc, double eps, int center, int k, double* W_host,
+                            double* means_host, double* vals_host, int* k_out) {
+  check_common(mom, n, dims, m, k);
+  if (!(eps > 0.0)) fail(CCZ_EINVAL, "eps must be > 0, got %g", eps);
+  auto off = offsets(dims, m);
+  const int64_t D = off[m];
+  const double* G = mom;
+  const double* s = mom + D * D;
+  const double inv = 1.0 / double(n - 1);
+  for (int i = 0; i < m; ++i)
+    if (!(cc[i] >= 0.0 && cc[i] <= 1.0)) fail(CCZ_EINVAL, "ridge parameter c[%d]=%g outside [0, 1]", i, cc[i]);
+
+  // B blocks (always from the CENTRED covariance: np.cov / PCA re-centre)
+  std::vector<DBuf> R(m);
+  double min_eig = eps;
+  for (int i = 0; i < m; ++i) {
+    R[i] = DBuf(c, dims[i] * dims[i]);
+    cov_block(c, G, D, s, n, true, (1.0 - cc[i]) * inv, off[i], dims[i], off[i], dims[i], R[i], dims[i]);
+    add_diag(c, dims[i], R[i], dims[i], cc[i]);
+    min_eig = std::min(min_eig, min_eig_if_below(c, R[i], dims[i], cc[i], eps));
+  }
+  const double shift = min_eig < eps ? eps - min_eig : 0.0;
+  std::vector<Whitener> F(m);
+  for (int i = 0; i < m; ++i) {
+    if (shift > 0.0) add_diag(c, dims[i], R[i], dims[i], shift);
+    F[i] = make_whitener(c, R[i], dims[i], false);
+    R[i].reset();
+  }
+  // S = L^-1 (C - blockdiag C) L^-T,  zero diagonal blocks
+  DBuf S(c, D * D);
+  fill2d(c, D, D, S, D, 0.0);
+  for (int i = 0; i < m; ++i) {
+    for (int j = i + 1; j < m; ++j) {
+      const int64_t di = dims[i], dj = dims[j];
+      DBuf Cij(c, di * dj);
+      cov_block(c, G, D, s, n, true, inv, off[i], di, off[j], dj, Cij, dj);
+      F[j].right_apply(c, di, Cij, dj, Cij, dj);                 // C_ij L_j^-T
+      DBuf Ct(c, dj * di);
+      transpose(c, di, dj, Cij, dj, Ct, di);
+      F[i].right_apply(c, dj, Ct, di, Ct, di);                   // (L_i^-1 C_ij L_j^-T)' = S_ji
+      copy2d(c, dj, di, Ct, di, S.get() + off[j] * D + off[i], D);
+      transpose(c, dj, di, Ct, di, S.get() + off[i] * D + off[j], D);
+    }
+  }
+  const int kk = int(std::min<int64_t>(k, D));
+  std::vector<double> lam;
+  DBuf Yt(c, int64_t(kk) * D);
+  eig_topk_dense(c, S, D, kk, lam, Yt, D);
+  S.reset();
+  // v_i = sqrt(m) L_i^-T y_i   (normalisation v'(B/m)v = 1 of LAPACK sygvx on (A/m, B/m))
+  int64_t wofs = 0;
+  for (int i = 0; i < m; ++i) {
+    F[i].back_project_rows(c, kk, Yt.get() + off[i], D, Yt.get() + off[i], D);
+    rows_to_host_cols(c, Yt.get() + off[i], kk, dims[i], D, std::sqrt(double(m)), W_host + wofs);
+    wofs += dims[i] * kk;
+  }
+  means_out(c, s, D, n, center != 0, means_host);
+  if (vals_host) std::copy(lam.begin(), lam.begin() + kk, vals_host);
+  if (k_out) *k_out = kk;
+}
+
+// ===========================================================================
+// GCCA in D x D Gram form      reference: cca_zoo/linear/_gcca.py:80-110
+// ===========================================================================
+static void gcca_solve_impl(ccz_ctx* c, const double* mom, int64_t n, const int64_t* dims, int m,
+                            const double* cc, const double* mu, double eps, int center, int k,
+                            double* W_host, double* means_host, double* vals_host, int* k_out) {
+  check_common(mom, n, dims, m, k);
+  if (!(eps > 0.0)) fail(CCZ_EINVAL, "eps must be > 0, got %g", eps);
+  auto off = offsets(dims, m);
+  const int64_t D = off[m];
+  const double* G = mom;
+  const double* s = mom + D * D;
+  const double inv = 1.0 / double(n - 1);
+  const bool ctr = center != 0;
+  std::vector<double> rmu(m);
+  for (int i = 0; i < m; ++i) {
+    if (!(cc[i] >= 0.0 && cc[i] <= 1.0)) fail(CCZ_EINVAL, "ridge parameter c[%d]=%g outside [0, 1]", i, cc[i]);
+    const double w = mu ? mu[i] : 1.0;
+    if (!(w >= 0.0)) fail(CCZ_EINVAL, "view weight %d must be non-negative, got %g", i, w);
+    rmu[i] = std::sqrt(w);
+  }
+  std::vector<Whitener> F(m);
+  for (int i = 0; i < m; ++i) {
+    DBuf R(c, dims[i] * dims[i]);
+    cov_block(c, G, D, s, n, true, (1.0 - cc[i]) * inv, off[i], dims[i], off[i], dims[i], R, dims[i]);
+    add_diag(c, dims[i], R, dims[i], cc[i]);
+    const double lo = min_eig_if_below(c, R, dims[i], cc[i], eps);
+    if (lo < eps) add_diag(c, dims[i], R, dims[i], eps - lo);
+    F[i] = make_whitener(c, R, dims[i], false);
+  }
+  // Z[:, j] = sqrt(mu_j) Gx[:, j] L_j^-T      (Gx: second moments of the data as fitted)
+  DBuf Z(c, D * D), K(c, D * D);
+  for (int j = 0; j < m; ++j) {
+    cov_block(c, G, D, s, n, ctr, rmu[j], 0, D, off[j], dims[j], Z.get() + off[j], D);
+    F[j].right_apply(c, D, Z.get() + off[j], D, Z.get() + off[j], D);
+  }
+  // K[:, i] = ( sqrt(mu_i) L_i^-1 Z[i, :] )' = sqrt(mu_i) Z[i, :]' L_i^-T
+  for (int i = 0; i < m; ++i) {
+    transpose(c, dims[i], D, Z.get() + off[i] * D, D, K.get() + off[i], D);
+    F[i].right_apply(c, D, K.get() + off[i], D, K.get() + off[i], D);
+    axpby2d(c, D, dims[i], rmu[i], K.get() + off[i], D, 0.0, nullptr, 0);
+  }
+  {  // symmetrise (K is symmetric up to round-off)
+    DBuf Kt(c, D * D);
+    transpose(c, D, D, K, D, Kt, D);
+    axpby2d(c, D, D, 0.5, K, D, 0.5, Kt, D);
+  }
+  const int kk = int(std::min<int64_t>({int64_t(k), D, n}));
+  std::vector<double> lam;
+  DBuf Ut(c, int64_t(kk) * D);
+  eig_topk_dense(c, K, D, kk, lam, Ut, D);
+  K.reset();
+  for (int i = 0; i < kk; ++i)
+    if (!(lam[i] > 0.0)) fail(CCZ_ENOCONV, "GCCA eigenvalue %d is not positive (%g); fewer than k shared directions", i, lam[i]);
+  // rhs = Z U / sqrt(lam)   (D x k)  == X' T stacked by view
+  DBuf U(c, D * kk), rhs(c, D * kk), lamd(c, kk);
+  transpose(c, kk, D, Ut, D, U, kk);
+  gemm(c, false, false, D, kk, D, 1.0, Z, D, U, kk, 0.0, rhs, kk);
+  h2d(c, lamd, lam.data(), size_t(kk) * 8);
+  scale_cols(c, D, kk, rhs, kk, lamd, 2);
+  Z.reset();
+  // W_i = pinv(X_i) T = (Gx_ii)^+ rhs_i
+  int64_t wofs = 0;
+  for (int i = 0; i < m; ++i) {
+    const int64_t di = dims[i];
+    DBuf Gii(c, di * di), keep(c, di * di);
+    cov_block(c, G, D, s, n, ctr, 1.0, off[i], di, off[i], di, Gii, di);
+    d2d(c, keep, Gii, size_t(di) * di * 8);
+    double* rb = rhs.get() + off[i] * kk;
+    if (potrf_lower(c, Gii, di, di) == 0) {
+      chol_solve_inplace(c, di, kk, Gii, di, rb, kk);
+    } else {  // rank-deficient view: eigen pseudo-inverse with a relative floor
+      std::vector<double> ev;
+      DBuf V(c, di * di);
+      syev_full_impl(c, keep, di, true, ev, V, di);
+      const double fl = kRankTol * double(di) * std::max(ev[0], 0.0);
+      int64_t r = 0;
+      while (r < di && ev[r] > fl) ++r;
+      if (r == 0) fail(CCZ_ENOTSPD, "view %d has zero variance", i);
+      std::vector<int64_t> perm(r);
+      std::vector<double> sc(r);
+      for (int64_t t = 0; t < r; ++t) { perm[t] = t; sc[t] = 1.0 / std::sqrt(ev[t]); }
+      DBuf Vs(c, r * di), t1(c, r * kk), t2(c, di * kk);
+      gather_rows(c, r, di, V, di, perm.data(), sc.data(), Vs, di);      // rows v_t / sqrt(lam_t)
+      gemm(c, false, false, r, kk, di, 1.0, Vs, di, rb, kk, 0.0, t1, kk);
+      gemm(c, true, false, di, kk, r, 1.0, Vs, di, t1, kk, 0.0, t2, kk);
+      copy2d(c, di, kk, t2, kk, rb, kk);
+    }
+    std::vector<double> h(size_t(di) * kk);
+    DBuf tmp(c, di * kk);
+    copy2d(c, di, kk, rb, kk, tmp, kk);
+    d2h(c, h.data(), tmp, h.size() * 8);
+    std::copy(h.begin(), h.end(), W_host + wofs);
+    wofs += di * kk;
+  }
+  means_out(c, s, D, n, ctr, means_host);
+  if (vals_host) std::copy(lam.begin(), lam.begin() + kk, vals_host);
+  if (k_out) *k_out = kk;
+}
+
+}  // namespace ccz
+
+// ===========================================================================
+// C ABI (solver part)
+// ===========================================================================
+#define CCZ_GUARD(h, ...)                                              \
+  if (!(h)) return CCZ_EINVAL;                                         \
+  try {                                                                \
+    __VA_ARGS__;                                                       \
+    return CCZ_OK;                                                     \
+  } catch (const ccz::Error& e) {                                      \
+    (h)->err = e.msg;                                                  \
+    return e.code;                                                     \
+  } catch (const std::bad_alloc&) {                                    \
+    (h)->err = "host allocation failed";                               \
+    return CCZ_ENOMEM;                                                 \
+  } catch (...) {                                                      \
+    (h)->err = "unknown internal error";                               \
+    return CCZ_EHIP;                                                   \
+  }
+
+extern "C" {
+
+int ccz_rcca_solve(ccz_handle h, const double* moments_dev, int64_t n, const int64_t dims[2],
+                   const double c[2], int center, int k, double* weights_host, double* means_host,
+                   double* vals_host, int* k_out) {
+  CCZ_GUARD(h, {
+    if (!c || !weights_host) ccz::fail(CCZ_EINVAL, "null argument");
+    ccz::rcca_solve_impl(h, moments_dev, n, dims, c, center, k, weights_host, means_host, vals_host, k_out);
+  })
+}
+
+int ccz_mcca_solve(ccz_handle h, const double* moments_dev, int64_t n, const int64_t* dims,
+                   int n_views, const double* c, double eps, int center, int k,
+                   double* weights_host, double* means_host, double* vals_host, int* k_out) {
+  CCZ_GUARD(h, {
+    if (!c || !weights_host) ccz::fail(CCZ_EINVAL, "null argument");
+    ccz::mcca_solve_impl(h, moments_dev, n, dims, n_views, c, eps, center, k, weights_host, means_host, vals_host, k_out);
+  })
+}
+
+int ccz_gcca_solve(ccz_handle h, const double* moments_dev, int64_t n, const int64_t* dims,
+                   int n_views, const double* c, const double* view_weights, double eps,
+                   int center, int k, double* weights_host, double* means_host,
+                   double* vals_host, int* k_out) {
+  CCZ_GUARD(h, {
+    if (!c || !weights_host) ccz::fail(CCZ_EINVAL, "null argument");
+    ccz::gcca_solve_impl(h, moments_dev, n, dims, n_views, c, view_weights, eps, center, k, weights_host, means_host, vals_host, k_out);
+  })
+}
+
+int ccz_syevj(ccz_handle h, double* A_dev, int64_t d, double* w_dev, double* V_dev, int* sweeps_out) {
+  CCZ_GUARD(h, {
+    if (!A_dev || !w_dev || d < 1) ccz::fail(CCZ_EINVAL, "bad argument");
+    std::vector<double> w;
+    int sw = ccz::syev_full_impl(h, A_dev, d, false, w, V_dev, d);
+    ccz::h2d(h, w_dev, w.data(), size_t(d) * 8);
+    if (sweeps_out) *sweeps_out = sw;
+  })
+}
+
+int ccz_gesvj(ccz_handle h, const double* A_dev, int64_t p, int64_t q, double* U_dev,
+              double* s_dev, double* Vt_dev, int* sweeps_out) {
+  CCZ_GUARD(h, {
+    if (!A_dev || !s_dev || p < 1 || q < 1) ccz::fail(CCZ_EINVAL, "bad argument");
+    const int64_t r = std::min(p, q);
+    ccz::DBuf Ut(h, r * p);
+    std::vector<double> s;
+    int sw = ccz::gesvj_rows(h, A_dev, p, q, q, Ut, s, Vt_dev);
+    if (U_dev) ccz::transpose(h, r, p, Ut, p, U_dev, r);
+    ccz::h2d(h, s_dev, s.data(), size_t(r) * 8);
+    if (sweeps_out) *sweeps_out = sw;
+  })
+}
+
+int ccz_gevp_topk(ccz_handle h, const double* A_dev, const double* B_dev, int64_t p, int k,
+                  double* w_dev, double* V_dev) {
+  CCZ_GUARD(h, {
+    if (!A_dev || !w_dev || !V_dev || p < 1 || k < 1) ccz::fail(CCZ_EINVAL, "bad argument");
+    const int kk = int(std::min<int64_t>(k, p));
+    std::vector<double> lam;
+    ccz::DBuf Vt(h, int64_t(kk) * p);
+    if (!B_dev) {
+      ccz::eig_topk_dense(h, A_dev, p, kk, lam, Vt, p);
+    } else {
+      ccz::DBuf L(h, p * p), Y(h, p * p), St(h, p * p);
+      ccz::d2d(h, L, B_dev, size_t(p) * p * 8);
+      if (ccz::potrf_lower(h, L, p, p) != 0) ccz::fail(CCZ_ENOTSPD, "B is not positive definite");
+      ccz::d2d(h, Y, A_dev, size_t(p) * p * 8);
+      ccz::trsm_right_lower(h, true, p, p, L, p, Y, p);          // A L^-T
+      ccz::transpose(h, p, p, Y, p, St, p);
+      ccz::trsm_right_lower(h, true, p, p, L, p, St, p);         // (L^-1 A L^-T)'
+      ccz::transpose(h, p, p, St, p, Y, p);
+      ccz::axpby2d(h, p, p, 0.5, Y, p, 0.5, St, p);             // symmetrise
+      ccz::eig_topk_dense(h, Y, p, kk, lam, Vt, p);
+      ccz::trsm_right_lower(h, false, kk, p, L, p, Vt, p);       // rows y' L^-1 = (L^-T y)'
+    }
+    ccz::transpose(h, kk, p, Vt, p, V_dev, kk);
+    ccz::h2d(h, w_dev, lam.data(), size_t(kk) * 8);
+  })
+}
+
+int ccz_svd_topk(ccz_handle h, const double* T_dev, int64_t p, int64_t q, int k, double* U_dev,
+                 double* s_dev, double* V_dev) {
+  CCZ_GUARD(h, {
+    if (!T_dev || !s_dev || p < 1 || q < 1 || k < 1) ccz::fail(CCZ_EINVAL, "bad argument");
+    const int kk = int(std::min<int64_t>({int64_t(k), p, q}));
+    ccz::DBuf Tt(h, q * p), Ut(h, int64_t(kk) * p), Vt(h, int64_t(kk) * q);
+    ccz::transpose(h, p, q, T_dev, q, Tt, p);
+    std::vector<double> s;
+    ccz::svd_topk_dense(h, Tt, p, q, kk, s, Ut, Vt);
+    if (U_dev) ccz::transpose(h, kk, p, Ut, p, U_dev, kk);
+    if (V_dev) ccz::transpose(h, kk, q, Vt, q, V_dev, kk);
+    ccz::h2d(h, s_dev, s.data(), size_t(kk) * 8);
+  })
+}
+
+int ccz_whitener(ccz_handle h, const double* Gxx_dev, int64_t d, int64_t n, double ridge,
+                 double* W_dev, double* lam_dev, int64_t* r_out) {
+  CCZ_GUARD(h, {
+    if (!Gxx_dev || !W_dev || d < 1 || n < 2) ccz::fail(CCZ_EINVAL, "bad argument");
+    ccz::DBuf A(h, d * d), V(h, d * d);
+    ccz::d2d(h, A, Gxx_dev, size_t(d) * d * 8);
+    ccz::axpby2d(h, d, d, 1.0 / double(n - 1), A, d, 0.0, nullptr, 0);
+    std::vector<double> lam;
+    ccz::syev_full_impl(h, A, d, true, lam, V, d);
+    const int64_t r = std::min(n, d);
+    std::vector<int64_t> perm(r);
+    std::vector<double> sc(r);
+    for (int64_t i = 0; i < r; ++i) {
+      perm[i] = i;
+      lam[i] = std::max(lam[i], 0.0);
+      sc[i] = 1.0 / std::sqrt((1.0 - ridge) * lam[i] + ridge);
+    }
+    ccz::DBuf Wt(h, r * d);
+    ccz::gather_rows(h, r, d, V, d, perm.data(), sc.data(), Wt, d);
+    ccz::transpose(h, r, d, Wt, d, W_dev, r);
+    if (lam_dev) ccz::h2d(h, lam_dev, lam.data(), size_t(r) * 8);
+    if (r_out) *r_out = r;
+  })
+}
+
+int ccz_inv_sqrtm(ccz_handle h, const double* A_dev, int64_t d, double eps, double* out_dev) {
+  CCZ_GUARD(h, {
+    if (!A_dev || !out_dev || d < 1) ccz::fail(CCZ_EINVAL, "bad argument");
+    ccz::DBuf A(h, d * d), V(h, d * d), Vs(h, d * d);
+    ccz::d2d(h, A, A_dev, size_t(d) * d * 8);
+    std::vector<double> lam;
+    ccz::syev_full_impl(h, A, d, false, lam, V, d);
+    std::vector<int64_t> perm(d);
+    std::vector<double> sc(d);
+    for (int64_t i = 0; i < d; ++i) {
+      perm[i] = i;
+      sc[i] = std::pow(std::max(lam[i], eps), -0.25);
+    }
+    ccz::gather_rows(h, d, d, V, d, perm.data(), sc.data(), Vs, d);
+    ccz::gemm(h, true, false, d, d, d, 1.0, Vs, d, Vs, d, 0.0, out_dev, d);
+  })
+}
+
+int ccz_potrf_lower(ccz_handle h, double* A_dev, int64_t d, int64_t lda) {
+  CCZ_GUARD(h, {
+    if (!A_dev || d < 1 || lda < d) ccz::fail(CCZ_EINVAL, "bad argument");
+    int info = ccz::potrf_lower(h, A_dev, d, lda);
+    if (info != 0) ccz::fail(CCZ_ENOTSPD, "pivot %d is not positive", info - 1);
+  })
+}
+
+int ccz_trsm_right_lower(ccz_handle h, int trans, int64_t r, int64_t d, const double* L_dev,
+                         int64_t ldl, double* X_dev, int64_t ldx) {
+  CCZ_GUARD(h, {
+    if (!L_dev || !X_dev || r < 1 || d < 1 || ldl < d || ldx < d) ccz::fail(CCZ_EINVAL, "bad argument");
+    ccz::trsm_right_lower(h, trans != 0, r, d, L_dev, ldl, X_dev, ldx);
+  })
+}
+
+int ccz_gemm_f64(ccz_handle h, int transA, int transB, int64_t M, int64_t N, int64_t K,
+                 double alpha, const double* A_dev, int64_t lda, const double* B_dev, int64_t ldb,
+                 double beta, double* C_dev, int64_t ldc) {
+  CCZ_GUARD(h, {
+    if (!A_dev || !B_dev || !C_dev || M < 1 || N < 1 || K < 1) ccz::fail(CCZ_EINVAL, "bad argument");
+    ccz::gemm(h, transA != 0, transB != 0, M, N, K, alpha, A_dev, lda, B_dev, ldb, beta, C_dev, ldc);
+  })
+}
+
+}  // extern "C"

@@ -1,0 +1,202 @@
+// TEST DOUBLE for cca_zoo_amd/csrc/ops.h -- host loops, no GPU.
+//
+// Builds (with g++) into tests/hostsim/libccz_hostsim.so together with the
+// unmodified product driver source cca_zoo_amd/csrc/solve.cpp, so that the
+// driver LOGIC (Cholesky whitening, Chebyshev subspace iteration, rCCA / MCCA /
+// GCCA assembly, error paths) is exercised by the CPU test-suite.  "Device"
+// pointers are host pointers here.  Never loaded by the cca_zoo_amd package.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../cca_zoo_amd/csrc/ops.h"
+#include "../../cca_zoo_amd/csrc/rng_hash.h"
+
+namespace ccz {
+
+void* dev_alloc(ccz_ctx*, size_t bytes) {
+  void* p = std::malloc(bytes ? bytes : 8);
+  if (!p) fail(CCZ_ENOMEM, "malloc(%zu) failed", bytes);
+  return p;
+}
+void dev_free(ccz_ctx*, void* p) { std::free(p); }
+void h2d(ccz_ctx*, void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
+void d2h(ccz_ctx*, void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
+void d2d(ccz_ctx*, void* d, const void* s, size_t n) { std::memmove(d, s, n); }
+void zero(ccz_ctx*, void* d, size_t n) { std::memset(d, 0, n); }
+void sync(ccz_ctx*) {}
+
+void gemm(ccz_ctx*, bool tA, bool tB, int64_t M, int64_t N, int64_t K, double alpha, const double* A,
+          int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc) {
+  std::vector<double> acc(size_t(M) * N, 0.0);
+  for (int64_t i = 0; i < M; ++i)
+    for (int64_t k = 0; k < K; ++k) {
+      const double a = tA ? A[k * lda + i] : A[i * lda + k];
+      if (a == 0.0) continue;
+      for (int64_t j = 0; j < N; ++j) acc[i * N + j] += a * (tB ? B[j * ldb + k] : B[k * ldb + j]);
+    }
+  for (int64_t i = 0; i < M; ++i)
+    for (int64_t j = 0; j < N; ++j)
+      C[i * ldc + j] = alpha * acc[i * N + j] + (beta == 0.0 ? 0.0 : beta * C[i * ldc + j]);
+}
+
+int potrf_lower(ccz_ctx*, double* A, int64_t d, int64_t lda) {
+  for (int64_t j = 0; j < d; ++j) {
+    double v = A[j * lda + j];
+    for (int64_t t = 0; t < j; ++t) v -= A[j * lda + t] * A[j * lda + t];
+    if (!(v > 0.0)) return int(j) + 1;
+    const double piv = std::sqrt(v);
+    A[j * lda + j] = piv;
+    for (int64_t i = j + 1; i < d; ++i) {
+      double w = A[i * lda + j];
+      for (int64_t t = 0; t < j; ++t) w -= A[i * lda + t] * A[j * lda + t];
+      A[i * lda + j] = w / piv;
+    }
+  }
+  return 0;
+}
+
+void trsm_right_lower(ccz_ctx*, bool trans, int64_t r, int64_t d, const double* L, int64_t ldl,
+                      double* X, int64_t ldx) {
+  for (int64_t row = 0; row < r; ++row) {
+    double* x = X + row * ldx;
+    if (trans) {  // x L' = y  <=>  L x' = y'
+      for (int64_t i = 0; i < d; ++i) {
+        double v = x[i];
+        for (int64_t t = 0; t < i; ++t) v -= L[i * ldl + t] * x[t];
+        x[i] = v / L[i * ldl + i];
+      }
+    } else {      // x L = y
+      for (int64_t i = d - 1; i >= 0; --i) {
+        double v = x[i];
+        for (int64_t t = i + 1; t < d; ++t) v -= x[t] * L[t * ldl + i];
+        x[i] = v / L[i * ldl + i];
+      }
+    }
+  }
+}
+
+void transpose(ccz_ctx*, int64_t rows, int64_t cols, const double* in, int64_t ldi, double* out, int64_t ldo) {
+  for (int64_t i = 0; i < rows; ++i)
+    for (int64_t j = 0; j < cols; ++j) out[j * ldo + i] = in[i * ldi + j];
+}
+void copy2d(ccz_ctx*, int64_t rows, int64_t cols, const double* in, int64_t ldi, double* out, int64_t ldo) {
+  if (in == out && ldi == ldo) return;
+  for (int64_t i = 0; i < rows; ++i) std::memmove(out + i * ldo, in + i * ldi, size_t(cols) * 8);
+}
+void axpby2d(ccz_ctx*, int64_t rows, int64_t cols, double alpha, double* A, int64_t lda, double beta,
+             const double* B, int64_t ldb) {
+  for (int64_t i = 0; i < rows; ++i)
+    for (int64_t j = 0; j < cols; ++j)
+      A[i * lda + j] = alpha * A[i * lda + j] + (beta == 0.0 ? 0.0 : beta * B[i * ldb + j]);
+}
+void fill2d(ccz_ctx*, int64_t rows, int64_t cols, double* A, int64_t lda, double v) {
+  for (int64_t i = 0; i < rows; ++i) std::fill(A + i * lda, A + i * lda + cols, v);
+}
+void add_diag(ccz_ctx*, int64_t d, double* A, int64_t lda, double v) {
+  for (int64_t i = 0; i < d; ++i) A[i * lda + i] += v;
+}
+void scale_cols(ccz_ctx*, int64_t rows, int64_t cols, double* A, int64_t lda, const double* v, int mode) {
+  for (int64_t i = 0; i < rows; ++i)
+    for (int64_t j = 0; j < cols; ++j) {
+      const double f = mode == 0 ? v[j] : (mode == 1 ? 1.0 / v[j] : 1.0 / std::sqrt(v[j]));
+      A[i * lda + j] *= f;
+    }
+}
+void mirror_upper(ccz_ctx*, int64_t d, double* A, int64_t lda) {
+  for (int64_t i = 0; i < d; ++i)
+    for (int64_t j = 0; j < i; ++j) A[i * lda + j] = A[j * lda + i];
+}
+void cov_block(ccz_ctx*, const double* G, int64_t D, const double* s, int64_t n, bool centre, double alpha,
+               int64_t r0, int64_t rows, int64_t c0, int64_t cols, double* out, int64_t ldo) {
+  for (int64_t i = 0; i < rows; ++i)
+    for (int64_t j = 0; j < cols; ++j) {
+      double v = G[(r0 + i) * D + (c0 + j)];
+      if (centre) v -= s[r0 + i] * s[c0 + j] / double(n);
+      out[i * ldo + j] = alpha * v;
+    }
+}
+void randn_fill(ccz_ctx*, int64_t rows, int64_t cols, double* A, int64_t lda, uint64_t seed) {
+  for (int64_t i = 0; i < rows; ++i)
+    for (int64_t j = 0; j < cols; ++j) A[i * lda + j] = hash_normal(seed, uint64_t(i * cols + j));
+}
+void col_sqnorms(ccz_ctx*, int64_t rows, int64_t cols, const double* A, int64_t lda, double* out) {
+  std::fill(out, out + cols, 0.0);
+  for (int64_t i = 0; i < rows; ++i)
+    for (int64_t j = 0; j < cols; ++j) out[j] += A[i * lda + j] * A[i * lda + j];
+}
+double norm_inf(ccz_ctx*, int64_t rows, int64_t cols, const double* A, int64_t lda) {
+  double best = 0.0;
+  for (int64_t i = 0; i < rows; ++i) {
+    double s = 0.0;
+    for (int64_t j = 0; j < cols; ++j) s += std::fabs(A[i * lda + j]);
+    if (!(s <= best)) best = s;   // propagates NaN
+  }
+  return best;
+}
+
+int jacobi_rows(ccz_ctx*, int64_t p, int64_t q, double* W, int64_t ldw, double* Q, int64_t qc, int64_t ldq,
+                int max_sweeps) {
+  const double tol = 2.220446049250313e-16 * std::sqrt(double(q)) * 4.0;
+  for (int sweep = 1; sweep <= max_sweeps; ++sweep) {
+    int64_t rotations = 0;
+    for (int64_t a = 0; a < p - 1; ++a)
+      for (int64_t b = a + 1; b < p; ++b) {
+        double* wa = W + a * ldw;
+        double* wb = W + b * ldw;
+        double al = 0, be = 0, ga = 0;
+        for (int64_t t = 0; t < q; ++t) { al += wa[t] * wa[t]; be += wb[t] * wb[t]; ga += wa[t] * wb[t]; }
+        if (!(std::fabs(ga) > tol * std::sqrt(al * be)) || al * be == 0.0) continue;
+        ++rotations;
+        const double zeta = (be - al) / (2.0 * ga);
+        const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+        const double cs = 1.0 / std::sqrt(1.0 + t * t), sn = cs * t;
+        for (int64_t u = 0; u < q; ++u) {
+          const double x = wa[u], y = wb[u];
+          wa[u] = cs * x - sn * y;
+          wb[u] = sn * x + cs * y;
+        }
+        if (Q) {
+          double* qa = Q + a * ldq;
+          double* qb = Q + b * ldq;
+          for (int64_t u = 0; u < qc; ++u) {
+            const double x = qa[u], y = qb[u];
+            qa[u] = cs * x - sn * y;
+            qb[u] = sn * x + cs * y;
+          }
+        }
+      }
+    if (rotations == 0) return sweep;
+  }
+  fail(CCZ_ENOCONV, "Jacobi did not converge in %d sweeps", max_sweeps);
+}
+
+void row_dots(ccz_ctx*, int64_t rows, int64_t cols, const double* A, int64_t lda, const double* B, int64_t ldb,
+              double* out) {
+  for (int64_t i = 0; i < rows; ++i) {
+    double s = 0.0;
+    for (int64_t j = 0; j < cols; ++j) s += A[i * lda + j] * B[i * ldb + j];
+    out[i] = s;
+  }
+}
+void gather_rows(ccz_ctx*, int64_t rows, int64_t cols, const double* in, int64_t ldi, const int64_t* perm,
+                 const double* scale, double* out, int64_t ldo) {
+  for (int64_t i = 0; i < rows; ++i)
+    for (int64_t j = 0; j < cols; ++j) out[i * ldo + j] = in[perm[i] * ldi + j] * (scale ? scale[i] : 1.0);
+}
+
+}  // namespace ccz
+
+extern "C" {
+int ccz_version(void) { return CCZ_VERSION; }
+int ccz_create(ccz_handle* out, int device) {
+  if (!out) return CCZ_EINVAL;
+  *out = new ccz_ctx();
+  (*out)->device = device;
+  return CCZ_OK;
+}
+int ccz_destroy(ccz_handle h) { delete h; return CCZ_OK; }
+const char* ccz_last_error(ccz_handle h) { return h ? h->err.c_str() : "null handle"; }
+}

@@ -1,0 +1,33 @@
+"""Build + load the host test double of libccz's solver drivers (CPU tests only)."""
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SIM_DIR = os.path.join(HERE, "hostsim")
+SIM_SO = os.path.join(SIM_DIR, "libccz_hostsim.so")
+SOURCES = [os.path.join(SIM_DIR, "ops_host.cpp"), os.path.join(ROOT, "cca_zoo_amd", "csrc", "solve.cpp")]
+HEADERS = [os.path.join(ROOT, "cca_zoo_amd", "csrc", "ops.h"), os.path.join(ROOT, "cca_zoo_amd", "csrc", "rng_hash.h"),
+           os.path.join(ROOT, "include", "ccz.h")]
+
+
+def build_hostsim():
+    newest = max(os.path.getmtime(p) for p in SOURCES + HEADERS)
+    if not os.path.exists(SIM_SO) or os.path.getmtime(SIM_SO) < newest:
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", SIM_SO] + SOURCES)
+    return SIM_SO
+
+
+def hostsim_handle():
+    from cca_zoo_amd import _backend
+
+    lib = _backend.bind(ctypes.CDLL(build_hostsim()), strict=False)
+    return _backend.Handle(0, lib=lib)
+
+
+def pack_moments(G, s):
+    return np.concatenate([np.ascontiguousarray(G, dtype=np.float64).ravel(), np.asarray(s, dtype=np.float64)])
