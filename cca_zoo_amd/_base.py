@@ -1,0 +1,179 @@
+"""Estimator surface shared by the device-backed CCA models.
+
+Same public contract as the reference's ``BaseModel`` (cca_zoo/_base.py:19-258):
+sklearn ``BaseEstimator`` (``get_params/set_params/clone/repr``), constructor
+validation via ``_parameter_constraints``, ``fit`` sets ``weights_`` / ``means_`` /
+``n_views_`` / ``n_features_in_`` / ``n_samples_``; ``transform``, ``fit_transform``,
+``score``, ``pairwise_correlations``, ``average_pairwise_correlations``, ``weights`` and
+``get_factor_loadings`` derive from those.  What differs is underneath: ``fit`` never
+materialises centred copies -- the column sums come out of the same pass that builds
+the Gram matrix (libccz K1) and centring is applied to the d x d moments.
+"""
+
+from __future__ import annotations
+
+from abc import ABC, abstractmethod
+from numbers import Integral
+from typing import Any, ClassVar
+
+import numpy as np
+from sklearn.base import BaseEstimator
+from sklearn.utils import Tags
+from sklearn.utils._param_validation import Interval
+from sklearn.utils.validation import check_is_fitted
+
+from cca_zoo_amd._utils._validation import is_device_tensor, validate_views
+
+
+class BaseModel(BaseEstimator, ABC):
+    """Abstract base of the multiview estimators (see module docstring)."""
+
+    _parameter_constraints: ClassVar[dict[str, list[Any]]] = {
+        "latent_dimensions": [Interval(Integral, 1, None, closed="left")],
+        "center": ["boolean"],
+    }
+
+    def __init__(self, latent_dimensions: int = 1, center: bool = True) -> None:
+        self.latent_dimensions = latent_dimensions
+        self.center = center
+
+    @abstractmethod
+    def fit(self, views, y=None):
+        """Fit to a list of (n_samples, n_features_i) views; returns ``self``."""
+
+    # -- fit plumbing ------------------------------------------------------------
+    def _setup_fit(self, views) -> list:
+        """Validate parameters + views and record the metadata of cca_zoo/_base.py:92-96.
+
+        Unlike the reference this does NOT return centred copies: ``means_`` is filled in
+        by the concrete ``fit`` from the column sums of the moments pass.
+        """
+        self._validate_params()
+        validated = validate_views(views)
+        self.n_views_ = len(validated)
+        self.n_features_in_ = [int(v.shape[1]) for v in validated]
+        self.n_samples_ = int(validated[0].shape[0])
+        return validated
+
+    def _store(self, weights, means, in_kind, weights_like_input):
+        """dtype flow of the reference: rCCA keeps the input dtype for weights; MCCA/GCCA
+        promote to float64 (np.cov); ``means_`` follow the input dtype when centring, else
+        float64 zeros (np.zeros(p), _base.py:101)."""
+        wdt = np.float32 if (in_kind == "f32" and weights_like_input) else np.float64
+        mdt = np.float32 if (in_kind == "f32" and self.center) else np.float64
+        self.weights_ = [np.ascontiguousarray(w, dtype=wdt) for w in weights]
+        self.means_ = [np.ascontiguousarray(m, dtype=mdt) for m in means]
+
+    # -- public API ---------------------------------------------------------------------
+    def transform(self, views) -> list:
+        """``(X_i - mean_i) @ W_i`` per view.  Host arrays in -> numpy out (device GEMM inside
+        libccz); CUDA tensors in -> CUDA tensors out."""
+        check_is_fitted(self)
+        validated = validate_views(views)
+        out = []
+        for v, m, w in zip(validated, self.means_, self.weights_):
+            out.append(_device_project(v, m, w) if is_device_tensor(v) else _host_project(v, m, w))
+        return out
+
+    def fit_transform(self, views, y=None) -> list:
+        return self.fit(views, y).transform(views)
+
+    def score(self, views, y=None) -> np.ndarray:
+        return self.average_pairwise_correlations(views)
+
+    def pairwise_correlations(self, views) -> np.ndarray:
+        """(n_views, n_views, k) Pearson correlations between canonical variates."""
+        zs = self.transform(views)
+        if is_device_tensor(zs[0]):
+            import torch
+
+            T = torch.stack([z.double() for z in zs], dim=0)
+            T = T - T.mean(dim=1, keepdim=True)
+            nrm = torch.sqrt((T * T).sum(dim=1, keepdim=True))
+            T = T / torch.where(nrm > 1e-12, nrm, torch.ones_like(nrm))
+            return torch.einsum("isd,jsd->ijd", T, T).cpu().numpy()
+        T = np.stack(zs, axis=0)
+        T = T - T.mean(axis=1, keepdims=True)
+        nrm = np.sqrt((T**2).sum(axis=1, keepdims=True))
+        T = T / np.where(nrm > 1e-12, nrm, 1.0)
+        return np.einsum("isd,jsd->ijd", T, T)
+
+    def average_pairwise_correlations(self, views) -> np.ndarray:
+        R = self.pairwise_correlations(views)
+        m = R.shape[0]
+        off = R.sum(axis=(0, 1)) - sum(R[i, i, :] for i in range(m))
+        return off / (m * (m - 1))
+
+    @property
+    def weights(self) -> list:
+        check_is_fitted(self)
+        return self.weights_
+
+    def get_factor_loadings(self, views) -> list:
+        """Pearson correlation of every input feature with every canonical variate."""
+        validated = validate_views(views)
+        zs = self.transform(views)
+        out = []
+        for v, t in zip(validated, zs):
+            if is_device_tensor(v):
+                v, t = v.double().cpu().numpy(), t.double().cpu().numpy()
+            vc = v - v.mean(axis=0)
+            tc = t - t.mean(axis=0)
+            cov = vc.T @ tc / (v.shape[0] - 1)
+            sv = np.maximum(vc.std(axis=0, ddof=1), 1e-12)
+            st = np.maximum(tc.std(axis=0, ddof=1), 1e-12)
+            out.append(cov / np.outer(sv, st))
+        return out
+
+    def __sklearn_tags__(self) -> Tags:
+        tags = super().__sklearn_tags__()
+        tags.no_validation = True
+        tags.input_tags.two_d_array = False
+        tags._skip_test = True
+        return tags
+
+
+def _host_project(v, mean, w):
+    """(v - mean) @ w for a host array: staged through HBM, multiplied by ``ccz_transform``.
+    Result dtype follows NumPy promotion of (v, mean, w) like the reference expression."""
+    import ctypes as C
+
+    from cca_zoo_amd import _backend
+
+    rdt = np.result_type(v.dtype, mean.dtype, w.dtype)
+    rdt = np.float32 if rdt == np.float32 else np.float64
+    x = np.ascontiguousarray(v, dtype=rdt)
+    n, d = x.shape
+    k = int(w.shape[1])
+    h = _backend.default_handle()
+    xd = h.to_device(x)
+    md = h.to_device(np.ascontiguousarray(mean, dtype=np.float64))
+    wd = h.to_device(np.ascontiguousarray(w, dtype=np.float64))
+    od = h.alloc(max(n * k * x.itemsize, 8))
+    h.check(h.lib.ccz_transform(h.raw, _backend.F32 if rdt == np.float32 else _backend.F64,
+                                C.c_void_p(xd.ptr), n, d, d, C.c_void_p(md.ptr), C.c_void_p(wd.ptr), k,
+                                C.c_void_p(od.ptr), k))
+    return h.to_host(od, (n, k), dtype=rdt)
+
+
+def _device_project(v, mean, w):
+    """(v - mean) @ w for a CUDA tensor through ``ccz_transform`` (HBM-resident)."""
+    import ctypes as C
+
+    import torch
+
+    from cca_zoo_amd import _backend
+
+    h = _backend.default_handle(v.device.index or 0)
+    if v.stride(1) != 1:
+        v = v.contiguous()
+    k = int(w.shape[1])
+    out = torch.empty((v.shape[0], k), dtype=v.dtype, device=v.device)
+    md = torch.as_tensor(np.asarray(mean, dtype=np.float64), device=v.device)
+    wd = torch.as_tensor(np.ascontiguousarray(w, dtype=np.float64), device=v.device)
+    torch.cuda.current_stream(v.device).synchronize()
+    h.check(h.lib.ccz_transform(h.raw, _backend.F32 if v.element_size() == 4 else _backend.F64,
+                                C.c_void_p(v.data_ptr()), v.shape[0], v.shape[1], v.stride(0),
+                                C.c_void_p(md.data_ptr()), C.c_void_p(wd.data_ptr()), k,
+                                C.c_void_p(out.data_ptr()), out.stride(0)))
+    return out

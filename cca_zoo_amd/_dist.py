@@ -1,0 +1,74 @@
+"""Sample-axis sharding: one process per GPU, one all-reduce of the moments.
+
+The hot path shards naturally on rows: every rank computes the
+second moments ``[G | s]`` of ITS rows with K1, a single ``all_reduce(SUM)`` over
+RCCL/xGMI (``torch.distributed`` backend ``nccl``) makes them global, and the small
+dense solves run replicated.  No other collective exists on the path.
+
+Usage (under ``torchrun``)::
+
+    with cca_zoo_amd.row_sharded():          # views passed to fit() are this rank's rows
+        model.fit([X1_local, X2_local])
+
+``shard_bounds`` gives the contiguous row partition used by bench.py and the tests.
+"""
+
+from __future__ import annotations
+
+import contextlib
+import threading
+
+_state = threading.local()
+
+
+def shard_bounds(n_rows: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous, balanced partition: the first ``n % world`` ranks get one extra row."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError(f"bad rank/world: {rank}/{world}")
+    base, extra = divmod(int(n_rows), world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def active_group():
+    """The process group of the enclosing ``row_sharded`` block, or ``None``."""
+    return getattr(_state, "group", None)
+
+
+def is_sharded() -> bool:
+    return getattr(_state, "on", False)
+
+
+@contextlib.contextmanager
+def row_sharded(group=None):
+    """Treat the views given to ``fit`` as this rank's row shard of a global dataset."""
+    import torch.distributed as dist
+
+    if not dist.is_available() or not dist.is_initialized():
+        raise RuntimeError("row_sharded() needs an initialised torch.distributed process group")
+    prev = (getattr(_state, "on", False), getattr(_state, "group", None))
+    _state.on, _state.group = True, group
+    try:
+        yield
+    finally:
+        _state.on, _state.group = prev
+
+
+def allreduce_moments(moments, n_local: int, group=None):
+    """SUM-reduce the packed moments tensor in place and return the global row count.
+
+    ``moments`` is a float64 torch tensor ``[G (D*D) | s (D)]`` (CUDA for nccl, CPU for
+    gloo).  The row count travels in the same collective as one extra element so the
+    path has exactly ONE exchange step.
+    """
+    import torch
+    import torch.distributed as dist
+
+    if moments.dtype != torch.float64 or moments.dim() != 1:
+        raise ValueError("moments must be a flat float64 tensor")
+    buf = torch.empty(moments.numel() + 1, dtype=torch.float64, device=moments.device)
+    buf[:-1].copy_(moments)
+    buf[-1] = float(n_local)
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    moments.copy_(buf[:-1])
+    return int(round(float(buf[-1].item())))

@@ -1,0 +1,75 @@
+"""Host-side driver of K1: second moments of a list of views (+ the all-reduce).
+
+``views`` are what ``validate_views`` returned: C-contiguous-izable numpy arrays
+(streamed to the device in row chunks by libccz) or torch CUDA tensors (handed over
+by pointer).  Returns ``(moments_ptr, keepalive, n_total, dims, in_dtype)`` with the
+moments symmetrised and -- inside ``row_sharded()`` -- summed over all ranks.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from cca_zoo_amd import _backend, _dist
+from cca_zoo_amd._utils._validation import is_device_tensor
+
+
+def _common_float(views):
+    """float32 only if every view is float32; anything else computes in float64
+    (the reference's NumPy promotion of mixed inputs ends in float64 too)."""
+    kinds = []
+    for v in views:
+        if is_device_tensor(v):
+            kinds.append("f32" if v.element_size() == 4 else "f64")
+        else:
+            kinds.append("f32" if v.dtype == np.float32 else "f64")
+    return "f32" if all(k == "f32" for k in kinds) else "f64"
+
+
+def compute_moments(views, handle=None):
+    h = handle or _backend.default_handle()
+    n = int(views[0].shape[0])
+    dims = [int(v.shape[1]) for v in views]
+    D = sum(dims)
+    kind = _common_float(views)
+    on_device = all(is_device_tensor(v) for v in views)
+    if any(is_device_tensor(v) for v in views) and not on_device:
+        raise ValueError("views must be all host arrays or all CUDA tensors")
+    keep = []
+    sharded = _dist.is_sharded()
+    if on_device or sharded:
+        import torch
+
+        dev = views[0].device if on_device else torch.device("cuda", h.device)
+        mom_t = torch.empty(D * D + D, dtype=torch.float64, device=dev)
+        mom_ptr = mom_t.data_ptr()
+        keep.append(mom_t)
+    else:
+        mom_buf = h.alloc((D * D + D) * 8)
+        mom_ptr = mom_buf.ptr
+        keep.append(mom_buf)
+        mom_t = None
+    descr = []
+    if on_device:
+        import torch
+
+        tdt = torch.float32 if kind == "f32" else torch.float64
+        for v in views:
+            if v.dtype != tdt or v.stride(1) != 1:
+                v = v.to(tdt).contiguous()
+            keep.append(v)
+            descr.append((v.data_ptr(), v.shape[1], v.stride(0)))
+        torch.cuda.current_stream(views[0].device).synchronize()
+    else:
+        ndt = np.float32 if kind == "f32" else np.float64
+        for v in views:
+            a = np.ascontiguousarray(v, dtype=ndt)
+            keep.append(a)
+            descr.append((a, a.shape[1], a.shape[1]))
+    h.moments(descr, n, _backend.F32 if kind == "f32" else _backend.F64, on_device, mom_ptr, accumulate=False)
+    n_total = n
+    if sharded:
+        h.sync()
+        n_total = _dist.allreduce_moments(mom_t, n, _dist.active_group())
+    h.moments_symmetrize(mom_ptr, D)
+    return mom_ptr, keep, n_total, dims, kind

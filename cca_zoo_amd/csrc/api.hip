@@ -1,0 +1,261 @@
+// libccz C ABI: lifecycle, memory, moments, DCCA loss, transform (HIP build).
+// The solver entry points live in solve.cpp.
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "hip_common.h"
+
+using namespace ccz;
+
+#define CCZ_GUARD(h, ...)                   \
+  if (!(h)) return CCZ_EINVAL;              \
+  try {                                     \
+    __VA_ARGS__;                            \
+    return CCZ_OK;                          \
+  } catch (const ccz::Error& e) {           \
+    (h)->err = e.msg;                       \
+    return e.code;                          \
+  } catch (const std::bad_alloc&) {         \
+    (h)->err = "host allocation failed";    \
+    return CCZ_ENOMEM;                      \
+  } catch (...) {                           \
+    (h)->err = "unknown internal error";    \
+    return CCZ_EHIP;                        \
+  }
+
+namespace ccz {
+
+// ---------------------------------------------------------------------------
+// DCCA correlation loss: value + closed-form input gradients
+// reference: cca_zoo/deep/objectives.py:61-102 (forward) + autograd backward;
+// maths: oracle/losses.py::cca_loss_closed_form
+// ---------------------------------------------------------------------------
+static void cca_loss_impl(ccz_ctx* c, int dtype, const void* z1, const void* z2, int64_t n, int64_t d1, int64_t d2,
+                          int64_t ld1, int64_t ld2, double eps, void* loss_dev, void* g1, void* g2, int64_t ldg1,
+                          int64_t ldg2) {
+  if (dtype != CCZ_F32 && dtype != CCZ_F64) fail(CCZ_EUNSUP, "cca_loss: dtype must be CCZ_F32 or CCZ_F64");
+  if (!z1 || !z2 || !loss_dev) fail(CCZ_EINVAL, "cca_loss: null argument");
+  if (n < 2 || d1 < 1 || d2 < 1 || ld1 < d1 || ld2 < d2) fail(CCZ_EINVAL, "cca_loss: bad shape");
+  if ((g1 && ldg1 < d1) || (g2 && ldg2 < d2)) fail(CCZ_EINVAL, "cca_loss: bad gradient stride");
+  const int64_t D = d1 + d2;
+  DBuf mom(c, D * D + D);
+  ccz_view views[2] = {{z1, d1, ld1}, {z2, d2, ld2}};
+  moments_impl(c, dtype, views, 2, n, true, mom, false);
+  double* G = mom;
+  double* s = mom.get() + D * D;
+  mirror_upper(c, D, G, D);
+  const double inv = 1.0 / double(n - 1);
+
+  DBuf L1(c, d1 * d1), L2(c, d2 * d2), S12(c, d1 * d2);
+  cov_block(c, G, D, s, n, true, inv, 0, d1, 0, d1, L1, d1);
+  add_diag(c, d1, L1, d1, eps);
+  cov_block(c, G, D, s, n, true, inv, d1, d2, d1, d2, L2, d2);
+  add_diag(c, d2, L2, d2, eps);
+  cov_block(c, G, D, s, n, true, inv, 0, d1, d1, d2, S12, d2);
+  if (potrf_lower(c, L1, d1, d1) != 0) fail(CCZ_ENOTSPD, "cca_loss: S11 + eps I is not positive definite");
+  if (potrf_lower(c, L2, d2, d2) != 0) fail(CCZ_ENOTSPD, "cca_loss: S22 + eps I is not positive definite");
+
+  DBuf A(c, d1 * d2), Bm(c, d2 * d1), Bmt(c, d1 * d2);
+  d2d(c, A, S12, size_t(d1) * d2 * 8);
+  chol_solve_inplace(c, d1, d2, L1, d1, A, d2);              // A  = S11^-1 S12
+  transpose(c, d1, d2, S12, d2, Bm, d1);
+  chol_solve_inplace(c, d2, d1, L2, d2, Bm, d1);             // Bm = S22^-1 S21
+  transpose(c, d2, d1, Bm, d1, Bmt, d2);
+  DBuf rd(c, d1);
+  row_dots(c, d1, d2, A, d2, Bmt, d2, rd);
+  std::vector<double> rh(d1);
+  d2h(c, rh.data(), rd, size_t(d1) * 8);
+  double loss = 0.0;
+  for (double v : rh) loss -= v;
+  if (dtype == CCZ_F32) { const float lf = float(loss); h2d(c, loss_dev, &lf, 4); }
+  else h2d(c, loss_dev, &loss, 8);
+  if (!g1 && !g2) return;
+
+  // G12' = -2 S22^-1 A'   (d2 x d1)
+  DBuf G12t(c, d2 * d1), G12(c, d1 * d2);
+  transpose(c, d1, d2, A, d2, G12t, d1);
+  chol_solve_inplace(c, d2, d1, L2, d2, G12t, d1);
+  axpby2d(c, d2, d1, -2.0, G12t, d1, 0.0, nullptr, 0);
+  transpose(c, d2, d1, G12t, d1, G12, d2);
+  // mean row vector
+  DBuf mu(c, D);
+  d2d(c, mu, s, size_t(D) * 8);
+  axpby2d(c, 1, D, 1.0 / double(n), mu, D, 0.0, nullptr, 0);
+
+  auto sym_grad = [&](int64_t da, const double* P /*da x da*/, const double* L, DBuf& out) {
+    // out = P S^-1 + (P S^-1)'  with S = L L'
+    DBuf Pt(c, da * da);
+    transpose(c, da, da, P, da, Pt, da);
+    chol_solve_inplace(c, da, da, L, da, Pt, da);           // S^-1 P' = (P S^-1)'
+    out = DBuf(c, da * da);
+    transpose(c, da, da, Pt, da, out, da);
+    axpby2d(c, da, da, 1.0, out, da, 1.0, Pt, da);
+  };
+  if (g1) {
+    DBuf P(c, d1 * d1), G11s, bias(c, d1);
+    gemm(c, false, false, d1, d1, d2, 1.0, A, d2, Bm, d1, 0.0, P, d1);
+    sym_grad(d1, P, L1, G11s);
+    gemm(c, false, false, 1, d1, d1, 1.0, mu, D, G11s, d1, 0.0, bias, d1);
+    gemm(c, false, false, 1, d1, d2, 1.0, mu.get() + d1, D, G12t, d1, 1.0, bias, d1);
+    gemm_mixed(c, dtype, n, d1, d1, inv, z1, ld1, G11s, d1, 0.0, g1, ldg1, bias);
+    gemm_mixed(c, dtype, n, d1, d2, inv, z2, ld2, G12t, d1, 1.0, g1, ldg1, nullptr);
+    sync(c);   // G11s / bias are pooled scratch: finish before they are recycled
+  }
+  if (g2) {
+    DBuf P(c, d2 * d2), G22s, bias(c, d2);
+    gemm(c, false, false, d2, d2, d1, 1.0, Bm, d1, A, d2, 0.0, P, d2);
+    sym_grad(d2, P, L2, G22s);
+    gemm(c, false, false, 1, d2, d2, 1.0, mu.get() + d1, D, G22s, d2, 0.0, bias, d2);
+    gemm(c, false, false, 1, d2, d1, 1.0, mu, D, G12, d2, 1.0, bias, d2);
+    gemm_mixed(c, dtype, n, d2, d2, inv, z2, ld2, G22s, d2, 0.0, g2, ldg2, bias);
+    gemm_mixed(c, dtype, n, d2, d1, inv, z1, ld1, G12, d2, 1.0, g2, ldg2, nullptr);
+    sync(c);
+  }
+}
+
+// out = (X - mean) W     reference: cca_zoo/_base.py:108-123
+static void transform_impl(ccz_ctx* c, int dtype, const void* X, int64_t n, int64_t d, int64_t ld, const double* mean,
+                           const double* W, int64_t k, void* out, int64_t ldo) {
+  if (dtype != CCZ_F32 && dtype != CCZ_F64) fail(CCZ_EUNSUP, "transform: dtype must be CCZ_F32 or CCZ_F64");
+  if (!X || !W || !out || n < 1 || d < 1 || k < 1 || ld < d || ldo < k) fail(CCZ_EINVAL, "transform: bad argument");
+  DBuf bias(c, k);
+  if (mean) gemm(c, false, false, 1, k, d, 1.0, mean, d, W, k, 0.0, bias, k);
+  gemm_mixed(c, dtype, n, k, d, 1.0, X, ld, W, k, 0.0, out, ldo, mean ? bias.get() : nullptr);
+  sync(c);
+}
+
+}  // namespace ccz
+
+extern "C" {
+
+int ccz_version(void) { return CCZ_VERSION; }
+
+int ccz_create(ccz_handle* out, int device) {
+  if (!out) return CCZ_EINVAL;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); return CCZ_EHIP; }
+  if (device < 0 || device >= count) return CCZ_EINVAL;
+  if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return CCZ_EHIP; }
+  ccz_ctx* c = new (std::nothrow) ccz_ctx();
+  Impl* im = new (std::nothrow) Impl();
+  if (!c || !im) { delete c; delete im; return CCZ_ENOMEM; }
+  c->device = device;
+  c->impl = im;
+  bool ok = hipGetDeviceProperties(&im->props, device) == hipSuccess;
+  for (int i = 0; ok && i < 4; ++i) ok = hipEventCreate(&im->ev[i]) == hipSuccess;
+  ok = ok && hipMalloc(reinterpret_cast<void**>(&im->d_flag), 64 * sizeof(int)) == hipSuccess;
+  ok = ok && hipMalloc(reinterpret_cast<void**>(&im->d_small), im->small_cap * sizeof(double)) == hipSuccess;
+  if (!ok) { (void)hipGetLastError(); delete im; delete c; return CCZ_EHIP; }
+  *out = c;
+  return CCZ_OK;
+}
+
+int ccz_destroy(ccz_handle h) {
+  if (!h) return CCZ_OK;
+  Impl* im = impl(h);
+  if (im) {
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    for (auto& b : im->pool) (void)hipFree(b.p);
+    for (int i = 0; i < 4; ++i) (void)hipEventDestroy(im->ev[i]);
+    (void)hipFree(im->d_flag);
+    (void)hipFree(im->d_small);
+    delete im;
+  }
+  delete h;
+  return CCZ_OK;
+}
+
+const char* ccz_last_error(ccz_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+int ccz_set_stream(ccz_handle h, void* s) {
+  CCZ_GUARD(h, {
+    CCZ_HIP(hipSetDevice(h->device));
+    CCZ_HIP(hipStreamSynchronize(stream(h)));
+    h->stream = s;
+  })
+}
+
+int ccz_sync(ccz_handle h) { CCZ_GUARD(h, sync(h)) }
+
+int ccz_device_info(ccz_handle h, ccz_devinfo* out) {
+  CCZ_GUARD(h, {
+    if (!out) fail(CCZ_EINVAL, "null argument");
+    Impl* im = impl(h);
+    std::memset(out, 0, sizeof(*out));
+    std::strncpy(out->name, im->props.name, sizeof(out->name) - 1);
+    std::strncpy(out->arch, im->props.gcnArchName, sizeof(out->arch) - 1);
+    out->compute_units = im->props.multiProcessorCount;
+    out->wavefront = im->props.warpSize;
+    out->hbm_bytes = int64_t(im->props.totalGlobalMem);
+    out->lds_bytes_per_cu = int64_t(im->props.maxSharedMemoryPerMultiProcessor);
+  })
+}
+
+int ccz_dev_alloc(ccz_handle h, void** out, size_t bytes) {
+  CCZ_GUARD(h, {
+    if (!out) fail(CCZ_EINVAL, "null argument");
+    CCZ_HIP(hipSetDevice(h->device));
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 8);
+    if (e != hipSuccess) { (void)hipGetLastError(); fail(CCZ_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
+    *out = p;
+  })
+}
+
+int ccz_dev_free(ccz_handle h, void* p) {
+  CCZ_GUARD(h, {
+    if (p) {
+      CCZ_HIP(hipStreamSynchronize(stream(h)));
+      CCZ_HIP(hipFree(p));
+    }
+  })
+}
+
+int ccz_memcpy_h2d(ccz_handle h, void* dst, const void* src, size_t bytes) { CCZ_GUARD(h, h2d(h, dst, src, bytes)) }
+int ccz_memcpy_d2h(ccz_handle h, void* dst, const void* src, size_t bytes) { CCZ_GUARD(h, d2h(h, dst, src, bytes)) }
+int ccz_memset0(ccz_handle h, void* dst, size_t bytes) { CCZ_GUARD(h, zero(h, dst, bytes)) }
+
+int ccz_moments(ccz_handle h, int dtype, const ccz_view* views, int n_views, int64_t n_rows, int views_on_device,
+                double* moments_dev, int accumulate) {
+  CCZ_GUARD(h, {
+    CCZ_HIP(hipSetDevice(h->device));
+    moments_impl(h, dtype, views, n_views, n_rows, views_on_device != 0, moments_dev, accumulate != 0);
+  })
+}
+
+int ccz_moments_symmetrize(ccz_handle h, double* moments_dev, int64_t D) {
+  CCZ_GUARD(h, {
+    if (!moments_dev || D < 1) fail(CCZ_EINVAL, "bad argument");
+    mirror_upper(h, D, moments_dev, D);
+  })
+}
+
+int ccz_moments_last_ms(ccz_handle h, double* gram_ms, double* colsum_ms) {
+  CCZ_GUARD(h, {
+    if (gram_ms) *gram_ms = h->last_gram_ms;
+    if (colsum_ms) *colsum_ms = h->last_colsum_ms;
+  })
+}
+
+int ccz_cca_loss(ccz_handle h, int dtype, const void* z1_dev, const void* z2_dev, int64_t n, int64_t d1, int64_t d2,
+                 int64_t ld1, int64_t ld2, double eps, void* loss_dev, void* g1_dev, void* g2_dev, int64_t ldg1,
+                 int64_t ldg2) {
+  CCZ_GUARD(h, {
+    CCZ_HIP(hipSetDevice(h->device));
+    cca_loss_impl(h, dtype, z1_dev, z2_dev, n, d1, d2, ld1, ld2, eps, loss_dev, g1_dev, g2_dev, ldg1, ldg2);
+  })
+}
+
+int ccz_transform(ccz_handle h, int dtype, const void* X_dev, int64_t n, int64_t d, int64_t ld, const double* mean_dev,
+                  const double* W_dev, int64_t k, void* out_dev, int64_t ldo) {
+  CCZ_GUARD(h, {
+    CCZ_HIP(hipSetDevice(h->device));
+    transform_impl(h, dtype, X_dev, n, d, ld, mean_dev, W_dev, k, out_dev, ldo);
+  })
+}
+
+}  // extern "C"

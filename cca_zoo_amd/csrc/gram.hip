@@ -1,0 +1,479 @@
+// K1 -- second moments of the column-stacked views on the gfx950 matrix pipe.
+//
+//   G += [X_1..X_m]' [X_1..X_m]      (upper-triangular tiles, fp64 in HBM)
+//   s += 1' [X_1..X_m]
+//
+// Data layout: every view is row-major n x d_i (the reference's layout,
+// cca_zoo/_base.py:78-102), so a k-step of the contraction is a ROW of the
+// data: the A and B operands of X'X are both "k-major", exactly the layout the
+// MFMA A (i, k) / B (k, j) fragments want.  A workgroup stages BK rows of a
+// 256-column (fp32) / 128-column (fp64) panel into LDS with coalesced 16-byte
+// loads; each wave then reads its fragments with ONE ds_read_b128 per operand
+// per k-step: lane l takes 4 consecutive columns 4*(l % 32) .. +3 of row
+// (l / 32), and the 4 values feed 4 different 32x32 MFMA tiles (tile t owns the
+// columns == t mod 4).  That strided tile ownership is undone in the epilogue.
+//
+// Work decomposition: grid = (upper-triangular tile) x (row chunk).  fp32 views
+// accumulate a chunk (<= 4096 rows) in fp32 MFMA accumulators and flush into
+// the fp64 G with hardware fp64 atomics, so cross-chunk / cross-GPU
+// accumulation is fp64 (hard part 2).  blockIdx is chunk-major:
+// the ~256 resident workgroups stream the same rows of different panels, which
+// keeps the panel rows hot in L2 / Infinity Cache while HBM sees each input
+// byte about once.
+//
+// Roofline: F = n D (D+1) flop on v_mfma_f32_32x32x2_f32 (157.3 TF peak) or
+// v_mfma_f64_16x16x4_f64; B = n D sizeof(T) bytes.  MFMA-bound.
+#include <algorithm>
+#include <cstdio>
+#include <vector>
+
+#include "hip_common.h"
+
+namespace ccz {
+
+struct GramTile {
+  const void* a;
+  const void* b;
+  int64_t lda, ldb;
+  int64_t out_row, out_col;
+  int32_t wa, wb;
+  int32_t diag;
+  int32_t pad_;
+};
+
+typedef float v16f32 __attribute__((ext_vector_type(16)));
+typedef float v4f32 __attribute__((ext_vector_type(4)));
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+typedef double v2f64 __attribute__((ext_vector_type(2)));
+
+constexpr int BK = 16;
+
+// The panel pointers come out of the tile table (memory), so the compiler cannot prove their
+// address space and would emit flat_load (which also ties up lgkmcnt and stalls the LDS reads).
+// Cast to the global address space explicitly.
+typedef const float __attribute__((address_space(1)))* gptr_f32;
+typedef const double __attribute__((address_space(1)))* gptr_f64;
+
+// ---------------------------------------------------------------------------
+// fp32: 256 x 256 tile per workgroup, 4 waves (2 x 2), each wave 128 x 128 =
+// 4 x 4 MFMA 32x32x2 tiles (256 accumulator registers, one wave per SIMD)
+// ---------------------------------------------------------------------------
+constexpr int T32 = 256;
+
+template <bool FAST>
+__device__ __forceinline__ v4f32 load4_f32(gptr_f32 base, int64_t row, int64_t last_row, int cg, int64_t ld, int width) {
+  // rows past the shard end are clamped to a valid row here and zeroed when staged into LDS
+  // (a select on the loaded value here would force the vmcnt wait ahead of the MFMAs)
+  const bool ok = row <= last_row;
+  gptr_f32 p = base + (ok ? row : last_row) * ld + 4 * cg;
+  v4f32 v = {0.f, 0.f, 0.f, 0.f};
+  if (FAST) {
+    v = *reinterpret_cast<const v4f32 __attribute__((address_space(1)))*>(p);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (4 * cg + e < width) v[e] = p[e];
+  }
+  return v;
+}
+
+template <bool FAST>
+__global__ __launch_bounds__(256, 1) void k_gram_f32(const GramTile* __restrict__ tiles, int ntiles, int64_t n,
+                                                     int64_t rows_per_wg, double* __restrict__ G, int64_t ldg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* lds = reinterpret_cast<float*>(smem);  // [2 buffers][A | B][BK][256]
+  const int tile_id = int(blockIdx.x % unsigned(ntiles));
+  const int64_t ks = blockIdx.x / unsigned(ntiles);
+  const GramTile t = tiles[tile_id];
+  const int64_t k_begin = ks * rows_per_wg;
+  const int64_t k_end = min(n, k_begin + rows_per_wg);
+  if (k_begin >= k_end) return;
+  gptr_f32 A = (gptr_f32)(t.a);
+  gptr_f32 B = (gptr_f32)(t.b);
+  const int64_t last_row = k_end - 1;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int cg = tid & 63, r4 = tid >> 6;
+
+  v16f32 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  v4f32 ra[4], rb[4];
+  auto gload = [&](int64_t k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t row = k0 + r4 + 4 * i;
+      ra[i] = load4_f32<FAST>(A, row, last_row, cg, t.lda, t.wa);
+      rb[i] = load4_f32<FAST>(B, row, last_row, cg, t.ldb, t.wb);
+    }
+  };
+  auto lstore = [&](int buf, int64_t k0) {
+    float* as = lds + buf * (2 * BK * T32);
+    float* bs = as + BK * T32;
+    const v4f32 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool ok = k0 + r4 + 4 * i <= last_row;
+      *reinterpret_cast<v4f32*>(as + (r4 + 4 * i) * T32 + 4 * cg) = ok ? ra[i] : z;
+      *reinterpret_cast<v4f32*>(bs + (r4 + 4 * i) * T32 + 4 * cg) = ok ? rb[i] : z;
+    }
+  };
+
+  const int64_t nkb = (k_end - k_begin + BK - 1) / BK;
+  gload(k_begin);
+  lstore(0, k_begin);
+  __syncthreads();
+  for (int64_t kb = 0; kb < nkb; ++kb) {
+    const int cur = int(kb & 1);
+    if (kb + 1 < nkb) gload(k_begin + (kb + 1) * BK);
+    const float* as = lds + cur * (2 * BK * T32);
+    const float* bs = as + BK * T32;
+    // fragment reads run one k-step ahead of the MFMAs that consume them
+    v4f32 af[2], bf[2];
+    af[0] = *reinterpret_cast<const v4f32*>(as + (lane >> 5) * T32 + wr * 128 + 4 * (lane & 31));
+    bf[0] = *reinterpret_cast<const v4f32*>(bs + (lane >> 5) * T32 + wc * 128 + 4 * (lane & 31));
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      if (kk + 1 < BK / 2) {
+        const int krow = 2 * (kk + 1) + (lane >> 5);
+        af[(kk + 1) & 1] = *reinterpret_cast<const v4f32*>(as + krow * T32 + wr * 128 + 4 * (lane & 31));
+        bf[(kk + 1) & 1] = *reinterpret_cast<const v4f32*>(bs + krow * T32 + wc * 128 + 4 * (lane & 31));
+      }
+      __builtin_amdgcn_sched_barrier(0);   // keep the next k-step's LDS reads in flight under these MFMAs
+      const v4f32 a4 = af[kk & 1], b4 = bf[kk & 1];
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+          acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[ti], b4[tj], acc[ti][tj], 0, 0, 0);
+    }
+    if (kb + 1 < nkb) lstore(cur ^ 1, k_begin + (kb + 1) * BK);
+    __syncthreads();
+  }
+
+  // epilogue: fp32 chunk sums -> fp64 G.  32x32 C/D layout: col = lane & 31,
+  // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); tile (ti, tj) owns the
+  // columns == ti (A side) / tj (B side) mod 4 of the wave's 128-wide slabs.
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int trow = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int i = wr * 128 + 4 * trow + ti;
+      if (!FAST && i >= t.wa) continue;
+      double* grow = G + (t.out_row + i) * ldg + t.out_col;
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj) {
+        const int j = wc * 128 + 4 * (lane & 31) + tj;
+        if (FAST || j < t.wb) unsafeAtomicAdd(grow + j, double(acc[ti][tj][r]));
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// fp64: 128 x 128 tile per workgroup, 4 waves (2 x 2), each wave 64 x 64 =
+// 4 x 4 MFMA f64 16x16x4 tiles (128 accumulator registers)
+// ---------------------------------------------------------------------------
+constexpr int T64 = 128;
+
+template <bool FAST>
+__device__ __forceinline__ v2f64 load2_f64(gptr_f64 base, int64_t row, int64_t last_row, int cg, int64_t ld, int width) {
+  const bool ok = row <= last_row;
+  gptr_f64 p = base + (ok ? row : last_row) * ld + 2 * cg;
+  v2f64 v = {0.0, 0.0};
+  if (FAST) {
+    v = *reinterpret_cast<const v2f64 __attribute__((address_space(1)))*>(p);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+      if (2 * cg + e < width) v[e] = p[e];
+  }
+  return v;
+}
+
+template <bool FAST>
+__global__ __launch_bounds__(256, 1) void k_gram_f64(const GramTile* __restrict__ tiles, int ntiles, int64_t n,
+                                                     int64_t rows_per_wg, double* __restrict__ G, int64_t ldg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* lds = reinterpret_cast<double*>(smem);  // [2 buffers][A | B][BK][128]
+  const int tile_id = int(blockIdx.x % unsigned(ntiles));
+  const int64_t ks = blockIdx.x / unsigned(ntiles);
+  const GramTile t = tiles[tile_id];
+  const int64_t k_begin = ks * rows_per_wg;
+  const int64_t k_end = min(n, k_begin + rows_per_wg);
+  if (k_begin >= k_end) return;
+  gptr_f64 A = (gptr_f64)(t.a);
+  gptr_f64 B = (gptr_f64)(t.b);
+  const int64_t last_row = k_end - 1;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int cg = tid & 63, r4 = tid >> 6;
+
+  v4f64 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
+
+  v2f64 ra[4], rb[4];
+  auto gload = [&](int64_t k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t row = k0 + r4 + 4 * i;
+      ra[i] = load2_f64<FAST>(A, row, last_row, cg, t.lda, t.wa);
+      rb[i] = load2_f64<FAST>(B, row, last_row, cg, t.ldb, t.wb);
+    }
+  };
+  auto lstore = [&](int buf, int64_t k0) {
+    double* as = lds + buf * (2 * BK * T64);
+    double* bs = as + BK * T64;
+    const v2f64 z = {0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool ok = k0 + r4 + 4 * i <= last_row;
+      *reinterpret_cast<v2f64*>(as + (r4 + 4 * i) * T64 + 2 * cg) = ok ? ra[i] : z;
+      *reinterpret_cast<v2f64*>(bs + (r4 + 4 * i) * T64 + 2 * cg) = ok ? rb[i] : z;
+    }
+  };
+
+  const int64_t nkb = (k_end - k_begin + BK - 1) / BK;
+  gload(k_begin);
+  lstore(0, k_begin);
+  __syncthreads();
+  for (int64_t kb = 0; kb < nkb; ++kb) {
+    const int cur = int(kb & 1);
+    if (kb + 1 < nkb) gload(k_begin + (kb + 1) * BK);
+    const double* as = lds + cur * (2 * BK * T64);
+    const double* bs = as + BK * T64;
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk) {
+      const int krow = 4 * kk + (lane >> 4);
+      const double* ap = as + krow * T64 + wr * 64 + 4 * (lane & 15);
+      const double* bp = bs + krow * T64 + wc * 64 + 4 * (lane & 15);
+      const v2f64 a01 = *reinterpret_cast<const v2f64*>(ap), a23 = *reinterpret_cast<const v2f64*>(ap + 2);
+      const v2f64 b01 = *reinterpret_cast<const v2f64*>(bp), b23 = *reinterpret_cast<const v2f64*>(bp + 2);
+      const double a4[4] = {a01[0], a01[1], a23[0], a23[1]};
+      const double b4[4] = {b01[0], b01[1], b23[0], b23[1]};
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+          acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[ti], b4[tj], acc[ti][tj], 0, 0, 0);
+    }
+    if (kb + 1 < nkb) lstore(cur ^ 1, k_begin + (kb + 1) * BK);
+    __syncthreads();
+  }
+
+  // f64 16x16 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int trow = (lane >> 4) + 4 * r;
+      const int i = wr * 64 + 4 * trow + ti;
+      if (!FAST && i >= t.wa) continue;
+      double* grow = G + (t.out_row + i) * ldg + t.out_col;
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj) {
+        const int j = wc * 64 + 4 * (lane & 15) + tj;
+        if (FAST || j < t.wb) unsafeAtomicAdd(grow + j, acc[ti][tj][r]);
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// column sums: HBM-bound single pass, fp64 accumulation
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_colsum(const T* __restrict__ X, int64_t n, int64_t cols, int64_t ld,
+                                                double* __restrict__ out, int64_t rows_per_block) {
+  const int64_t col = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (col >= cols) return;
+  const int64_t r0 = int64_t(blockIdx.y) * rows_per_block;
+  const int64_t r1 = min(n, r0 + rows_per_block);
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int64_t r = r0;
+  for (; r + 3 < r1; r += 4) {
+    a0 += double(X[(r + 0) * ld + col]);
+    a1 += double(X[(r + 1) * ld + col]);
+    a2 += double(X[(r + 2) * ld + col]);
+    a3 += double(X[(r + 3) * ld + col]);
+  }
+  for (; r < r1; ++r) a0 += double(X[r * ld + col]);
+  unsafeAtomicAdd(out + col, (a0 + a1) + (a2 + a3));
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+namespace {
+
+struct Panel {
+  int view;
+  int64_t col0, width, gcol0;
+};
+
+template <typename T>
+void launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, double* G, double* s, int64_t D,
+                    bool time_it) {
+  Impl* im = impl(c);
+  hipStream_t st = stream(c);
+  constexpr bool is32 = sizeof(T) == 4;
+  const int tile = is32 ? T32 : T64;
+  std::vector<Panel> panels;
+  int64_t g0 = 0;
+  bool fast = true;
+  for (int v = 0; v < n_views; ++v) {
+    for (int64_t c0 = 0; c0 < views[v].cols; c0 += tile)
+      panels.push_back({v, c0, std::min<int64_t>(tile, views[v].cols - c0), g0 + c0});
+    if (views[v].cols % tile != 0) fast = false;
+    if ((views[v].ld * sizeof(T)) % 16 != 0) fast = false;
+    if (reinterpret_cast<uintptr_t>(views[v].data) % 16 != 0) fast = false;
+    g0 += views[v].cols;
+  }
+  std::vector<GramTile> tiles;
+  const int np = int(panels.size());
+  for (int i = 0; i < np; ++i)
+    for (int j = i; j < np; ++j) {
+      const Panel& a = panels[i];
+      const Panel& b = panels[j];
+      GramTile t;
+      t.a = static_cast<const T*>(views[a.view].data) + a.col0;
+      t.b = static_cast<const T*>(views[b.view].data) + b.col0;
+      t.lda = views[a.view].ld;
+      t.ldb = views[b.view].ld;
+      t.out_row = a.gcol0;
+      t.out_col = b.gcol0;
+      t.wa = int32_t(a.width);
+      t.wb = int32_t(b.width);
+      t.diag = (i == j) ? 1 : 0;
+      t.pad_ = 0;
+      tiles.push_back(t);
+    }
+  const int ntiles = int(tiles.size());
+  GramTile* d_tiles = static_cast<GramTile*>(dev_alloc(c, tiles.size() * sizeof(GramTile)));
+  h2d(c, d_tiles, tiles.data(), tiles.size() * sizeof(GramTile));
+
+  const int ncu = std::max(1, im->props.multiProcessorCount);
+  const int64_t max_rows = is32 ? 4096 : 16384;
+  int64_t rows_per_wg = (n * ntiles + int64_t(ncu) * 8 - 1) / (int64_t(ncu) * 8);
+  rows_per_wg = std::max<int64_t>(256, std::min<int64_t>(max_rows, rows_per_wg));
+  rows_per_wg = (rows_per_wg + BK - 1) / BK * BK;
+  const int64_t ksplit = (n + rows_per_wg - 1) / rows_per_wg;
+  const int64_t nblocks = ksplit * ntiles;
+  if (nblocks > 0x7fffffffLL) fail(CCZ_EUNSUP, "gram: grid too large");
+  const size_t lds_bytes = size_t(2) * 2 * BK * tile * sizeof(T);  // 64 KiB either way
+
+  if (time_it) CCZ_HIP(hipEventRecord(im->ev[0], st));
+  if (is32) {
+    if (fast) {
+      CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_f32<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
+      hipLaunchKernelGGL(k_gram_f32<true>, dim3((unsigned)nblocks), dim3(256), lds_bytes, st, d_tiles, ntiles, n, rows_per_wg, G, D);
+    } else {
+      CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_f32<false>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
+      hipLaunchKernelGGL(k_gram_f32<false>, dim3((unsigned)nblocks), dim3(256), lds_bytes, st, d_tiles, ntiles, n, rows_per_wg, G, D);
+    }
+  } else {
+    if (fast) {
+      CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_f64<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
+      hipLaunchKernelGGL(k_gram_f64<true>, dim3((unsigned)nblocks), dim3(256), lds_bytes, st, d_tiles, ntiles, n, rows_per_wg, G, D);
+    } else {
+      CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_f64<false>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
+      hipLaunchKernelGGL(k_gram_f64<false>, dim3((unsigned)nblocks), dim3(256), lds_bytes, st, d_tiles, ntiles, n, rows_per_wg, G, D);
+    }
+  }
+  CCZ_LAUNCH_CHECK();
+  if (time_it) {
+    CCZ_HIP(hipEventRecord(im->ev[1], st));
+    CCZ_HIP(hipEventRecord(im->ev[2], st));
+  }
+  int64_t off = 0;
+  for (int v = 0; v < n_views; ++v) {
+    const int64_t rpb = 2048;
+    dim3 grid((unsigned)((views[v].cols + 255) / 256), (unsigned)((n + rpb - 1) / rpb));
+    hipLaunchKernelGGL(k_colsum<T>, grid, dim3(256), 0, st, static_cast<const T*>(views[v].data), n, views[v].cols,
+                       views[v].ld, s + off, rpb);
+    off += views[v].cols;
+  }
+  CCZ_LAUNCH_CHECK();
+  if (time_it) {
+    CCZ_HIP(hipEventRecord(im->ev[3], st));
+    CCZ_HIP(hipEventSynchronize(im->ev[3]));
+    float g = 0.f, cs = 0.f;
+    CCZ_HIP(hipEventElapsedTime(&g, im->ev[0], im->ev[1]));
+    CCZ_HIP(hipEventElapsedTime(&cs, im->ev[2], im->ev[3]));
+    c->last_gram_ms += g;
+    c->last_colsum_ms += cs;
+  }
+  // the tile table must outlive the kernel: stream-ordered, so synchronise before recycling it
+  CCZ_HIP(hipStreamSynchronize(st));
+  dev_free(c, d_tiles);
+}
+
+}  // namespace
+
+void moments_impl(ccz_ctx* c, int dtype, const ccz_view* views, int n_views, int64_t n_rows, bool on_device,
+                  double* moments, bool accumulate) {
+  if (!views || n_views < 1 || !moments) fail(CCZ_EINVAL, "moments: null argument");
+  if (dtype != CCZ_F32 && dtype != CCZ_F64) fail(CCZ_EUNSUP, "moments: dtype must be CCZ_F32 or CCZ_F64");
+  if (n_rows < 0) fail(CCZ_EINVAL, "moments: negative row count");
+  int64_t D = 0;
+  for (int v = 0; v < n_views; ++v) {
+    if (views[v].cols < 1 || views[v].ld < views[v].cols || (!views[v].data && n_rows > 0))
+      fail(CCZ_EINVAL, "moments: view %d is malformed (cols=%lld ld=%lld)", v, (long long)views[v].cols, (long long)views[v].ld);
+    D += views[v].cols;
+  }
+  double* G = moments;
+  double* s = moments + D * D;
+  if (!accumulate) zero(c, moments, size_t(D * D + D) * 8);
+  c->last_gram_ms = 0.0;
+  c->last_colsum_ms = 0.0;
+  if (n_rows == 0) return;
+  const size_t es = dtype == CCZ_F32 ? 4 : 8;
+  if (on_device) {
+    if (dtype == CCZ_F32) launch_moments<float>(c, views, n_views, n_rows, G, s, D, true);
+    else launch_moments<double>(c, views, n_views, n_rows, G, s, D, true);
+    return;
+  }
+  // host-resident views: stream row chunks through a dense device staging area
+  int64_t row_bytes = 0;
+  for (int v = 0; v < n_views; ++v) row_bytes += views[v].cols * int64_t(es);
+  int64_t chunk = std::max<int64_t>(1, (int64_t(512) << 20) / row_bytes);
+  chunk = std::min(chunk, n_rows);
+  std::vector<void*> stage(n_views, nullptr);
+  std::vector<ccz_view> dv(n_views);
+  try {
+    for (int v = 0; v < n_views; ++v) {
+      stage[v] = dev_alloc(c, size_t(chunk) * views[v].cols * es);
+      dv[v].data = stage[v];
+      dv[v].cols = views[v].cols;
+      dv[v].ld = views[v].cols;
+    }
+    for (int64_t r0 = 0; r0 < n_rows; r0 += chunk) {
+      const int64_t rows = std::min(chunk, n_rows - r0);
+      for (int v = 0; v < n_views; ++v) {
+        const char* src = static_cast<const char*>(views[v].data) + size_t(r0) * views[v].ld * es;
+        CCZ_HIP(hipMemcpy2DAsync(stage[v], size_t(views[v].cols) * es, src, size_t(views[v].ld) * es,
+                                 size_t(views[v].cols) * es, size_t(rows), hipMemcpyHostToDevice, stream(c)));
+      }
+      CCZ_HIP(hipStreamSynchronize(stream(c)));
+      if (dtype == CCZ_F32) launch_moments<float>(c, dv.data(), n_views, rows, G, s, D, true);
+      else launch_moments<double>(c, dv.data(), n_views, rows, G, s, D, true);
+    }
+  } catch (...) {
+    for (void* p : stage) dev_free(c, p);
+    throw;
+  }
+  for (void* p : stage) dev_free(c, p);
+}
+
+}  // namespace ccz

@@ -1,0 +1,49 @@
+// Shared HIP-side declarations of libccz (product build only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "ops.h"
+
+namespace ccz {
+
+struct PoolBlock {
+  void* p;
+  size_t bytes;
+  bool used;
+};
+
+struct Impl {
+  hipDeviceProp_t props;
+  std::vector<PoolBlock> pool;
+  hipEvent_t ev[4];
+  int* d_flag = nullptr;      // small device scratch: ints
+  double* d_small = nullptr;  // small device scratch: 64K doubles
+  size_t small_cap = 65536;
+};
+
+inline Impl* impl(ccz_ctx* c) { return static_cast<Impl*>(c->impl); }
+inline hipStream_t stream(ccz_ctx* c) { return static_cast<hipStream_t>(c->stream); }
+
+#define CCZ_HIP(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess)                                                                     \
+      ::ccz::fail(CCZ_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                  __LINE__);                                                                  \
+  } while (0)
+
+#define CCZ_LAUNCH_CHECK() CCZ_HIP(hipGetLastError())
+
+// gram.hip
+void moments_impl(ccz_ctx* c, int dtype, const ccz_view* views, int n_views, int64_t n_rows,
+                  bool on_device, double* moments, bool accumulate);
+// typed GEMM used by the loss backward / transform: C (M x N) = alpha A (M x K) B (K x N) + beta C
+// A, C of type T (float or double); B is float64 on the device and converted on load.
+void gemm_mixed(ccz_ctx* c, int dtype, int64_t M, int64_t N, int64_t K, double alpha, const void* A,
+                int64_t lda, const double* B, int64_t ldb, double beta, void* C, int64_t ldc,
+                const double* bias_row /* N, subtracted before alpha; may be null */);
+
+}  // namespace ccz

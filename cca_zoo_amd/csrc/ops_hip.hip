@@ -1,0 +1,692 @@
+// HIP (gfx950 / CDNA4) implementation of the device-op interface in ops.h.
+//
+// Everything here is float64 dense linear algebra on d x d (d <= ~16k) blocks
+// that lives AFTER the Gram reduction: it is latency / launch bound, not on the
+// MFMA or HBM roofline (DESIGN.md "solver stage").  The GEMM uses the fp64
+// matrix pipe (v_mfma_f64_16x16x4_f64); Cholesky / triangular solves are
+// blocked around it; the Jacobi rotations run one workgroup per row pair.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "hip_common.h"
+#include "rng_hash.h"
+
+namespace ccz {
+
+// ===========================================================================
+// memory pool + copies
+// ===========================================================================
+void* dev_alloc(ccz_ctx* c, size_t bytes) {
+  Impl* im = impl(c);
+  if (bytes == 0) bytes = 8;
+  bytes = (bytes + 255) & ~size_t(255);
+  int best = -1;
+  for (size_t i = 0; i < im->pool.size(); ++i) {
+    PoolBlock& b = im->pool[i];
+    if (!b.used && b.bytes >= bytes && b.bytes <= bytes + bytes / 4 + 4096) {
+      if (best < 0 || b.bytes < im->pool[best].bytes) best = int(i);
+    }
+  }
+  if (best >= 0) {
+    im->pool[best].used = true;
+    return im->pool[best].p;
+  }
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) {
+    // release cached blocks and retry once
+    (void)hipGetLastError();
+    CCZ_HIP(hipStreamSynchronize(stream(c)));
+    for (auto it = im->pool.begin(); it != im->pool.end();) {
+      if (!it->used) { (void)hipFree(it->p); it = im->pool.erase(it); } else ++it;
+    }
+    e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) { (void)hipGetLastError(); fail(CCZ_ENOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e)); }
+  }
+  im->pool.push_back({p, bytes, true});
+  return p;
+}
+
+void dev_free(ccz_ctx* c, void* p) {
+  if (!p) return;
+  Impl* im = impl(c);
+  for (auto& b : im->pool)
+    if (b.p == p) { b.used = false; return; }
+  // not ours: stream-ordered work may still use it, so synchronise before freeing
+  (void)hipStreamSynchronize(stream(c));
+  (void)hipFree(p);
+}
+
+void h2d(ccz_ctx* c, void* dst, const void* src, size_t bytes) {
+  if (!bytes) return;
+  CCZ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream(c)));
+  CCZ_HIP(hipStreamSynchronize(stream(c)));  // src is pageable host memory owned by the caller
+}
+void d2h(ccz_ctx* c, void* dst, const void* src, size_t bytes) {
+  if (!bytes) return;
+  CCZ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream(c)));
+  CCZ_HIP(hipStreamSynchronize(stream(c)));
+}
+void d2d(ccz_ctx* c, void* dst, const void* src, size_t bytes) {
+  if (!bytes || dst == src) return;
+  CCZ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream(c)));
+}
+void zero(ccz_ctx* c, void* dst, size_t bytes) {
+  if (!bytes) return;
+  CCZ_HIP(hipMemsetAsync(dst, 0, bytes, stream(c)));
+}
+void sync(ccz_ctx* c) { CCZ_HIP(hipStreamSynchronize(stream(c))); }
+
+// ===========================================================================
+// GEMM on the matrix pipe: 64x64 block tile, 4 waves (2x2), each wave 2x2 MFMA 16x16x4
+// ===========================================================================
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+typedef float v4f32 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct Mfma16;
+template <> struct Mfma16<double> {
+  typedef v4f64 acc_t;
+  static __device__ __forceinline__ acc_t run(double a, double b, acc_t c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+  static __device__ __forceinline__ int row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
+};
+template <> struct Mfma16<float> {
+  typedef v4f32 acc_t;
+  static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  // C/D layout of v_mfma_f32_16x16x4_f32: col = lane & 15, row = 4 * (lane >> 4) + reg
+  static __device__ __forceinline__ int row(int lane, int reg) { return 4 * (lane >> 4) + reg; }
+};
+
+constexpr int GB = 64;   // block tile edge
+constexpr int GK = 16;   // k-step
+constexpr int GP = 4;    // LDS row padding (elements)
+
+// C = alpha * (op(A) op(B) - bias) + beta * C ;  A, C are T ; B is TB (converted on load)
+template <typename T, typename TBs, bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_kernel(int64_t M, int64_t N, int64_t K, T alpha,
+                                                   const T* __restrict__ A, int64_t lda,
+                                                   const TBs* __restrict__ B, int64_t ldb, T beta,
+                                                   T* __restrict__ C, int64_t ldc,
+                                                   const double* __restrict__ bias) {
+  __shared__ T As[2][GK][GB + GP];
+  __shared__ T Bs[2][GK][GB + GP];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int64_t m0 = int64_t(blockIdx.y) * GB, n0 = int64_t(blockIdx.x) * GB;
+
+  typename Mfma16<T>::acc_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = T(0);
+
+  T ra[4], rb[4];
+  auto load_regs = [&](int64_t k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int m, k;
+      if (TA) { m = tid & 63; k = (tid >> 6) + 4 * i; } else { k = tid & 15; m = (tid >> 4) + 16 * i; }
+      const int64_t gm = m0 + m, gk = k0 + k;
+      T v = T(0);
+      if (gm < M && gk < K) v = TA ? A[gk * lda + gm] : A[gm * lda + gk];
+      ra[i] = v;
+      int n, kb;
+      if (TB) { kb = tid & 15; n = (tid >> 4) + 16 * i; } else { n = tid & 63; kb = (tid >> 6) + 4 * i; }
+      const int64_t gn = n0 + n, gkb = k0 + kb;
+      T w = T(0);
+      if (gn < N && gkb < K) w = T(TB ? B[gn * ldb + gkb] : B[gkb * ldb + gn]);
+      rb[i] = w;
+    }
+  };
+  auto store_regs = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int m, k;
+      if (TA) { m = tid & 63; k = (tid >> 6) + 4 * i; } else { k = tid & 15; m = (tid >> 4) + 16 * i; }
+      As[buf][k][m] = ra[i];
+      int n, kb;
+      if (TB) { kb = tid & 15; n = (tid >> 4) + 16 * i; } else { n = tid & 63; kb = (tid >> 6) + 4 * i; }
+      Bs[buf][kb][n] = rb[i];
+    }
+  };
+
+  const int64_t nk = (K + GK - 1) / GK;
+  load_regs(0);
+  store_regs(0);
+  __syncthreads();
+  for (int64_t kt = 0; kt < nk; ++kt) {
+    const int cur = int(kt & 1);
+    if (kt + 1 < nk) load_regs((kt + 1) * GK);
+#pragma unroll
+    for (int kk = 0; kk < GK / 4; ++kk) {
+      const int kr = 4 * kk + (lane >> 4);
+      T a[2], b[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        a[t] = As[cur][kr][wr * 32 + t * 16 + (lane & 15)];
+        b[t] = Bs[cur][kr][wc * 32 + t * 16 + (lane & 15)];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = Mfma16<T>::run(a[i], b[j], acc[i][j]);
+    }
+    if (kt + 1 < nk) store_regs(cur ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t gm = m0 + wr * 32 + i * 16 + Mfma16<T>::row(lane, r);
+        const int64_t gn = n0 + wc * 32 + j * 16 + (lane & 15);
+        if (gm < M && gn < N) {
+          T v = acc[i][j][r];
+          if (bias) v -= T(bias[gn]);
+          v *= alpha;
+          if (beta != T(0)) v += beta * C[gm * ldc + gn];
+          C[gm * ldc + gn] = v;
+        }
+      }
+}
+
+template <typename T, typename TBs>
+static void gemm_launch(ccz_ctx* c, bool tA, bool tB, int64_t M, int64_t N, int64_t K, T alpha, const T* A,
+                        int64_t lda, const TBs* B, int64_t ldb, T beta, T* C, int64_t ldc, const double* bias) {
+  if (M <= 0 || N <= 0) return;
+  dim3 grid((unsigned)((N + GB - 1) / GB), (unsigned)((M + GB - 1) / GB));
+  if (grid.y > 65535) fail(CCZ_EUNSUP, "gemm: M=%lld too large for one launch", (long long)M);
+  hipStream_t st = stream(c);
+  if (!tA && !tB) hipLaunchKernelGGL((gemm_kernel<T, TBs, false, false>), grid, dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias);
+  else if (tA && !tB) hipLaunchKernelGGL((gemm_kernel<T, TBs, true, false>), grid, dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias);
+  else if (!tA && tB) hipLaunchKernelGGL((gemm_kernel<T, TBs, false, true>), grid, dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias);
+  else hipLaunchKernelGGL((gemm_kernel<T, TBs, true, true>), grid, dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias);
+  CCZ_LAUNCH_CHECK();
+}
+
+void gemm(ccz_ctx* c, bool tA, bool tB, int64_t M, int64_t N, int64_t K, double alpha, const double* A,
+          int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc) {
+  // split very tall outputs so that grid.y stays legal
+  const int64_t maxM = int64_t(65535) * GB;
+  for (int64_t m = 0; m < M; m += maxM) {
+    const int64_t mm = std::min(maxM, M - m);
+    const double* Ap = tA ? A + m : A + m * lda;
+    gemm_launch<double, double>(c, tA, tB, mm, N, K, alpha, Ap, lda, B, ldb, beta, C + m * ldc, ldc, nullptr);
+  }
+}
+
+void gemm_mixed(ccz_ctx* c, int dtype, int64_t M, int64_t N, int64_t K, double alpha, const void* A, int64_t lda,
+                const double* B, int64_t ldb, double beta, void* C, int64_t ldc, const double* bias_row) {
+  const int64_t maxM = int64_t(65535) * GB;
+  for (int64_t m = 0; m < M; m += maxM) {
+    const int64_t mm = std::min(maxM, M - m);
+    if (dtype == CCZ_F32)
+      gemm_launch<float, double>(c, false, false, mm, N, K, float(alpha), static_cast<const float*>(A) + m * lda, lda,
+                                 B, ldb, float(beta), static_cast<float*>(C) + m * ldc, ldc, bias_row);
+    else
+      gemm_launch<double, double>(c, false, false, mm, N, K, alpha, static_cast<const double*>(A) + m * lda, lda, B,
+                                  ldb, beta, static_cast<double*>(C) + m * ldc, ldc, bias_row);
+  }
+}
+
+// ===========================================================================
+// elementwise / layout kernels
+// ===========================================================================
+__global__ void k_transpose(int64_t rows, int64_t cols, const double* __restrict__ in, int64_t ldi,
+                            double* __restrict__ out, int64_t ldo) {
+  __shared__ double t[32][33];
+  const int64_t r0 = int64_t(blockIdx.y) * 32, c0 = int64_t(blockIdx.x) * 32;
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int64_t r = r0 + i, cc = c0 + threadIdx.x;
+    if (r < rows && cc < cols) t[i][threadIdx.x] = in[r * ldi + cc];
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int64_t orow = c0 + i, ocol = r0 + threadIdx.x;   // out is cols x rows
+    if (orow < cols && ocol < rows) out[orow * ldo + ocol] = t[threadIdx.x][i];
+  }
+}
+
+void transpose(ccz_ctx* c, int64_t rows, int64_t cols, const double* in, int64_t ldi, double* out, int64_t ldo) {
+  if (rows <= 0 || cols <= 0) return;
+  const int64_t by = (rows + 31) / 32;
+  for (int64_t y0 = 0; y0 < by; y0 += 65535) {   // grid.y limit
+    const int64_t ny = std::min<int64_t>(65535, by - y0);
+    dim3 grid((unsigned)((cols + 31) / 32), (unsigned)ny);
+    hipLaunchKernelGGL(k_transpose, grid, dim3(32, 8), 0, stream(c), rows - y0 * 32, cols, in + y0 * 32 * ldi, ldi,
+                       out + y0 * 32, ldo);
+  }
+  CCZ_LAUNCH_CHECK();
+}
+
+#define CCZ_GRID2D(rows, cols) \
+  dim3 grid((unsigned)std::min<int64_t>(((rows) * (cols) + 255) / 256, 1 << 20)); \
+  const int64_t total = (rows) * (cols)
+
+__global__ void k_copy2d(int64_t total, int64_t cols, const double* __restrict__ in, int64_t ldi,
+                         double* __restrict__ out, int64_t ldo) {
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += int64_t(gridDim.x) * blockDim.x) {
+    const int64_t r = i / cols, cc = i - r * cols;
+    out[r * ldo + cc] = in[r * ldi + cc];
+  }
+}
+void copy2d(ccz_ctx* c, int64_t rows, int64_t cols, const double* in, int64_t ldi, double* out, int64_t ldo) {
+  if (rows <= 0 || cols <= 0 || (in == out && ldi == ldo)) return;
+  if (in == out) fail(CCZ_EINVAL, "copy2d: in-place with different strides");
+  CCZ_GRID2D(rows, cols);
+  hipLaunchKernelGGL(k_copy2d, grid, dim3(256), 0, stream(c), total, cols, in, ldi, out, ldo);
+  CCZ_LAUNCH_CHECK();
+}
+
+__global__ void k_axpby2d(int64_t total, int64_t cols, double alpha, double* __restrict__ A, int64_t lda, double beta,
+                          const double* __restrict__ B, int64_t ldb) {
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += int64_t(gridDim.x) * blockDim.x) {
+    const int64_t r = i / cols, cc = i - r * cols;
+    double v = alpha * A[r * lda + cc];
+    if (B) v += beta * B[r * ldb + cc];
+    A[r * lda + cc] = v;
+  }
+}
+void axpby2d(ccz_ctx* c, int64_t rows, int64_t cols, double alpha, double* A, int64_t lda, double beta, const double* B,
+             int64_t ldb) {
+  if (rows <= 0 || cols <= 0) return;
+  if (beta == 0.0) B = nullptr;
+  CCZ_GRID2D(rows, cols);
+  hipLaunchKernelGGL(k_axpby2d, grid, dim3(256), 0, stream(c), total, cols, alpha, A, lda, beta, B, ldb);
+  CCZ_LAUNCH_CHECK();
+}
+
+__global__ void k_fill2d(int64_t total, int64_t cols, double* __restrict__ A, int64_t lda, double v) {
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += int64_t(gridDim.x) * blockDim.x) {
+    const int64_t r = i / cols, cc = i - r * cols;
+    A[r * lda + cc] = v;
+  }
+}
+void fill2d(ccz_ctx* c, int64_t rows, int64_t cols, double* A, int64_t lda, double v) {
+  if (rows <= 0 || cols <= 0) return;
+  CCZ_GRID2D(rows, cols);
+  hipLaunchKernelGGL(k_fill2d, grid, dim3(256), 0, stream(c), total, cols, A, lda, v);
+  CCZ_LAUNCH_CHECK();
+}
+
+__global__ void k_add_diag(int64_t d, double* __restrict__ A, int64_t lda, double v) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < d) A[i * lda + i] += v;
+}
+void add_diag(ccz_ctx* c, int64_t d, double* A, int64_t lda, double v) {
+  if (d <= 0) return;
+  hipLaunchKernelGGL(k_add_diag, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, stream(c), d, A, lda, v);
+  CCZ_LAUNCH_CHECK();
+}
+
+__global__ void k_scale_cols(int64_t total, int64_t cols, double* __restrict__ A, int64_t lda,
+                             const double* __restrict__ v, int mode) {
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += int64_t(gridDim.x) * blockDim.x) {
+    const int64_t r = i / cols, cc = i - r * cols;
+    const double f = mode == 0 ? v[cc] : (mode == 1 ? 1.0 / v[cc] : 1.0 / sqrt(v[cc]));
+    A[r * lda + cc] *= f;
+  }
+}
+void scale_cols(ccz_ctx* c, int64_t rows, int64_t cols, double* A, int64_t lda, const double* v, int mode) {
+  if (rows <= 0 || cols <= 0) return;
+  CCZ_GRID2D(rows, cols);
+  hipLaunchKernelGGL(k_scale_cols, grid, dim3(256), 0, stream(c), total, cols, A, lda, v, mode);
+  CCZ_LAUNCH_CHECK();
+}
+
+__global__ void k_mirror_upper(int64_t d, double* __restrict__ A, int64_t lda) {
+  const int64_t total = d * d;
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += int64_t(gridDim.x) * blockDim.x) {
+    const int64_t r = i / d, cc = i - r * d;
+    if (r > cc) A[r * lda + cc] = A[cc * lda + r];
+  }
+}
+void mirror_upper(ccz_ctx* c, int64_t d, double* A, int64_t lda) {
+  if (d <= 0) return;
+  CCZ_GRID2D(d, d);
+  (void)total;
+  hipLaunchKernelGGL(k_mirror_upper, grid, dim3(256), 0, stream(c), d, A, lda);
+  CCZ_LAUNCH_CHECK();
+}
+
+__global__ void k_cov_block(int64_t total, int64_t cols, const double* __restrict__ G, int64_t D,
+                            const double* __restrict__ s, double inv_n, int centre, double alpha, int64_t r0,
+                            int64_t c0, double* __restrict__ out, int64_t ldo) {
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += int64_t(gridDim.x) * blockDim.x) {
+    const int64_t r = i / cols, cc = i - r * cols;
+    double v = G[(r0 + r) * D + (c0 + cc)];
+    if (centre) v -= s[r0 + r] * s[c0 + cc] * inv_n;
+    out[r * ldo + cc] = alpha * v;
+  }
+}
+void cov_block(ccz_ctx* c, const double* G, int64_t D, const double* s, int64_t n, bool centre, double alpha,
+               int64_t r0, int64_t rows, int64_t c0, int64_t cols, double* out, int64_t ldo) {
+  if (rows <= 0 || cols <= 0) return;
+  CCZ_GRID2D(rows, cols);
+  hipLaunchKernelGGL(k_cov_block, grid, dim3(256), 0, stream(c), total, cols, G, D, s, 1.0 / double(n), centre ? 1 : 0,
+                     alpha, r0, c0, out, ldo);
+  CCZ_LAUNCH_CHECK();
+}
+
+__global__ void k_randn(int64_t total, int64_t cols, double* __restrict__ A, int64_t lda, uint64_t seed) {
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += int64_t(gridDim.x) * blockDim.x) {
+    const int64_t r = i / cols, cc = i - r * cols;
+    A[r * lda + cc] = hash_normal(seed, uint64_t(i));
+  }
+}
+void randn_fill(ccz_ctx* c, int64_t rows, int64_t cols, double* A, int64_t lda, uint64_t seed) {
+  if (rows <= 0 || cols <= 0) return;
+  CCZ_GRID2D(rows, cols);
+  hipLaunchKernelGGL(k_randn, grid, dim3(256), 0, stream(c), total, cols, A, lda, seed);
+  CCZ_LAUNCH_CHECK();
+}
+
+// ===========================================================================
+// reductions
+// ===========================================================================
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// block-wide sum; result valid in every thread.  red: >= (blockDim/64) doubles of LDS
+__device__ __forceinline__ double block_sum(double v, double* red) {
+  v = wave_sum(v);
+  const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[wave] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
+
+__global__ void k_col_sqnorms(int64_t rows, int64_t cols, const double* __restrict__ A, int64_t lda,
+                              double* __restrict__ out, int64_t rows_per_block) {
+  const int64_t r0 = int64_t(blockIdx.x) * rows_per_block;
+  const int64_t r1 = min(rows, r0 + rows_per_block);
+  for (int64_t j = threadIdx.x; j < cols; j += blockDim.x) {
+    double acc = 0.0;
+    for (int64_t r = r0; r < r1; ++r) { const double v = A[r * lda + j]; acc += v * v; }
+    unsafeAtomicAdd(&out[j], acc);
+  }
+}
+void col_sqnorms(ccz_ctx* c, int64_t rows, int64_t cols, const double* A, int64_t lda, double* out) {
+  if (cols <= 0) return;
+  zero(c, out, size_t(cols) * 8);
+  if (rows <= 0) return;
+  const int64_t rpb = 64;
+  hipLaunchKernelGGL(k_col_sqnorms, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, stream(c), rows, cols, A,
+                     lda, out, rpb);
+  CCZ_LAUNCH_CHECK();
+}
+
+__global__ void k_row_abs_sums(int64_t cols, const double* __restrict__ A, int64_t lda, double* __restrict__ out) {
+  __shared__ double red[8];
+  const double* a = A + int64_t(blockIdx.x) * lda;
+  double acc = 0.0;
+  for (int64_t j = threadIdx.x; j < cols; j += blockDim.x) acc += fabs(a[j]);
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) out[blockIdx.x] = acc;
+}
+double norm_inf(ccz_ctx* c, int64_t rows, int64_t cols, const double* A, int64_t lda) {
+  if (rows <= 0 || cols <= 0) return 0.0;
+  DBuf tmp(c, rows);
+  hipLaunchKernelGGL(k_row_abs_sums, dim3((unsigned)rows), dim3(256), 0, stream(c), cols, A, lda, tmp.get());
+  CCZ_LAUNCH_CHECK();
+  std::vector<double> h(rows);
+  d2h(c, h.data(), tmp, size_t(rows) * 8);
+  double best = 0.0;
+  for (double v : h)
+    if (!(v <= best)) best = v;  // NaN propagates
+  return best;
+}
+
+__global__ void k_row_dots(int64_t cols, const double* __restrict__ A, int64_t lda, const double* __restrict__ B,
+                           int64_t ldb, double* __restrict__ out) {
+  __shared__ double red[8];
+  const double* a = A + int64_t(blockIdx.x) * lda;
+  const double* b = B + int64_t(blockIdx.x) * ldb;
+  double acc = 0.0;
+  for (int64_t j = threadIdx.x; j < cols; j += blockDim.x) acc += a[j] * b[j];
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) out[blockIdx.x] = acc;
+}
+void row_dots(ccz_ctx* c, int64_t rows, int64_t cols, const double* A, int64_t lda, const double* B, int64_t ldb,
+              double* out) {
+  if (rows <= 0) return;
+  hipLaunchKernelGGL(k_row_dots, dim3((unsigned)rows), dim3(256), 0, stream(c), cols, A, lda, B, ldb, out);
+  CCZ_LAUNCH_CHECK();
+}
+
+__global__ void k_gather_rows(int64_t total, int64_t cols, const double* __restrict__ in, int64_t ldi,
+                              const int64_t* __restrict__ perm, const double* __restrict__ scale,
+                              double* __restrict__ out, int64_t ldo) {
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += int64_t(gridDim.x) * blockDim.x) {
+    const int64_t r = i / cols, cc = i - r * cols;
+    out[r * ldo + cc] = in[perm[r] * ldi + cc] * (scale ? scale[r] : 1.0);
+  }
+}
+void gather_rows(ccz_ctx* c, int64_t rows, int64_t cols, const double* in, int64_t ldi, const int64_t* perm_host,
+                 const double* scale_host, double* out, int64_t ldo) {
+  if (rows <= 0 || cols <= 0) return;
+  DBuf pd(c, rows), sd(c, scale_host ? rows : 0);
+  h2d(c, pd.get(), perm_host, size_t(rows) * 8);
+  if (scale_host) h2d(c, sd.get(), scale_host, size_t(rows) * 8);
+  CCZ_GRID2D(rows, cols);
+  hipLaunchKernelGGL(k_gather_rows, grid, dim3(256), 0, stream(c), total, cols, in, ldi,
+                     reinterpret_cast<const int64_t*>(pd.get()), scale_host ? sd.get() : nullptr, out, ldo);
+  CCZ_LAUNCH_CHECK();
+}
+
+// ===========================================================================
+// Cholesky (lower, blocked, right-looking) and right triangular solves
+// ===========================================================================
+constexpr int NB = 64;
+
+// factor the nb x nb diagonal block in LDS; info: first failing global pivot index + 1 (atomicMin-like)
+__global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ A, int64_t lda, int nb, int64_t j0,
+                                                    int* __restrict__ info) {
+  __shared__ double t[NB][NB + 1];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < nb * nb; i += 256) { const int r = i / nb, cc = i - r * nb; t[r][cc] = A[r * lda + cc]; }
+  __syncthreads();
+  for (int j = 0; j < nb; ++j) {
+    if (tid == 0) {
+      double d = t[j][j];
+      if (!(d > 0.0)) { atomicMin(info, int(j0 + j + 1)); d = 1.0; }
+      t[j][j] = sqrt(d);
+    }
+    __syncthreads();
+    const double piv = t[j][j];
+    for (int i = j + 1 + tid; i < nb; i += 256) t[i][j] /= piv;
+    __syncthreads();
+    const int rem = nb - j - 1;
+    for (int idx = tid; idx < rem * rem; idx += 256) {
+      const int i = j + 1 + idx / rem, k = j + 1 + idx % rem;
+      if (k <= i) t[i][k] -= t[i][j] * t[k][j];
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < nb * nb; i += 256) { const int r = i / nb, cc = i - r * nb; if (cc <= r) A[r * lda + cc] = t[r][cc]; }
+}
+
+// one thread per row of X: x <- x L^-T (trans) or x L^-1 (!trans) for the nb x nb lower block L
+template <bool TRANS>
+__global__ __launch_bounds__(256) void k_trsm_diag_rows(int64_t r, int nb, const double* __restrict__ L, int64_t ldl,
+                                                        double* __restrict__ X, int64_t ldx) {
+  __shared__ double Ls[NB][NB + 1];
+  for (int i = threadIdx.x; i < NB * NB; i += 256) {
+    const int a = i / NB, b = i - a * NB;
+    double v = (a == b) ? 1.0 : 0.0;
+    if (a < nb && b < nb && b <= a) v = L[a * ldl + b];
+    Ls[a][b] = v;
+  }
+  __syncthreads();
+  const int64_t row = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (row >= r) return;
+  double* xr = X + row * ldx;
+  double x[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) x[i] = (i < nb) ? xr[i] : 0.0;
+  if (TRANS) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      double v = x[i];
+#pragma unroll
+      for (int t = 0; t < i; ++t) v -= Ls[i][t] * x[t];
+      x[i] = v / Ls[i][i];
+    }
+  } else {
+#pragma unroll
+    for (int i = NB - 1; i >= 0; --i) {
+      double v = x[i];
+#pragma unroll
+      for (int t = i + 1; t < NB; ++t) v -= x[t] * Ls[t][i];
+      x[i] = v / Ls[i][i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+    if (i < nb) xr[i] = x[i];
+}
+
+static void trsm_diag_rows(ccz_ctx* c, bool trans, int64_t r, int nb, const double* L, int64_t ldl, double* X,
+                           int64_t ldx) {
+  dim3 grid((unsigned)((r + 255) / 256));
+  if (trans) hipLaunchKernelGGL(k_trsm_diag_rows<true>, grid, dim3(256), 0, stream(c), r, nb, L, ldl, X, ldx);
+  else hipLaunchKernelGGL(k_trsm_diag_rows<false>, grid, dim3(256), 0, stream(c), r, nb, L, ldl, X, ldx);
+  CCZ_LAUNCH_CHECK();
+}
+
+int potrf_lower(ccz_ctx* c, double* A, int64_t d, int64_t lda) {
+  Impl* im = impl(c);
+  const int big = 0x7fffffff;
+  CCZ_HIP(hipMemcpyAsync(im->d_flag, &big, sizeof(int), hipMemcpyHostToDevice, stream(c)));
+  CCZ_HIP(hipStreamSynchronize(stream(c)));
+  for (int64_t j = 0; j < d; j += NB) {
+    const int nb = int(std::min<int64_t>(NB, d - j));
+    double* Ajj = A + j * lda + j;
+    hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, stream(c), Ajj, lda, nb, j, im->d_flag);
+    CCZ_LAUNCH_CHECK();
+    const int64_t rem = d - j - nb;
+    if (rem > 0) {
+      double* A21 = A + (j + nb) * lda + j;
+      trsm_diag_rows(c, true, rem, nb, Ajj, lda, A21, lda);                       // L21 = A21 L11^-T
+      gemm(c, false, true, rem, rem, nb, -1.0, A21, lda, A21, lda, 1.0, A + (j + nb) * lda + (j + nb), lda);
+    }
+  }
+  int info = 0;
+  d2h(c, &info, im->d_flag, sizeof(int));
+  return info == big ? 0 : info;
+}
+
+void trsm_right_lower(ccz_ctx* c, bool trans, int64_t r, int64_t d, const double* L, int64_t ldl, double* X,
+                      int64_t ldx) {
+  if (r <= 0 || d <= 0) return;
+  if (trans) {
+    // X L' = B, forward over column blocks:  X_j = (B_j - sum_{t<j} X_t L_jt') L_jj^-T
+    for (int64_t j = 0; j < d; j += NB) {
+      const int nb = int(std::min<int64_t>(NB, d - j));
+      trsm_diag_rows(c, true, r, nb, L + j * ldl + j, ldl, X + j, ldx);
+      const int64_t rem = d - j - nb;
+      if (rem > 0)  // X[:, j+nb:] -= X_j  L[j+nb:, j]'
+        gemm(c, false, true, r, rem, nb, -1.0, X + j, ldx, L + (j + nb) * ldl + j, ldl, 1.0, X + j + nb, ldx);
+    }
+  } else {
+    // X L = B, backward:  X_j = (B_j - sum_{t>j} X_t L_tj) L_jj^-1
+    const int64_t nblk = (d + NB - 1) / NB;
+    for (int64_t bj = nblk - 1; bj >= 0; --bj) {
+      const int64_t j = bj * NB;
+      const int nb = int(std::min<int64_t>(NB, d - j));
+      trsm_diag_rows(c, false, r, nb, L + j * ldl + j, ldl, X + j, ldx);
+      if (j > 0)  // X[:, :j] -= X_j L[j:j+nb, :j]
+        gemm(c, false, false, r, j, nb, -1.0, X + j, ldx, L + j * ldl, ldl, 1.0, X, ldx);
+    }
+  }
+}
+
+// ===========================================================================
+// one-sided Jacobi on rows: one workgroup per row pair, one launch per tournament round
+// ===========================================================================
+template <int BS>
+__global__ __launch_bounds__(BS) void k_jacobi_round(int64_t p, int64_t pe, int64_t q, double* __restrict__ W,
+                                                     int64_t ldw, double* __restrict__ Q, int64_t qc, int64_t ldq,
+                                                     int64_t round, double tol, int* __restrict__ counter) {
+  __shared__ double red[3][BS / 64 > 0 ? BS / 64 : 1];
+  const int64_t k = blockIdx.x, m1 = pe - 1;
+  int64_t a, b;
+  if (k == 0) { a = m1; b = round; } else { a = (round + k) % m1; b = (round - k + m1) % m1; }
+  if (a >= p || b >= p) return;
+  double* wa = W + a * ldw;
+  double* wb = W + b * ldw;
+  double al = 0.0, be = 0.0, ga = 0.0;
+  for (int64_t t = threadIdx.x; t < q; t += BS) {
+    const double x = wa[t], y = wb[t];
+    al += x * x; be += y * y; ga += x * y;
+  }
+  al = wave_sum(al); be = wave_sum(be); ga = wave_sum(ga);
+  if (BS > 64) {
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][wave] = al; red[1][wave] = be; red[2][wave] = ga; }
+    __syncthreads();
+    al = be = ga = 0.0;
+    for (int i = 0; i < BS / 64; ++i) { al += red[0][i]; be += red[1][i]; ga += red[2][i]; }
+  }
+  const double prod = al * be;
+  if (!(prod > 0.0) || !(fabs(ga) > tol * sqrt(prod))) return;
+  if (threadIdx.x == 0) atomicAdd(counter, 1);
+  const double zeta = (be - al) / (2.0 * ga);
+  const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+  const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
+  for (int64_t t = threadIdx.x; t < q; t += BS) {
+    const double x = wa[t], y = wb[t];
+    wa[t] = cs * x - sn * y;
+    wb[t] = sn * x + cs * y;
+  }
+  if (Q) {
+    double* qa = Q + a * ldq;
+    double* qb = Q + b * ldq;
+    for (int64_t t = threadIdx.x; t < qc; t += BS) {
+      const double x = qa[t], y = qb[t];
+      qa[t] = cs * x - sn * y;
+      qb[t] = sn * x + cs * y;
+    }
+  }
+}
+
+int jacobi_rows(ccz_ctx* c, int64_t p, int64_t q, double* W, int64_t ldw, double* Q, int64_t qc, int64_t ldq,
+                int max_sweeps) {
+  if (p < 2) return 1;
+  Impl* im = impl(c);
+  const int64_t pe = (p + 1) & ~int64_t(1);
+  const double tol = 2.220446049250313e-16 * std::sqrt(double(q)) * 4.0;
+  const bool small = std::max(q, Q ? qc : 0) <= 256;
+  dim3 grid((unsigned)(pe / 2));
+  for (int sweep = 1; sweep <= max_sweeps; ++sweep) {
+    CCZ_HIP(hipMemsetAsync(im->d_flag + 1, 0, sizeof(int), stream(c)));
+    for (int64_t round = 0; round < pe - 1; ++round) {
+      if (small) hipLaunchKernelGGL(k_jacobi_round<64>, grid, dim3(64), 0, stream(c), p, pe, q, W, ldw, Q, qc, ldq, round, tol, im->d_flag + 1);
+      else hipLaunchKernelGGL(k_jacobi_round<256>, grid, dim3(256), 0, stream(c), p, pe, q, W, ldw, Q, qc, ldq, round, tol, im->d_flag + 1);
+    }
+    CCZ_LAUNCH_CHECK();
+    int rot = 0;
+    d2h(c, &rot, im->d_flag + 1, sizeof(int));
+    if (rot == 0) return sweep;
+  }
+  fail(CCZ_ENOCONV, "Jacobi did not converge in %d sweeps (p=%lld, q=%lld)", max_sweeps, (long long)p, (long long)q);
+}
+
+}  // namespace ccz

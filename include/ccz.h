@@ -27,6 +27,12 @@ extern "C" {
 
 #define CCZ_VERSION 100 /* 0.1.0 */
 
+#if defined(__GNUC__)
+#define CCZ_API __attribute__((visibility("default")))
+#else
+#define CCZ_API
+#endif
+
 #define CCZ_OK 0
 #define CCZ_EINVAL (-1)   /* bad argument                                   -> ValueError   */
 #define CCZ_ENOMEM (-2)   /* device allocation failed                       -> MemoryError  */
@@ -57,21 +63,21 @@ typedef struct ccz_devinfo {
 } ccz_devinfo;
 
 /* ---- lifecycle ---------------------------------------------------------- */
-int ccz_version(void);
-int ccz_create(ccz_handle* out, int device);
-int ccz_destroy(ccz_handle h);
-const char* ccz_last_error(ccz_handle h);
+CCZ_API int ccz_version(void);
+CCZ_API int ccz_create(ccz_handle* out, int device);
+CCZ_API int ccz_destroy(ccz_handle h);
+CCZ_API const char* ccz_last_error(ccz_handle h);
 /* stream = hipStream_t as void* (torch: torch.cuda.current_stream().cuda_stream); NULL = default */
-int ccz_set_stream(ccz_handle h, void* stream);
-int ccz_sync(ccz_handle h);
-int ccz_device_info(ccz_handle h, ccz_devinfo* out);
+CCZ_API int ccz_set_stream(ccz_handle h, void* stream);
+CCZ_API int ccz_sync(ccz_handle h);
+CCZ_API int ccz_device_info(ccz_handle h, ccz_devinfo* out);
 
 /* ---- raw device memory for callers that do not bring torch tensors ------- */
-int ccz_dev_alloc(ccz_handle h, void** out, size_t bytes);
-int ccz_dev_free(ccz_handle h, void* p);
-int ccz_memcpy_h2d(ccz_handle h, void* dst_dev, const void* src_host, size_t bytes);
-int ccz_memcpy_d2h(ccz_handle h, void* dst_host, const void* src_dev, size_t bytes);
-int ccz_memset0(ccz_handle h, void* dst_dev, size_t bytes);
+CCZ_API int ccz_dev_alloc(ccz_handle h, void** out, size_t bytes);
+CCZ_API int ccz_dev_free(ccz_handle h, void* p);
+CCZ_API int ccz_memcpy_h2d(ccz_handle h, void* dst_dev, const void* src_host, size_t bytes);
+CCZ_API int ccz_memcpy_d2h(ccz_handle h, void* dst_host, const void* src_dev, size_t bytes);
+CCZ_API int ccz_memset0(ccz_handle h, void* dst_dev, size_t bytes);
 
 /* ---- K1: second moments ---------------------------------------------------
  * moments = [ G (D x D, ld = D) | colsum (D) ]  float64, D = sum cols, device.
@@ -86,12 +92,12 @@ int ccz_memset0(ccz_handle h, void* dst_dev, size_t bytes);
  *   linear/_rcca.py:96; np.cov linear/_mcca.py:151-152,166, linear/_gcca.py:101;
  *   v.mean(axis=0) / v - m  _base.py:97-99.
  */
-int ccz_moments(ccz_handle h, int dtype, const ccz_view* views, int n_views, int64_t n_rows,
+CCZ_API int ccz_moments(ccz_handle h, int dtype, const ccz_view* views, int n_views, int64_t n_rows,
                 int views_on_device, double* moments_dev, int accumulate);
-int ccz_moments_symmetrize(ccz_handle h, double* moments_dev, int64_t D);
+CCZ_API int ccz_moments_symmetrize(ccz_handle h, double* moments_dev, int64_t D);
 /* kernel timing of the last ccz_moments call on this handle (HIP events on the
  * handle's stream): milliseconds of the Gram kernel(s) and of the column-sum pass */
-int ccz_moments_last_ms(ccz_handle h, double* gram_ms, double* colsum_ms);
+CCZ_API int ccz_moments_last_ms(ccz_handle h, double* gram_ms, double* colsum_ms);
 
 /* ---- fused solves on reduced moments (replicated after the all-reduce) ----
  * Inputs: symmetrized moments (device), total rows n, per-view widths.
@@ -99,15 +105,15 @@ int ccz_moments_last_ms(ccz_handle h, double* gram_ms, double* colsum_ms);
  * (d_i x k_out); means (D) ; vals (k_out).
  */
 /* linear/_rcca.py:69-101 (rCCA.fit; CCA c=0 linear/_cca.py:52; PLS c=1 linear/_pls.py:53) */
-int ccz_rcca_solve(ccz_handle h, const double* moments_dev, int64_t n, const int64_t dims[2],
+CCZ_API int ccz_rcca_solve(ccz_handle h, const double* moments_dev, int64_t n, const int64_t dims[2],
                    const double c[2], int center, int k, double* weights_host,
                    double* means_host, double* vals_host, int* k_out);
 /* linear/_mcca.py:99-197 (MCCA.fit, _build_A, _build_B, _build_B_pca, gevp) */
-int ccz_mcca_solve(ccz_handle h, const double* moments_dev, int64_t n, const int64_t* dims,
+CCZ_API int ccz_mcca_solve(ccz_handle h, const double* moments_dev, int64_t n, const int64_t* dims,
                    int n_views, const double* c, double eps, int center, int k,
                    double* weights_host, double* means_host, double* vals_host, int* k_out);
 /* linear/_gcca.py:80-110 (GCCA.fit) restated in D x D Gram form */
-int ccz_gcca_solve(ccz_handle h, const double* moments_dev, int64_t n, const int64_t* dims,
+CCZ_API int ccz_gcca_solve(ccz_handle h, const double* moments_dev, int64_t n, const int64_t* dims,
                    int n_views, const double* c, const double* view_weights, double eps,
                    int center, int k, double* weights_host, double* means_host,
                    double* vals_host, int* k_out);
@@ -116,34 +122,34 @@ int ccz_gcca_solve(ccz_handle h, const double* moments_dev, int64_t n, const int
 /* full symmetric EVD by one-sided Jacobi: A (d x d, overwritten) -> w (d, descending),
  * V (d x d, row i = eigenvector i).  torch.linalg.eigh deep/objectives.py:19;
  * np.linalg.eigvalsh linear/_mcca.py:170,194, linear/_gcca.py:102 */
-int ccz_syevj(ccz_handle h, double* A_dev, int64_t d, double* w_dev, double* V_dev,
+CCZ_API int ccz_syevj(ccz_handle h, double* A_dev, int64_t d, double* w_dev, double* V_dev,
               int* sweeps_out);
 /* full SVD by one-sided Jacobi: A (p x q) = U diag(s) Vt, r = min(p,q); U (p x r),
  * s (r, descending), Vt (r x q).  np.linalg.svd linear/_rcca.py:97 */
-int ccz_gesvj(ccz_handle h, const double* A_dev, int64_t p, int64_t q, double* U_dev,
+CCZ_API int ccz_gesvj(ccz_handle h, const double* A_dev, int64_t p, int64_t q, double* U_dev,
               double* s_dev, double* Vt_dev, int* sweeps_out);
 /* top-k symmetric (generalised) eigenpairs, descending; B_dev may be NULL.
  * V (p x k), B-normalised (v'Bv = 1).  gevp _utils/_linalg.py:44-73 */
-int ccz_gevp_topk(ccz_handle h, const double* A_dev, const double* B_dev, int64_t p, int k,
+CCZ_API int ccz_gevp_topk(ccz_handle h, const double* A_dev, const double* B_dev, int64_t p, int k,
                   double* w_dev, double* V_dev);
 /* top-k singular triplets of T (p x q): U (p x k), s (k), V (q x k) */
-int ccz_svd_topk(ccz_handle h, const double* T_dev, int64_t p, int64_t q, int k,
+CCZ_API int ccz_svd_topk(ccz_handle h, const double* T_dev, int64_t p, int64_t q, int k,
                  double* U_dev, double* s_dev, double* V_dev);
 /* whitening matrix from the Gram of a centred view: lam (r) descending eigenvalues of
  * Gxx/(n-1), W (d x r) = V ((1-ridge) lam + ridge)^-1/2, r = min(n, d).
  * svd_whiten _utils/_linalg.py:9-41 */
-int ccz_whitener(ccz_handle h, const double* Gxx_dev, int64_t d, int64_t n, double ridge,
+CCZ_API int ccz_whitener(ccz_handle h, const double* Gxx_dev, int64_t d, int64_t n, double ridge,
                  double* W_dev, double* lam_dev, int64_t* r_out);
 /* A^-1/2 with eigenvalues clamped at eps.  _inv_sqrtm deep/objectives.py:9-21 */
-int ccz_inv_sqrtm(ccz_handle h, const double* A_dev, int64_t d, double eps, double* out_dev);
+CCZ_API int ccz_inv_sqrtm(ccz_handle h, const double* A_dev, int64_t d, double eps, double* out_dev);
 
 /* building blocks (exported for tests and for the seams above) */
-int ccz_potrf_lower(ccz_handle h, double* A_dev, int64_t d, int64_t lda);
+CCZ_API int ccz_potrf_lower(ccz_handle h, double* A_dev, int64_t d, int64_t lda);
 /* X (r x d) <- X L^-T (trans=1) or X L^-1 (trans=0), L lower (d x d) */
-int ccz_trsm_right_lower(ccz_handle h, int trans, int64_t r, int64_t d, const double* L_dev,
+CCZ_API int ccz_trsm_right_lower(ccz_handle h, int trans, int64_t r, int64_t d, const double* L_dev,
                          int64_t ldl, double* X_dev, int64_t ldx);
 /* C (M x N) = alpha op(A) op(B) + beta C; op = transpose when the flag is 1 */
-int ccz_gemm_f64(ccz_handle h, int transA, int transB, int64_t M, int64_t N, int64_t K,
+CCZ_API int ccz_gemm_f64(ccz_handle h, int transA, int transB, int64_t M, int64_t N, int64_t K,
                  double alpha, const double* A_dev, int64_t lda, const double* B_dev, int64_t ldb,
                  double beta, double* C_dev, int64_t ldc);
 
@@ -153,14 +159,14 @@ int ccz_gemm_f64(ccz_handle h, int transA, int transB, int64_t M, int64_t N, int
  * Any of g1/g2 may be NULL (forward only).  loss_dev: one element of `dtype`.
  * deep/objectives.py:61-102 (CCALoss.forward) + its autograd backward.
  */
-int ccz_cca_loss(ccz_handle h, int dtype, const void* z1_dev, const void* z2_dev, int64_t n,
+CCZ_API int ccz_cca_loss(ccz_handle h, int dtype, const void* z1_dev, const void* z2_dev, int64_t n,
                  int64_t d1, int64_t d2, int64_t ld1, int64_t ld2, double eps, void* loss_dev,
                  void* g1_dev, void* g2_dev, int64_t ldg1, int64_t ldg2);
 
 /* ---- transform / score -------------------------------
  * out (n x k, dtype) = (X - mean) W ; X,out device; mean (d), W (d x k) device float64.
  * _base.py:108-123 */
-int ccz_transform(ccz_handle h, int dtype, const void* X_dev, int64_t n, int64_t d, int64_t ld,
+CCZ_API int ccz_transform(ccz_handle h, int dtype, const void* X_dev, int64_t n, int64_t d, int64_t ld,
                   const double* mean_dev, const double* W_dev, int64_t k, void* out_dev,
                   int64_t ldo);
 

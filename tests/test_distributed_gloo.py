@@ -1,0 +1,100 @@
+"""world_size-2 gloo test of the sharded path's host logic (no GPU).
+
+Each rank owns a row shard, forms its partial moments (here with NumPy as the checker
+-- on the GPU the same buffer comes out of K1), runs the ONE collective of the path
+(``allreduce_moments``) and then the product solver drivers (host test double) on the
+reduced moments.  Every rank must reproduce the single-process result.
+"""
+
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cca_zoo_amd import _dist
+        from hostsim_util import hostsim_handle
+        from oracle import gram_form as gf
+        from oracle import reference_form as rf
+
+        views = rf.joint_data(2, 301, 3, [12, 9], 2.0, 5)       # same data on every rank
+        lo, hi = _dist.shard_bounds(301, rank, world)
+        G, s, n_loc = gf.moments([v[lo:hi] for v in views])
+        mom = torch.from_numpy(np.concatenate([G.ravel(), s]))
+        with _dist.row_sharded():
+            assert _dist.is_sharded()
+            n_tot = _dist.allreduce_moments(mom, n_loc, _dist.active_group())
+        assert not _dist.is_sharded()
+        H = hostsim_handle()
+        W, means, vals = H.rcca_solve(mom.numpy(), n_tot, [12, 9], [0.1, 0.1], True, 3)
+        q.put((rank, n_tot, [w.copy() for w in W], [m.copy() for m in means]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_bounds_partition():
+    from cca_zoo_amd import shard_bounds
+
+    for n in (0, 1, 7, 100, 1_000_003):
+        for w in (1, 2, 3, 8):
+            edges = [shard_bounds(n, r, w) for r in range(w)]
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            assert all(edges[i][1] == edges[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in edges]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_bounds(10, 2, 2)
+
+
+def test_row_sharded_requires_process_group():
+    from cca_zoo_amd import row_sharded
+
+    with pytest.raises(RuntimeError, match="process group"):
+        with row_sharded():
+            pass
+
+
+def test_two_rank_allreduce_then_solve():
+    from conftest import col_rel_err
+    from oracle import reference_form as rf
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    views = rf.joint_data(2, 301, 3, [12, 9], 2.0, 5)
+    W_ref, means_ref = rf.rcca_weights(views, 3, c=0.1)
+    for rank, n_tot, W, means in results:
+        assert n_tot == 301
+        for w, r in zip(W, W_ref):
+            assert col_rel_err(w, r) < 1e-9
+        for m, r in zip(means, means_ref):
+            np.testing.assert_allclose(m, r, atol=1e-12)

@@ -1,0 +1,129 @@
+"""GPU parity: K1 (fused Gram + column sums) against float64 NumPy, through the C ABI."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def H():
+    from cca_zoo_amd import _backend
+
+    return _backend.default_handle(0)
+
+
+def _moments(H, views, dtype, on_device=False):
+    from cca_zoo_amd import _backend
+
+    n = views[0].shape[0]
+    dims = [v.shape[1] for v in views]
+    D = sum(dims)
+    mom = H.alloc((D * D + D) * 8)
+    keep = []
+    if on_device:
+        descr = []
+        for v in views:
+            b = H.to_device(v)
+            keep.append(b)
+            descr.append((b.ptr, v.shape[1], v.shape[1]))
+    else:
+        descr = [(v, v.shape[1], v.shape[1]) for v in views]
+    H.moments(descr, n, _backend.F32 if dtype == np.float32 else _backend.F64, on_device, mom.ptr)
+    gm, cm = H.moments_last_ms()
+    assert gm >= 0 and cm >= 0
+    upper = H.to_host(mom, (D * D + D,))
+    H.moments_symmetrize(mom.ptr, D)
+    flat = H.to_host(mom, (D * D + D,))
+    return flat[: D * D].reshape(D, D), flat[D * D:], upper[: D * D].reshape(D, D)
+
+
+def _ref(views):
+    X = np.hstack([v.astype(np.float64) for v in views])
+    return X.T @ X, X.sum(axis=0)
+
+
+# asymmetric, non-random structure so that a transposed / permuted tile cannot pass
+def _structured(n, d, dtype, seed):
+    rng = np.random.default_rng(seed)
+    base = rng.standard_normal((n, d))
+    ramp = (1.0 + np.arange(d) / d)[None, :] * (1.0 + (np.arange(n) % 7)[:, None] / 7.0)
+    return (base * ramp + 0.25).astype(dtype)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n,dims", [
+    (200, [50, 50]),                # C1 shape: ragged tiles, slow path
+    (777, [256, 256]),              # fast path (aligned), row tail inside a k-block
+    (4100, [512, 256]),             # several tiles, two row chunks for fp32 (max 4096 rows / chunk)
+    (1000, [40, 30, 20]),           # three ragged views
+    (33, [300, 7]),                 # fewer rows than a k-block multiple, panel straddling
+    (5000, [384]),                  # single view (svd_whiten seam): 256 + 128 / 3 x 128 panels
+])
+def test_moments_host_views(H, dtype, n, dims):
+    views = [_structured(n, d, dtype, 10 * i + d) for i, d in enumerate(dims)]
+    G, s, _ = _moments(H, views, dtype)
+    Gr, sr = _ref(views)
+    scale = np.sqrt(np.outer(np.diag(Gr), np.diag(Gr)))
+    tol = 2e-6 if dtype == np.float32 else 1e-13
+    assert np.max(np.abs(G - Gr) / scale) < tol
+    np.testing.assert_allclose(s, sr, rtol=1e-12, atol=1e-9)
+    assert np.array_equal(G, G.T)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_moments_device_views_and_upper_only(H, dtype):
+    views = [_structured(3000, 512, dtype, 1), _structured(3000, 256, dtype, 2)]
+    G, s, upper = _moments(H, views, dtype, on_device=True)
+    Gr, sr = _ref(views)
+    scale = np.sqrt(np.outer(np.diag(Gr), np.diag(Gr)))
+    assert np.max(np.abs(G - Gr) / scale) < (2e-6 if dtype == np.float32 else 1e-13)
+    # before symmetrisation only upper-triangular TILES are populated
+    tile = 256 if dtype == np.float32 else 128
+    assert np.all(upper[tile:, :tile] == 0.0)
+    assert np.any(upper[:tile, tile:] != 0.0)
+
+
+def test_moments_accumulate_row_shards(H):
+    """Two row shards accumulated into the same buffer == one pass (the multi-GPU identity)."""
+    from cca_zoo_amd import _backend
+
+    v = [_structured(2000, 256, np.float32, 3), _structured(2000, 256, np.float32, 4)]
+    D = 512
+    mom = H.alloc((D * D + D) * 8)
+    H.moments([(np.ascontiguousarray(a[:900]), 256, 256) for a in v], 900, _backend.F32, False, mom.ptr, accumulate=False)
+    H.moments([(np.ascontiguousarray(a[900:]), 256, 256) for a in v], 1100, _backend.F32, False, mom.ptr, accumulate=True)
+    H.moments_symmetrize(mom.ptr, D)
+    flat = H.to_host(mom, (D * D + D,))
+    Gr, sr = _ref(v)
+    scale = np.sqrt(np.outer(np.diag(Gr), np.diag(Gr)))
+    assert np.max(np.abs(flat[: D * D].reshape(D, D) - Gr) / scale) < 2e-6
+    np.testing.assert_allclose(flat[D * D:], sr, rtol=1e-12, atol=1e-9)
+
+
+def test_moments_strided_device_view(H):
+    """ld > cols: a column slice of a wider device matrix."""
+    import ctypes as C
+
+    from cca_zoo_amd import _backend
+
+    big = _structured(1500, 640, np.float64, 5)
+    bd = H.to_device(big)
+    D = 384
+    mom = H.alloc((D * D + D) * 8)
+    H.moments([(bd.ptr + 128 * 8, 256, 640), (bd.ptr + 512 * 8, 128, 640)], 1500, _backend.F64, True, mom.ptr)
+    H.moments_symmetrize(mom.ptr, D)
+    flat = H.to_host(mom, (D * D + D,))
+    Gr, sr = _ref([big[:, 128:384], big[:, 512:640]])
+    np.testing.assert_allclose(flat[: D * D].reshape(D, D), Gr, rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(flat[D * D:], sr, rtol=1e-12, atol=1e-9)
+
+
+def test_moments_errors(H):
+    from cca_zoo_amd import _backend
+
+    mom = H.alloc(1024)
+    with pytest.raises(ValueError, match="dtype"):
+        H.moments([(np.zeros((4, 2), np.float32), 2, 2)], 4, 7, False, mom.ptr)
+    with pytest.raises(ValueError, match="malformed"):
+        H.moments([(np.zeros((4, 2), np.float32), 2, 1)], 4, _backend.F32, False, mom.ptr)
