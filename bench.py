@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Headline benchmark: CCA fit()/sec at n=1e6, 2 views x 4096 features, k=64 (BASELINE.json).
+
+    python bench.py --gpus 1 --steps 5 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one full ``CCA(latent_dimensions=64).fit(views)`` on synthetic latent-variable
+views already resident in HBM (JointData model): K1 Gram + column sums on
+the MFMA pipe, (N > 1) one RCCL all-reduce of the packed moments, replicated device solves,
+weights back on the host.  With N ranks the n rows are split contiguously across the ranks
+(total work fixed -> "scaling": "strong").  Rank 0 prints ONE JSON line.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}   # dense MFMA peaks, MI355X_MICROARCH.md / datasheet
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--d", type=int, default=4096)
+    ap.add_argument("--k", type=int, default=64)
+    ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dcca", action="store_true")
+    ap.add_argument("--cpu-sample-rows", type=int, default=6144)
+    return ap.parse_args()
+
+
+def cpu_baseline(n_full, d, k, sample_rows):
+    """Reference-structured NumPy path (thin SVD of each n x d view, oracle.reference_form) on a
+    bounded row sample of the same workload; its cost is linear in n."""
+    import numpy as np
+
+    from oracle import reference_form as rf
+
+    try:
+        from threadpoolctl import threadpool_info
+
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    views = rf.joint_data(2, sample_rows, k, [d, d], 1.0, 0)
+    views = [v.astype(np.float32) for v in views]
+    t0 = time.perf_counter()
+    rf.rcca_weights(views, k, c=0.0)
+    dt = time.perf_counter() - t0
+    full = dt * (n_full / sample_rows)
+    return {
+        "value": 1.0 / full, "unit": "fit/s", "cores": int(threads), "kind": "port",
+        "sample": (f"oracle.reference_form.rcca_weights (thin SVD per view, as cca_zoo/linear/_rcca.py) on "
+                   f"{sample_rows} of {n_full} rows, 2x{d} fp32, k={k}: {dt:.2f} s measured; value = 1/(t * n/n_sample) "
+                   f"(reference cost is linear in n); host has {os.cpu_count()} logical cores"),
+        "measured_s": dt,
+    }
+
+
+def dcca_extra(steps=20, warmup=3):
+    """BASELINE configs[3]: CCALoss fwd+bwd, batch 8192, 2 x 512, fp32."""
+    import torch
+
+    from cca_zoo_amd.deep.objectives import CCALoss
+
+    torch.manual_seed(0)
+    z1 = torch.randn(8192, 512, device="cuda", requires_grad=True)
+    z2 = (0.5 * z1.detach() + torch.randn(8192, 512, device="cuda")).requires_grad_(True)
+    obj = CCALoss(eps=1e-6)
+    for _ in range(warmup):
+        obj([z1, z2]).backward()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        z1.grad = None
+        z2.grad = None
+        obj([z1, z2]).backward()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"metric": "DCCA CCALoss fwd+bwd/sec (batch 8192, 2x512, fp32)", "value": 1.0 / dt, "ms": dt * 1e3}
+
+
+def main():
+    a = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("launch with torch.distributed.run for --gpus > 1")
+    torch.cuda.set_device(local)
+    os.environ["CCZ_DEVICE"] = str(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    from cca_zoo_amd import _backend, row_sharded, shard_bounds
+    from cca_zoo_amd.datasets import JointData
+    from cca_zoo_amd.linear import CCA
+
+    h = _backend.default_handle(local)
+    info = h.device_info()
+    lo, hi = shard_bounds(a.n, rank, world)
+    n_local = hi - lo
+    tdt = torch.float32 if a.dtype == "f32" else torch.float64
+    jd = JointData(n_views=2, n_samples=a.n, latent_dimensions=a.k, n_features=[a.d, a.d],
+                   signal_to_noise=1.0, random_state=0, latent_scales=list(np.linspace(2.0, 0.5, a.k)))
+    views = jd.sample_device(device=f"cuda:{local}", dtype=tdt, n_samples=n_local, seed=1000 + rank)
+    torch.cuda.synchronize()
+    model = CCA(latent_dimensions=a.k)
+
+    def step():
+        if world > 1:
+            with row_sharded():
+                model.fit(views)
+        else:
+            model.fit(views)
+
+    gram_ms = []
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+        gram_ms.append(h.moments_last_ms()[0])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / a.steps * 1e3
+
+    if rank == 0:
+        D = 2 * a.d
+        flop = float(n_local) * D * (D + 1)                    # algorithmic flops of ONE Gram launch (this rank)
+        g_ms = float(np.mean(gram_ms))
+        achieved = flop / (g_ms * 1e-3) / 1e12
+        peak = PEAK_TFLOPS[a.dtype]
+        out = {
+            "metric": "CCA fit()/sec at n=1e6 d=4096 k=64",
+            "value": 1e3 / ms_per_step, "unit": "fit/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": a.dtype, "data": "synthetic (JointData latent-variable model, generated in HBM)",
+            "config": {"workload": f"CCA(latent_dimensions={a.k}).fit on JointData n={a.n}, 2 views x {a.d}, {a.dtype}; "
+                                   f"rows sharded over {world} GPU(s)", "n": a.n, "d": a.d, "k": a.k,
+                       "device": info["name"], "arch": info["arch"], "compute_units": info["compute_units"]},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": None,
+                         "kernel": "k_gram_f32" if a.dtype == "f32" else "k_gram_f64",
+                         "kernel_ms": g_ms, "flop_per_launch": flop,
+                         "bytes_per_launch": float(n_local) * D * (4 if a.dtype == "f32" else 8),
+                         "gram_share_of_step": g_ms / ms_per_step},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.n, a.d, a.k, a.cpu_sample_rows)
+        if world == 1 and not a.no_dcca:
+            out["extra"] = {"dcca_loss": dcca_extra()}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
