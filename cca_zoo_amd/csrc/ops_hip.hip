@@ -345,18 +345,26 @@ void scale_cols(ccz_ctx* c, int64_t rows, int64_t cols, double* A, int64_t lda, 
   CCZ_LAUNCH_CHECK();
 }
 
+// lower tile (bi > bj) <- transpose of upper tile (bj, bi) through LDS; diagonal tiles in place
 __global__ void k_mirror_upper(int64_t d, double* __restrict__ A, int64_t lda) {
-  const int64_t total = d * d;
-  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += int64_t(gridDim.x) * blockDim.x) {
-    const int64_t r = i / d, cc = i - r * d;
-    if (r > cc) A[r * lda + cc] = A[cc * lda + r];
+  __shared__ double t[32][33];
+  const int64_t bi = blockIdx.y, bj = blockIdx.x;
+  if (bi < bj) return;
+  const int64_t r0 = bj * 32, c0 = bi * 32;   // source tile: rows of block bj, cols of block bi (upper)
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int64_t r = r0 + i, cc = c0 + threadIdx.x;
+    if (r < d && cc < d) t[i][threadIdx.x] = A[r * lda + cc];
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int64_t r = c0 + i, cc = r0 + threadIdx.x;   // destination (lower): A[r][cc] = A[cc][r]
+    if (r < d && cc < d && r > cc) A[r * lda + cc] = t[threadIdx.x][i];
   }
 }
 void mirror_upper(ccz_ctx* c, int64_t d, double* A, int64_t lda) {
   if (d <= 0) return;
-  CCZ_GRID2D(d, d);
-  (void)total;
-  hipLaunchKernelGGL(k_mirror_upper, grid, dim3(256), 0, stream(c), d, A, lda);
+  const unsigned nb = (unsigned)((d + 31) / 32);
+  hipLaunchKernelGGL(k_mirror_upper, dim3(nb, nb), dim3(32, 8), 0, stream(c), d, A, lda);
   CCZ_LAUNCH_CHECK();
 }
 
@@ -496,78 +504,96 @@ void gather_rows(ccz_ctx* c, int64_t rows, int64_t cols, const double* in, int64
 // ===========================================================================
 constexpr int NB = 64;
 
-// factor the nb x nb diagonal block in LDS; info: first failing global pivot index + 1 (atomicMin-like)
-__global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ A, int64_t lda, int nb, int64_t j0,
-                                                    int* __restrict__ info) {
-  __shared__ double t[NB][NB + 1];
-  const int tid = threadIdx.x;
-  for (int i = tid; i < nb * nb; i += 256) { const int r = i / nb, cc = i - r * nb; t[r][cc] = A[r * lda + cc]; }
-  __syncthreads();
-  for (int j = 0; j < nb; ++j) {
-    if (tid == 0) {
-      double d = t[j][j];
-      if (!(d > 0.0)) { atomicMin(info, int(j0 + j + 1)); d = 1.0; }
-      t[j][j] = sqrt(d);
-    }
-    __syncthreads();
-    const double piv = t[j][j];
-    for (int i = j + 1 + tid; i < nb; i += 256) t[i][j] /= piv;
-    __syncthreads();
-    const int rem = nb - j - 1;
-    for (int idx = tid; idx < rem * rem; idx += 256) {
-      const int i = j + 1 + idx / rem, k = j + 1 + idx % rem;
-      if (k <= i) t[i][k] -= t[i][j] * t[k][j];
-    }
-    __syncthreads();
-  }
-  for (int i = tid; i < nb * nb; i += 256) { const int r = i / nb, cc = i - r * nb; if (cc <= r) A[r * lda + cc] = t[r][cc]; }
+// ---------------------------------------------------------------------------
+// 64 x 64 diagonal block on ONE wavefront: lane i owns row i in registers, columns are
+// exchanged with v_readlane broadcasts (no LDS, no barriers).  Optionally factors the
+// block (right-looking Cholesky), then forms invT = L^-T (lane c solves L x = e_c),
+// which turns every triangular solve against this block into an MFMA GEMM.
+// Blocks narrower than 64 are padded with the identity.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double lane_bcast(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
 }
 
-// one thread per row of X: x <- x L^-T (trans) or x L^-1 (!trans) for the nb x nb lower block L
-template <bool TRANS>
-__global__ __launch_bounds__(256) void k_trsm_diag_rows(int64_t r, int nb, const double* __restrict__ L, int64_t ldl,
-                                                        double* __restrict__ X, int64_t ldx) {
-  __shared__ double Ls[NB][NB + 1];
-  for (int i = threadIdx.x; i < NB * NB; i += 256) {
-    const int a = i / NB, b = i - a * NB;
-    double v = (a == b) ? 1.0 : 0.0;
-    if (a < nb && b < nb && b <= a) v = L[a * ldl + b];
-    Ls[a][b] = v;
-  }
-  __syncthreads();
-  const int64_t row = int64_t(blockIdx.x) * 256 + threadIdx.x;
-  if (row >= r) return;
-  double* xr = X + row * ldx;
-  double x[NB];
+template <bool DO_CHOL>
+__global__ __launch_bounds__(64) void k_wave_chol_inv(double* __restrict__ A, int64_t lda, int64_t d, int64_t j_first,
+                                                      int* __restrict__ info, double* __restrict__ invT) {
+  const int lane = threadIdx.x;
+  const int64_t j0 = j_first + int64_t(blockIdx.x) * NB;
+  const int nb = int(min(int64_t(NB), d - j0));
+  double* Ajj = A + j0 * lda + j0;
+  double a[NB];
+  if (nb == NB) {
+    // full block: plain row loads (the strictly upper part is loaded but never read)
 #pragma unroll
-  for (int i = 0; i < NB; ++i) x[i] = (i < nb) ? xr[i] : 0.0;
-  if (TRANS) {
+    for (int t = 0; t < NB; ++t) a[t] = Ajj[int64_t(lane) * lda + t];
+  } else {
+    // ragged last block: pad with the identity
+#pragma unroll
+    for (int t = 0; t < NB; ++t) {
+      double v = (t == lane) ? 1.0 : 0.0;
+      if (lane < nb && t < nb) v = Ajj[int64_t(lane) * lda + t];
+      a[t] = v;
+    }
+  }
+  if (DO_CHOL) {
+    int first_bad = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      double piv = lane_bcast(a[j], j);
+      const bool bad = !(piv > 0.0);                 // wave-uniform
+      first_bad = bad ? min(first_bad, j) : first_bad;
+      piv = bad ? 1.0 : piv;
+      const double root = sqrt(piv);
+      const double rinv = 1.0 / root;
+      const double l = a[j] * rinv;                  // lane j: piv / sqrt(piv) = l_jj (no lane select needed)
+      a[j] = l;
+      // (i, k) -= l_ij l_kj ; only k <= i is ever read back.  Broadcasts are consumed in groups of 8
+      // so that the scalar registers holding them are recycled instead of spilled.
+#pragma unroll
+      for (int k = j + 1; k < NB; ++k) {
+        a[k] -= l * lane_bcast(a[j], k);
+        if (((k - j) & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (first_bad != 0x7fffffff && lane == 0) atomicMin(info, int(j0 + first_bad + 1));
+#pragma unroll
+    for (int t = 0; t < NB; ++t)
+      if (lane < nb && t <= lane) Ajj[int64_t(lane) * lda + t] = a[t];
+  }
+  if (invT) {
+    if (DO_CHOL) {
+      // make the factor opaque: otherwise the compiler keeps the ~2000 broadcasts of the factorisation
+      // alive (spilled scalar registers) to reuse them below, which is slower than re-broadcasting
+#pragma unroll
+      for (int t = 0; t < NB; ++t) asm volatile("" : "+v"(a[t]));
+    }
+    double x[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      double v = x[i];
+      double v = (i == lane) ? 1.0 : 0.0;
 #pragma unroll
-      for (int t = 0; t < i; ++t) v -= Ls[i][t] * x[t];
-      x[i] = v / Ls[i][i];
+      for (int t = 0; t < i; ++t) {
+        v -= lane_bcast(a[t], i) * x[t];                                  // L[i][t] lives in lane i, register t
+        if ((t & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+      }
+      x[i] = v / lane_bcast(a[i], i);
+      __builtin_amdgcn_sched_barrier(0);
     }
-  } else {
+    double* out = invT + (int64_t(blockIdx.x) * NB + lane) * NB;          // row `lane` of L^-T: (L^-1)[i][lane]
 #pragma unroll
-    for (int i = NB - 1; i >= 0; --i) {
-      double v = x[i];
-#pragma unroll
-      for (int t = i + 1; t < NB; ++t) v -= x[t] * Ls[t][i];
-      x[i] = v / Ls[i][i];
-    }
+    for (int i = 0; i < NB; ++i) out[i] = x[i];
   }
-#pragma unroll
-  for (int i = 0; i < NB; ++i)
-    if (i < nb) xr[i] = x[i];
 }
 
-static void trsm_diag_rows(ccz_ctx* c, bool trans, int64_t r, int nb, const double* L, int64_t ldl, double* X,
-                           int64_t ldx) {
-  dim3 grid((unsigned)((r + 255) / 256));
-  if (trans) hipLaunchKernelGGL(k_trsm_diag_rows<true>, grid, dim3(256), 0, stream(c), r, nb, L, ldl, X, ldx);
-  else hipLaunchKernelGGL(k_trsm_diag_rows<false>, grid, dim3(256), 0, stream(c), r, nb, L, ldl, X, ldx);
+// invT[b] = L_bb^-T for every diagonal block b of L (one wave each, all blocks in one launch)
+static void diag_inverses(ccz_ctx* c, const double* L, int64_t ldl, int64_t d, double* invT) {
+  const unsigned nblk = (unsigned)((d + NB - 1) / NB);
+  hipLaunchKernelGGL(k_wave_chol_inv<false>, dim3(nblk), dim3(64), 0, stream(c), const_cast<double*>(L), ldl, d,
+                     int64_t(0), static_cast<int*>(nullptr), invT);
   CCZ_LAUNCH_CHECK();
 }
 
@@ -576,16 +602,19 @@ int potrf_lower(ccz_ctx* c, double* A, int64_t d, int64_t lda) {
   const int big = 0x7fffffff;
   CCZ_HIP(hipMemcpyAsync(im->d_flag, &big, sizeof(int), hipMemcpyHostToDevice, stream(c)));
   CCZ_HIP(hipStreamSynchronize(stream(c)));
+  DBuf invT(c, NB * NB);
+  DBuf tmp(c, std::max<int64_t>(d - NB, 1) * NB);
   for (int64_t j = 0; j < d; j += NB) {
     const int nb = int(std::min<int64_t>(NB, d - j));
-    double* Ajj = A + j * lda + j;
-    hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, stream(c), Ajj, lda, nb, j, im->d_flag);
-    CCZ_LAUNCH_CHECK();
     const int64_t rem = d - j - nb;
+    if (rem > 0) hipLaunchKernelGGL(k_wave_chol_inv<true>, dim3(1), dim3(64), 0, stream(c), A, lda, d, j, im->d_flag, invT.get());
+    else hipLaunchKernelGGL(k_wave_chol_inv<true>, dim3(1), dim3(64), 0, stream(c), A, lda, d, j, im->d_flag, static_cast<double*>(nullptr));
+    CCZ_LAUNCH_CHECK();
     if (rem > 0) {
       double* A21 = A + (j + nb) * lda + j;
-      trsm_diag_rows(c, true, rem, nb, Ajj, lda, A21, lda);                       // L21 = A21 L11^-T
-      gemm(c, false, true, rem, rem, nb, -1.0, A21, lda, A21, lda, 1.0, A + (j + nb) * lda + (j + nb), lda);
+      gemm(c, false, false, rem, nb, nb, 1.0, A21, lda, invT, NB, 0.0, tmp, NB);          // L21 = A21 L11^-T
+      copy2d(c, rem, nb, tmp, NB, A21, lda);
+      gemm(c, false, true, rem, rem, nb, -1.0, tmp, NB, tmp, NB, 1.0, A + (j + nb) * lda + (j + nb), lda);
     }
   }
   int info = 0;
@@ -596,24 +625,29 @@ int potrf_lower(ccz_ctx* c, double* A, int64_t d, int64_t lda) {
 void trsm_right_lower(ccz_ctx* c, bool trans, int64_t r, int64_t d, const double* L, int64_t ldl, double* X,
                       int64_t ldx) {
   if (r <= 0 || d <= 0) return;
+  const int64_t nblk = (d + NB - 1) / NB;
+  DBuf invT(c, nblk * NB * NB), tmp(c, r * NB);
+  diag_inverses(c, L, ldl, d, invT);
   if (trans) {
     // X L' = B, forward over column blocks:  X_j = (B_j - sum_{t<j} X_t L_jt') L_jj^-T
-    for (int64_t j = 0; j < d; j += NB) {
+    for (int64_t bj = 0; bj < nblk; ++bj) {
+      const int64_t j = bj * NB;
       const int nb = int(std::min<int64_t>(NB, d - j));
-      trsm_diag_rows(c, true, r, nb, L + j * ldl + j, ldl, X + j, ldx);
+      gemm(c, false, false, r, nb, nb, 1.0, X + j, ldx, invT.get() + bj * NB * NB, NB, 0.0, tmp, NB);
+      copy2d(c, r, nb, tmp, NB, X + j, ldx);
       const int64_t rem = d - j - nb;
       if (rem > 0)  // X[:, j+nb:] -= X_j  L[j+nb:, j]'
-        gemm(c, false, true, r, rem, nb, -1.0, X + j, ldx, L + (j + nb) * ldl + j, ldl, 1.0, X + j + nb, ldx);
+        gemm(c, false, true, r, rem, nb, -1.0, tmp, NB, L + (j + nb) * ldl + j, ldl, 1.0, X + j + nb, ldx);
     }
   } else {
-    // X L = B, backward:  X_j = (B_j - sum_{t>j} X_t L_tj) L_jj^-1
-    const int64_t nblk = (d + NB - 1) / NB;
+    // X L = B, backward:  X_j = (B_j - sum_{t>j} X_t L_tj) L_jj^-1 ;  L_jj^-1 = (invT_j)'
     for (int64_t bj = nblk - 1; bj >= 0; --bj) {
       const int64_t j = bj * NB;
       const int nb = int(std::min<int64_t>(NB, d - j));
-      trsm_diag_rows(c, false, r, nb, L + j * ldl + j, ldl, X + j, ldx);
+      gemm(c, false, true, r, nb, nb, 1.0, X + j, ldx, invT.get() + bj * NB * NB, NB, 0.0, tmp, NB);
+      copy2d(c, r, nb, tmp, NB, X + j, ldx);
       if (j > 0)  // X[:, :j] -= X_j L[j:j+nb, :j]
-        gemm(c, false, false, r, j, nb, -1.0, X + j, ldx, L + j * ldl, ldl, 1.0, X, ldx);
+        gemm(c, false, false, r, j, nb, -1.0, tmp, NB, L + j * ldl, ldl, 1.0, X, ldx);
     }
   }
 }
