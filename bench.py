@@ -171,7 +171,7 @@ def main():
                        "device": info["name"], "arch": info["arch"], "compute_units": info["compute_units"]},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": None,
-                         "kernel": "k_gram_f32" if a.dtype == "f32" else "k_gram_f64",
+                         "kernel": "k_gram_f32_fifo" if a.dtype == "f32" else "k_gram_f64",
                          "kernel_ms": g_ms, "flop_per_launch": flop,
                          "bytes_per_launch": float(n_local) * D * (4 if a.dtype == "f32" else 8),
                          "gram_share_of_step": g_ms / ms_per_step},

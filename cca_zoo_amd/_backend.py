@@ -113,6 +113,14 @@ def library():
     global _lib
     with _lock:
         if _lib is None:
+            # PyTorch-ROCm ships its own libamdhip64.so.7 / libhsa-runtime64.so.1 with the SAME sonames
+            # as /opt/rocm's.  Whichever is mapped first serves the whole process; torch cannot start
+            # on top of the system runtime ("No HIP GPUs are available"), the other order works and
+            # gives one shared runtime (same null stream, same allocations).  So: torch first.
+            try:
+                import torch  # noqa: F401
+            except ImportError:  # pragma: no cover - torch-less deployment uses /opt/rocm's runtime
+                pass
             path = library_path()
             if not os.path.exists(path):
                 raise CCZError(

@@ -14,8 +14,9 @@
 // columns == t mod 4).  That strided tile ownership is undone in the epilogue.
 //
 // Work decomposition: grid = (upper-triangular tile) x (row chunk).  fp32 views
-// accumulate a chunk (<= 4096 rows) in fp32 MFMA accumulators and flush into
-// the fp64 G with hardware fp64 atomics, so cross-chunk / cross-GPU
+// accumulate a chunk (<= 16384 rows) in fp32 MFMA accumulators and flush into
+// the fp64 G with hardware fp64 atomics (the flush costs ~45 us per workgroup:
+// 4096-row chunks lose 4.5% to it, 16384-row chunks 1.2%), so cross-chunk / cross-GPU
 // accumulation is fp64 (hard part 2).  blockIdx is chunk-major:
 // the ~256 resident workgroups stream the same rows of different panels, which
 // keeps the panel rows hot in L2 / Infinity Cache while HBM sees each input
@@ -25,6 +26,7 @@
 // v_mfma_f64_16x16x4_f64; B = n D sizeof(T) bytes.  MFMA-bound.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "hip_common.h"
@@ -53,6 +55,23 @@ constexpr int BK = 16;
 // Cast to the global address space explicitly.
 typedef const float __attribute__((address_space(1)))* gptr_f32;
 typedef const double __attribute__((address_space(1)))* gptr_f64;
+
+// Fast-path staging loads go through a buffer resource: the descriptor (panel base + byte
+// extent of this workgroup's rows) sits in SGPRs, the per-lane byte offset is a loop-invariant
+// VGPR and the k-block advance is a scalar add -- zero vector address arithmetic inside the
+// MFMA loop (PMC: the 64-bit address math of plain global loads cost ~13% of the wave's issue
+// time).  Rows past the extent are out of range for the descriptor and read as 0, which is
+// exactly the zero padding the row tail needs.
+typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t panel_rsrc(const void* base, int64_t bytes) {
+  const uint64_t p = reinterpret_cast<uint64_t>(base);
+  const unsigned lo = __builtin_amdgcn_readfirstlane(unsigned(p));
+  const unsigned hi = __builtin_amdgcn_readfirstlane(unsigned(p >> 32));
+  const unsigned nb = __builtin_amdgcn_readfirstlane(unsigned(bytes));
+  void* q = reinterpret_cast<void*>((uint64_t(hi) << 32) | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(q, 0, int(nb), 0x00020000);
+}
 
 // ---------------------------------------------------------------------------
 // fp32: 256 x 256 tile per workgroup, 4 waves (2 x 2), each wave 128 x 128 =
@@ -105,12 +124,35 @@ __global__ __launch_bounds__(256, 1) void k_gram_f32(const GramTile* __restrict_
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   v4f32 ra[4], rb[4];
-  auto gload = [&](int64_t k0) {
+  // fast path: descriptors over this workgroup's rows of the two panels
+  const int64_t nrows = k_end - k_begin;
+  __amdgpu_buffer_rsrc_t srcA, srcB;
+  int voffA[4], voffB[4];
+  if (FAST) {
+    srcA = panel_rsrc(static_cast<const float*>(t.a) + k_begin * t.lda, nrows * t.lda * 4);
+    srcB = panel_rsrc(static_cast<const float*>(t.b) + k_begin * t.ldb, nrows * t.ldb * 4);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int64_t row = k0 + r4 + 4 * i;
-      ra[i] = load4_f32<FAST>(A, row, last_row, cg, t.lda, t.wa);
-      rb[i] = load4_f32<FAST>(B, row, last_row, cg, t.ldb, t.wb);
+      voffA[i] = int(((r4 + 4 * i) * t.lda + 4 * cg) * 4);
+      voffB[i] = int(((r4 + 4 * i) * t.ldb + 4 * cg) * 4);
+    }
+  }
+  auto gload = [&](int64_t k0) {
+    if (FAST) {
+      const int soffA = __builtin_amdgcn_readfirstlane(int((k0 - k_begin) * t.lda * 4));
+      const int soffB = __builtin_amdgcn_readfirstlane(int((k0 - k_begin) * t.ldb * 4));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ra[i] = __builtin_bit_cast(v4f32, __builtin_amdgcn_raw_buffer_load_b128(srcA, voffA[i], soffA, 0));
+        rb[i] = __builtin_bit_cast(v4f32, __builtin_amdgcn_raw_buffer_load_b128(srcB, voffB[i], soffB, 0));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t row = k0 + r4 + 4 * i;
+        ra[i] = load4_f32<false>(A, row, last_row, cg, t.lda, t.wa);
+        rb[i] = load4_f32<false>(B, row, last_row, cg, t.ldb, t.wb);
+      }
     }
   };
   auto lstore = [&](int buf, int64_t k0) {
@@ -119,7 +161,7 @@ __global__ __launch_bounds__(256, 1) void k_gram_f32(const GramTile* __restrict_
     const v4f32 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const bool ok = k0 + r4 + 4 * i <= last_row;
+      const bool ok = FAST || k0 + r4 + 4 * i <= last_row;   // fast path: the descriptor already zero-fills
       *reinterpret_cast<v4f32*>(as + (r4 + 4 * i) * T32 + 4 * cg) = ok ? ra[i] : z;
       *reinterpret_cast<v4f32*>(bs + (r4 + 4 * i) * T32 + 4 * cg) = ok ? rb[i] : z;
     }
@@ -177,6 +219,145 @@ __global__ __launch_bounds__(256, 1) void k_gram_f32(const GramTile* __restrict_
 }
 
 // ---------------------------------------------------------------------------
+// fp32 fast path, WAVE-PRIVATE LDS FIFO: no barriers, counted vmcnt only.
+//
+// For X'X on row-major X the MFMA A/B fragment of a k-step IS a coalesced 16-byte-per-lane
+// global read (lane l: row k0 + l/32, columns 4 (l%32) .. +3 of the wave's 128-column slab), so
+// a wave can stream its own operands without sharing anything with the other waves.  Keeping the
+// in-flight window in VGPRs does not pipeline (hipcc drains vmcnt(0) at every loop back-edge for
+// register-destination loads: measured 126 TF); instead the window lives in LDS:
+// `buffer_load_dwordx4 ... lds` has no VGPR destination, so hipcc does not force vmcnt(0) at
+// the loop back-edge and the hand-placed `s_waitcnt vmcnt(14)` keeps ~3 blocks (24 rows,
+// ~12k cycles) of loads in flight per wave.  Each wave owns a 4-slot ring of 8-row blocks
+// (A slab | B slab, 8 KiB per slot, 32 KiB per wave, 128 KiB per workgroup); a lane reads back
+// with ds_read_b128 exactly the 16 bytes it DMA'd, so there is no cross-wave hazard and the
+// only ordering needed is the issuing wave's own vmcnt.  Per k-step (16 MFMAs = 1024 cycles):
+// 2 DMA issues for block b+3, 2 fragment reads for the next k-step, nothing else.
+// ---------------------------------------------------------------------------
+constexpr int FB = 8;        // rows per FIFO block
+constexpr int FR = 4;        // ring slots per wave
+constexpr int FSLOT = 2 * FB * 128 * 4;   // bytes per slot: A slab + B slab
+
+__global__ __launch_bounds__(256, 1) void k_gram_f32_fifo(const GramTile* __restrict__ tiles, int ntiles, int64_t n,
+                                                          int64_t rows_per_wg, double* __restrict__ G, int64_t ldg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tile_id = int(blockIdx.x % unsigned(ntiles));
+  const int64_t ks_id = blockIdx.x / unsigned(ntiles);
+  const GramTile t = tiles[tile_id];
+  const int64_t k_begin = ks_id * rows_per_wg;
+  const int64_t k_end = min(n, k_begin + rows_per_wg);
+  if (k_begin >= k_end) return;
+  const int64_t nrows = k_end - k_begin;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  char* ring = smem + wave * (FR * FSLOT);
+
+  const __amdgpu_buffer_rsrc_t srcA =
+      panel_rsrc(static_cast<const float*>(t.a) + k_begin * t.lda + wr * 128, ((nrows - 1) * t.lda + 128) * 4);
+  const __amdgpu_buffer_rsrc_t srcB =
+      panel_rsrc(static_cast<const float*>(t.b) + k_begin * t.ldb + wc * 128, ((nrows - 1) * t.ldb + 128) * 4);
+  const int voffA = int(((lane >> 5) * t.lda + 4 * (lane & 31)) * 4);
+  const int voffB = int(((lane >> 5) * t.ldb + 4 * (lane & 31)) * 4);
+  const int stepA = __builtin_amdgcn_readfirstlane(int(2 * t.lda * 4));   // bytes per k-step (2 rows)
+  const int stepB = __builtin_amdgcn_readfirstlane(int(2 * t.ldb * 4));
+  int soffA = 0, soffB = 0;          // byte offset of the next k-step to DMA
+  int wslot = 0;                     // byte offset (within the ring) of the k-step being written
+  // DMA one k-step (2 rows of both slabs) into the ring; rows past the extent arrive as zeros.
+  // Split in three pieces so that each piece can sit in the shadow of a different MFMA group.
+  auto dma_a = [&]() {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(srcA, (lds_ptr)(ring + wslot), 16, voffA, soffA, 0, 0);
+    soffA += stepA;
+  };
+  auto dma_b = [&]() {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(srcB, (lds_ptr)(ring + wslot + FB * 128 * 4), 16, voffB, soffB, 0, 0);
+    soffB += stepB;
+  };
+  auto dma_advance = [&]() {
+    // next k-step: +1 KiB inside the slab; after 4 k-steps jump to the next slot (wrap at the ring end)
+    wslot += 1024;
+    if ((wslot & (FB * 128 * 4 - 1)) == 0) wslot = (wslot + FB * 128 * 4) & (FR * FSLOT - 1);
+  };
+  auto dma_step = [&]() { dma_a(); dma_b(); dma_advance(); };
+
+  v16f32 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // prologue: blocks 0, 1, 2 in flight (12 k-steps = 24 DMA instructions)
+#pragma unroll
+  for (int u = 0; u < 3 * (FB / 2); ++u) dma_step();
+  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                  // block 0 landed
+  int rslot = 0;                                                    // byte offset of the k-step being read
+  v4f32 af[2], bf[2];
+  af[0] = *reinterpret_cast<const v4f32*>(ring + rslot + lane * 16);
+  bf[0] = *reinterpret_cast<const v4f32*>(ring + rslot + FB * 128 * 4 + lane * 16);
+
+  const int64_t nblk = (nrows + FB - 1) / FB;
+  for (int64_t b = 0; b < nblk; ++b) {
+#pragma unroll
+    for (int u = 0; u < FB / 2; ++u) {
+      // The 16 MFMAs of a k-step go out in four groups of four; the step's other work is spread
+      // over the gaps in front of the groups (a few instructions each, hidden under the preceding
+      // 64-cycle MFMA) instead of being clustered at the step boundary.
+      const v4f32 a4 = af[u & 1], b4 = bf[u & 1];
+      // -- gap 0: fragment reads for the next k-step
+      rslot += 1024;
+      if ((rslot & (FB * 128 * 4 - 1)) == 0) rslot = (rslot + FB * 128 * 4) & (FR * FSLOT - 1);
+      if (u == FB / 2 - 1) {
+        // the next k-step opens block b+1: newer than it are block b+2 (8) and 3 k-steps of b+3 (6)
+        asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+      }
+      af[(u + 1) & 1] = *reinterpret_cast<const v4f32*>(ring + rslot + lane * 16);
+      bf[(u + 1) & 1] = *reinterpret_cast<const v4f32*>(ring + rslot + FB * 128 * 4 + lane * 16);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj) acc[0][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[0], b4[tj], acc[0][tj], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      // -- gap 1: DMA of the A slab rows of k-step u of block b+3
+      dma_a();
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj) acc[1][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[1], b4[tj], acc[1][tj], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      // -- gap 2: DMA of the B slab rows
+      dma_b();
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj) acc[2][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[2], b4[tj], acc[2][tj], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      // -- gap 3: ring pointer bookkeeping (scalar)
+      dma_advance();
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj) acc[3][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[3], b4[tj], acc[3][tj], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int trow = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int i = wr * 128 + 4 * trow + ti;
+      double* grow = G + (t.out_row + i) * ldg + t.out_col;
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj) {
+        const int j = wc * 128 + 4 * (lane & 31) + tj;
+        unsafeAtomicAdd(grow + j, double(acc[ti][tj][r]));
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // fp64: 128 x 128 tile per workgroup, 4 waves (2 x 2), each wave 64 x 64 =
 // 4 x 4 MFMA f64 16x16x4 tiles (128 accumulator registers)
 // ---------------------------------------------------------------------------
@@ -225,12 +406,34 @@ __global__ __launch_bounds__(256, 1) void k_gram_f64(const GramTile* __restrict_
       for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
 
   v2f64 ra[4], rb[4];
-  auto gload = [&](int64_t k0) {
+  const int64_t nrows = k_end - k_begin;
+  __amdgpu_buffer_rsrc_t srcA, srcB;
+  int voffA[4], voffB[4];
+  if (FAST) {
+    srcA = panel_rsrc(static_cast<const double*>(t.a) + k_begin * t.lda, nrows * t.lda * 8);
+    srcB = panel_rsrc(static_cast<const double*>(t.b) + k_begin * t.ldb, nrows * t.ldb * 8);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int64_t row = k0 + r4 + 4 * i;
-      ra[i] = load2_f64<FAST>(A, row, last_row, cg, t.lda, t.wa);
-      rb[i] = load2_f64<FAST>(B, row, last_row, cg, t.ldb, t.wb);
+      voffA[i] = int(((r4 + 4 * i) * t.lda + 2 * cg) * 8);
+      voffB[i] = int(((r4 + 4 * i) * t.ldb + 2 * cg) * 8);
+    }
+  }
+  auto gload = [&](int64_t k0) {
+    if (FAST) {
+      const int soffA = __builtin_amdgcn_readfirstlane(int((k0 - k_begin) * t.lda * 8));
+      const int soffB = __builtin_amdgcn_readfirstlane(int((k0 - k_begin) * t.ldb * 8));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ra[i] = __builtin_bit_cast(v2f64, __builtin_amdgcn_raw_buffer_load_b128(srcA, voffA[i], soffA, 0));
+        rb[i] = __builtin_bit_cast(v2f64, __builtin_amdgcn_raw_buffer_load_b128(srcB, voffB[i], soffB, 0));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t row = k0 + r4 + 4 * i;
+        ra[i] = load2_f64<false>(A, row, last_row, cg, t.lda, t.wa);
+        rb[i] = load2_f64<false>(B, row, last_row, cg, t.ldb, t.wb);
+      }
     }
   };
   auto lstore = [&](int buf, int64_t k0) {
@@ -239,7 +442,7 @@ __global__ __launch_bounds__(256, 1) void k_gram_f64(const GramTile* __restrict_
     const v2f64 z = {0.0, 0.0};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const bool ok = k0 + r4 + 4 * i <= last_row;
+      const bool ok = FAST || k0 + r4 + 4 * i <= last_row;
       *reinterpret_cast<v2f64*>(as + (r4 + 4 * i) * T64 + 2 * cg) = ok ? ra[i] : z;
       *reinterpret_cast<v2f64*>(bs + (r4 + 4 * i) * T64 + 2 * cg) = ok ? rb[i] : z;
     }
@@ -364,7 +567,14 @@ void launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
   h2d(c, d_tiles, tiles.data(), tiles.size() * sizeof(GramTile));
 
   const int ncu = std::max(1, im->props.multiProcessorCount);
-  const int64_t max_rows = is32 ? 4096 : 16384;
+  static const int64_t rows_env = [] { const char* e = getenv("CCZ_GRAM_ROWS"); return e ? atoll(e) : 0LL; }();
+  int64_t max_rows = rows_env > 0 ? rows_env : 16384;
+  if (fast) {   // keep (rows + FIFO run-ahead) * ld * sizeof(T) inside the 32-bit buffer descriptor
+    int64_t cap = max_rows;
+    for (int v = 0; v < n_views; ++v)
+      cap = std::min<int64_t>(cap, ((int64_t(1) << 31) - 1) / (views[v].ld * int64_t(sizeof(T))) - 64);
+    if (cap < 256) fast = false; else max_rows = cap;
+  }
   int64_t rows_per_wg = (n * ntiles + int64_t(ncu) * 8 - 1) / (int64_t(ncu) * 8);
   rows_per_wg = std::max<int64_t>(256, std::min<int64_t>(max_rows, rows_per_wg));
   rows_per_wg = (rows_per_wg + BK - 1) / BK * BK;
@@ -374,8 +584,13 @@ void launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
   const size_t lds_bytes = size_t(2) * 2 * BK * tile * sizeof(T);  // 64 KiB either way
 
   if (time_it) CCZ_HIP(hipEventRecord(im->ev[0], st));
+  static const int impl_sel = [] { const char* e = getenv("CCZ_GRAM_IMPL"); return e ? atoi(e) : 1; }();   // 1: wave-private FIFO (default), 0: register-staged shared tile
   if (is32) {
-    if (fast) {
+    if (fast && impl_sel != 0) {
+      const size_t fifo_bytes = size_t(4) * FR * FSLOT;   // 128 KiB: four wave-private rings
+      CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_f32_fifo), hipFuncAttributeMaxDynamicSharedMemorySize, int(fifo_bytes)));
+      hipLaunchKernelGGL(k_gram_f32_fifo, dim3((unsigned)nblocks), dim3(256), fifo_bytes, st, d_tiles, ntiles, n, rows_per_wg, G, D);
+    } else if (fast) {
       CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_f32<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
       hipLaunchKernelGGL(k_gram_f32<true>, dim3((unsigned)nblocks), dim3(256), lds_bytes, st, d_tiles, ntiles, n, rows_per_wg, G, D);
     } else {
