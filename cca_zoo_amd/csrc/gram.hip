@@ -231,12 +231,19 @@ __global__ __launch_bounds__(256, 1) void k_gram_f32(const GramTile* __restrict_
 // ~12k cycles) of loads in flight per wave.  Each wave owns a 4-slot ring of 8-row blocks
 // (A slab | B slab, 8 KiB per slot, 32 KiB per wave, 128 KiB per workgroup); a lane reads back
 // with ds_read_b128 exactly the 16 bytes it DMA'd, so there is no cross-wave hazard and the
-// only ordering needed is the issuing wave's own vmcnt.  Per k-step (16 MFMAs = 1024 cycles):
-// 2 DMA issues for block b+3, 2 fragment reads for the next k-step, nothing else.
+// only ordering needed is the issuing wave's own vmcnt.
+//
+// Issue budget (measured): instructions of the same wave are NOT hidden under its MFMAs -- 8
+// extra VALU ops per k-step cost 8% -- so the loop is unrolled over the whole ring period
+// (4 blocks x 4 k-steps): every LDS address is base + immediate, and a k-step is 16 MFMAs +
+// 2 ds_read_b128 + 2 LDS-DMA (+ m0 / soffset scalar adds), spread over the four MFMA groups.
+// For the same reason the column sums stay in their own HBM-bound pass (5 ms at the headline
+// shape) instead of riding in this loop.
 // ---------------------------------------------------------------------------
 constexpr int FB = 8;        // rows per FIFO block
 constexpr int FR = 4;        // ring slots per wave
-constexpr int FSLOT = 2 * FB * 128 * 4;   // bytes per slot: A slab + B slab
+constexpr int FSLAB = FB * 128 * 4;       // bytes of one slab (A or B) in a slot
+constexpr int FSLOT = 2 * FSLAB;          // bytes per slot: A slab + B slab
 
 __global__ __launch_bounds__(256, 1) void k_gram_f32_fifo(const GramTile* __restrict__ tiles, int ntiles, int64_t n,
                                                           int64_t rows_per_wg, double* __restrict__ G, int64_t ldg) {
@@ -253,7 +260,8 @@ __global__ __launch_bounds__(256, 1) void k_gram_f32_fifo(const GramTile* __rest
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
   typedef __attribute__((address_space(3))) void* lds_ptr;
-  char* ring = smem + wave * (FR * FSLOT);
+  char* ring = smem + wave * (FR * FSLOT);       // wave-uniform base of this wave's ring
+  const char* rd = ring + lane * 16;             // per-lane read base: every read is rd + immediate
 
   const __amdgpu_buffer_rsrc_t srcA =
       panel_rsrc(static_cast<const float*>(t.a) + k_begin * t.lda + wr * 128, ((nrows - 1) * t.lda + 128) * 4);
@@ -263,24 +271,7 @@ __global__ __launch_bounds__(256, 1) void k_gram_f32_fifo(const GramTile* __rest
   const int voffB = int(((lane >> 5) * t.ldb + 4 * (lane & 31)) * 4);
   const int stepA = __builtin_amdgcn_readfirstlane(int(2 * t.lda * 4));   // bytes per k-step (2 rows)
   const int stepB = __builtin_amdgcn_readfirstlane(int(2 * t.ldb * 4));
-  int soffA = 0, soffB = 0;          // byte offset of the next k-step to DMA
-  int wslot = 0;                     // byte offset (within the ring) of the k-step being written
-  // DMA one k-step (2 rows of both slabs) into the ring; rows past the extent arrive as zeros.
-  // Split in three pieces so that each piece can sit in the shadow of a different MFMA group.
-  auto dma_a = [&]() {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(srcA, (lds_ptr)(ring + wslot), 16, voffA, soffA, 0, 0);
-    soffA += stepA;
-  };
-  auto dma_b = [&]() {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(srcB, (lds_ptr)(ring + wslot + FB * 128 * 4), 16, voffB, soffB, 0, 0);
-    soffB += stepB;
-  };
-  auto dma_advance = [&]() {
-    // next k-step: +1 KiB inside the slab; after 4 k-steps jump to the next slot (wrap at the ring end)
-    wslot += 1024;
-    if ((wslot & (FB * 128 * 4 - 1)) == 0) wslot = (wslot + FB * 128 * 4) & (FR * FSLOT - 1);
-  };
-  auto dma_step = [&]() { dma_a(); dma_b(); dma_advance(); };
+  int soffA = 0, soffB = 0;          // byte offset of the next k-step to DMA (rows past the extent arrive as 0)
 
   v16f32 acc[4][4];
 #pragma unroll
@@ -290,54 +281,62 @@ __global__ __launch_bounds__(256, 1) void k_gram_f32_fifo(const GramTile* __rest
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // prologue: blocks 0, 1, 2 in flight (12 k-steps = 24 DMA instructions)
+  // prologue: blocks 0, 1, 2 -> slots 0, 1, 2 (12 k-steps = 24 DMA instructions)
 #pragma unroll
-  for (int u = 0; u < 3 * (FB / 2); ++u) dma_step();
-  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                  // block 0 landed
-  int rslot = 0;                                                    // byte offset of the k-step being read
-  v4f32 af[2], bf[2];
-  af[0] = *reinterpret_cast<const v4f32*>(ring + rslot + lane * 16);
-  bf[0] = *reinterpret_cast<const v4f32*>(ring + rslot + FB * 128 * 4 + lane * 16);
-
-  const int64_t nblk = (nrows + FB - 1) / FB;
-  for (int64_t b = 0; b < nblk; ++b) {
+  for (int s = 0; s < 3; ++s)
 #pragma unroll
     for (int u = 0; u < FB / 2; ++u) {
-      // The 16 MFMAs of a k-step go out in four groups of four; the step's other work is spread
-      // over the gaps in front of the groups (a few instructions each, hidden under the preceding
-      // 64-cycle MFMA) instead of being clustered at the step boundary.
-      const v4f32 a4 = af[u & 1], b4 = bf[u & 1];
-      // -- gap 0: fragment reads for the next k-step
-      rslot += 1024;
-      if ((rslot & (FB * 128 * 4 - 1)) == 0) rslot = (rslot + FB * 128 * 4) & (FR * FSLOT - 1);
-      if (u == FB / 2 - 1) {
-        // the next k-step opens block b+1: newer than it are block b+2 (8) and 3 k-steps of b+3 (6)
-        asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srcA, (lds_ptr)(ring + s * FSLOT + u * 1024), 16, voffA, soffA, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srcB, (lds_ptr)(ring + s * FSLOT + FSLAB + u * 1024), 16, voffB, soffB, 0, 0);
+      soffA += stepA;
+      soffB += stepB;
+    }
+  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                  // block 0 landed
+  v4f32 af[2], bf[2];
+  af[0] = *reinterpret_cast<const v4f32*>(rd);
+  bf[0] = *reinterpret_cast<const v4f32*>(rd + FSLAB);
+
+  const int64_t nblk = (nrows + FB - 1) / FB;
+  for (int64_t b0 = 0; b0 < nblk; b0 += FR) {      // one trip = the whole ring period: slots are static
+#pragma unroll
+    for (int bb = 0; bb < FR; ++bb) {
+#pragma unroll
+      for (int u = 0; u < FB / 2; ++u) {
+        constexpr int NU = FB / 2;
+        const int cur = (bb * NU + u) & 1, nxt = cur ^ 1;
+        // next k-step to read: (bb, u+1) or the first of the next slot
+        const int nslot = (u + 1 < NU) ? bb : (bb + 1) % FR;
+        const int nu = (u + 1 < NU) ? u + 1 : 0;
+        const int wsl = (bb + 3) % FR;               // slot being refilled: block b0 + bb + 3
+        const v4f32 a4 = af[cur], b4 = bf[cur];
+        // -- gap 0: fragment reads for the next k-step
+        if (u == NU - 1) {
+          // the next k-step opens block b+1: newer than it are block b+2 (8) and 3 k-steps of b+3 (6)
+          asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+        }
+        af[nxt] = *reinterpret_cast<const v4f32*>(rd + nslot * FSLOT + nu * 1024);
+        bf[nxt] = *reinterpret_cast<const v4f32*>(rd + nslot * FSLOT + FSLAB + nu * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) acc[0][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[0], b4[tj], acc[0][tj], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // -- gap 1: DMA of the A slab rows of k-step u of block b+3
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srcA, (lds_ptr)(ring + wsl * FSLOT + u * 1024), 16, voffA, soffA, 0, 0);
+        soffA += stepA;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) acc[1][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[1], b4[tj], acc[1][tj], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // -- gap 2: DMA of the B slab rows
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srcB, (lds_ptr)(ring + wsl * FSLOT + FSLAB + u * 1024), 16, voffB, soffB, 0, 0);
+        soffB += stepB;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) acc[2][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[2], b4[tj], acc[2][tj], 0, 0, 0);
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) acc[3][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[3], b4[tj], acc[3][tj], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      af[(u + 1) & 1] = *reinterpret_cast<const v4f32*>(ring + rslot + lane * 16);
-      bf[(u + 1) & 1] = *reinterpret_cast<const v4f32*>(ring + rslot + FB * 128 * 4 + lane * 16);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int tj = 0; tj < 4; ++tj) acc[0][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[0], b4[tj], acc[0][tj], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      // -- gap 1: DMA of the A slab rows of k-step u of block b+3
-      dma_a();
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int tj = 0; tj < 4; ++tj) acc[1][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[1], b4[tj], acc[1][tj], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      // -- gap 2: DMA of the B slab rows
-      dma_b();
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int tj = 0; tj < 4; ++tj) acc[2][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[2], b4[tj], acc[2][tj], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      // -- gap 3: ring pointer bookkeeping (scalar)
-      dma_advance();
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int tj = 0; tj < 4; ++tj) acc[3][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[3], b4[tj], acc[3][tj], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -572,7 +571,7 @@ void launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
   if (fast) {   // keep (rows + FIFO run-ahead) * ld * sizeof(T) inside the 32-bit buffer descriptor
     int64_t cap = max_rows;
     for (int v = 0; v < n_views; ++v)
-      cap = std::min<int64_t>(cap, ((int64_t(1) << 31) - 1) / (views[v].ld * int64_t(sizeof(T))) - 64);
+      cap = std::min<int64_t>(cap, ((int64_t(1) << 31) - 1) / (views[v].ld * int64_t(sizeof(T))) - 128);
     if (cap < 256) fast = false; else max_rows = cap;
   }
   int64_t rows_per_wg = (n * ntiles + int64_t(ncu) * 8 - 1) / (int64_t(ncu) * 8);

@@ -701,12 +701,79 @@ __global__ __launch_bounds__(BS) void k_jacobi_round(int64_t p, int64_t pe, int6
   }
 }
 
+// Small problems (the Rayleigh-Ritz blocks of the subspace iteration, p ~ 80): the whole W and Q
+// live in LDS and ONE workgroup runs every round of every sweep, a wavefront per row pair with
+// shuffle reductions for the three inner products -- no launches, no global traffic inside.
+__global__ __launch_bounds__(1024) void k_jacobi_lds(int p, int q, double* __restrict__ W, int64_t ldw,
+                                                     double* __restrict__ Q, int qc, int64_t ldq, double tol,
+                                                     int max_sweeps, int* __restrict__ sweeps_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int sq = q | 1, sqc = qc | 1;                 // odd row strides: conflict-free column walks
+  double* Ws = reinterpret_cast<double*>(smem);
+  double* Qs = Ws + size_t(p) * sq;
+  // the counter lives at the end of the dynamic region (a static __shared__ object in front of it
+  // would shift the region's base off its 16-byte alignment)
+  int& rot_count = *reinterpret_cast<int*>(Qs + (Q ? size_t(p) * sqc : 0));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  for (int i = tid; i < p * q; i += blockDim.x) Ws[(i / q) * sq + i % q] = W[int64_t(i / q) * ldw + i % q];
+  if (Q) for (int i = tid; i < p * qc; i += blockDim.x) Qs[(i / qc) * sqc + i % qc] = Q[int64_t(i / qc) * ldq + i % qc];
+  const int pe = (p + 1) & ~1, m1 = pe - 1;
+  int sweep = 0, done = 0;
+  __syncthreads();
+  while (sweep < max_sweeps && !done) {
+    ++sweep;
+    if (tid == 0) rot_count = 0;
+    __syncthreads();
+    for (int round = 0; round < m1; ++round) {
+      for (int k = wave; k < pe / 2; k += nw) {
+        int a, b;
+        if (k == 0) { a = m1; b = round; } else { a = (round + k) % m1; b = (round - k + m1) % m1; }
+        if (a >= p || b >= p) continue;
+        double* wa = Ws + a * sq;
+        double* wb = Ws + b * sq;
+        double al = 0.0, be = 0.0, ga = 0.0;
+        for (int t = lane; t < q; t += 64) { const double x = wa[t], y = wb[t]; al += x * x; be += y * y; ga += x * y; }
+        al = wave_sum(al); be = wave_sum(be); ga = wave_sum(ga);
+        const double prod = al * be;
+        if (!(prod > 0.0) || !(fabs(ga) > tol * sqrt(prod))) continue;
+        if (lane == 0) atomicAdd(&rot_count, 1);
+        const double zeta = (be - al) / (2.0 * ga);
+        const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
+        for (int t = lane; t < q; t += 64) { const double x = wa[t], y = wb[t]; wa[t] = cs * x - sn * y; wb[t] = sn * x + cs * y; }
+        if (Q) {
+          double* qa = Qs + a * sqc;
+          double* qb = Qs + b * sqc;
+          for (int t = lane; t < qc; t += 64) { const double x = qa[t], y = qb[t]; qa[t] = cs * x - sn * y; qb[t] = sn * x + cs * y; }
+        }
+      }
+      __syncthreads();
+    }
+    done = (rot_count == 0);
+    __syncthreads();
+  }
+  for (int i = tid; i < p * q; i += blockDim.x) W[int64_t(i / q) * ldw + i % q] = Ws[(i / q) * sq + i % q];
+  if (Q) for (int i = tid; i < p * qc; i += blockDim.x) Q[int64_t(i / qc) * ldq + i % qc] = Qs[(i / qc) * sqc + i % qc];
+  if (tid == 0) *sweeps_out = done ? sweep : -1;
+}
+
 int jacobi_rows(ccz_ctx* c, int64_t p, int64_t q, double* W, int64_t ldw, double* Q, int64_t qc, int64_t ldq,
                 int max_sweeps) {
   if (p < 2) return 1;
   Impl* im = impl(c);
   const int64_t pe = (p + 1) & ~int64_t(1);
   const double tol = 2.220446049250313e-16 * std::sqrt(double(q)) * 4.0;
+  const size_t lds_need = (size_t(p) * (q | 1) + (Q ? size_t(p) * (qc | 1) : 0)) * 8;
+  if (lds_need <= size_t(144) * 1024) {
+    CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jacobi_lds), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_need + 16)));
+    hipLaunchKernelGGL(k_jacobi_lds, dim3(1), dim3(1024), lds_need + 16, stream(c), int(p), int(q), W, ldw, Q, int(Q ? qc : 0), ldq,
+                       tol, max_sweeps, im->d_flag + 1);
+    CCZ_LAUNCH_CHECK();
+    int sw = 0;
+    d2h(c, &sw, im->d_flag + 1, sizeof(int));
+    if (sw < 0) fail(CCZ_ENOCONV, "Jacobi did not converge in %d sweeps (p=%lld, q=%lld)", max_sweeps, (long long)p, (long long)q);
+    return sw;
+  }
   const bool small = std::max(q, Q ? qc : 0) <= 256;
   dim3 grid((unsigned)(pe / 2));
   for (int sweep = 1; sweep <= max_sweeps; ++sweep) {
