@@ -3,7 +3,7 @@
 ``views`` are what ``validate_views`` returned: C-contiguous-izable numpy arrays
 (streamed to the device in row chunks by libccz) or torch CUDA tensors (handed over
 by pointer).  Returns ``(moments_ptr, keepalive, n_total, dims, in_dtype)`` with the
-moments symmetrised and -- inside ``row_sharded()`` -- summed over all ranks.
+moments (upper-triangular tiles of G, column sums) and -- inside ``row_sharded()`` -- summed over all ranks.
 """
 
 from __future__ import annotations
@@ -71,5 +71,5 @@ def compute_moments(views, handle=None):
     if sharded:
         h.sync()
         n_total = _dist.allreduce_moments(mom_t, n, _dist.active_group())
-    h.moments_symmetrize(mom_ptr, D)
+    # no symmetrisation pass: the solvers read the upper triangle (authoritative) on both sides
     return mom_ptr, keep, n_total, dims, kind

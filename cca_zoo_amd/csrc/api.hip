@@ -45,7 +45,6 @@ static void cca_loss_impl(ccz_ctx* c, int dtype, const void* z1, const void* z2,
   moments_impl(c, dtype, views, 2, n, true, mom, false);
   double* G = mom;
   double* s = mom.get() + D * D;
-  mirror_upper(c, D, G, D);
   const double inv = 1.0 / double(n - 1);
 
   DBuf L1(c, d1 * d1), L2(c, d2 * d2), S12(c, d1 * d2);

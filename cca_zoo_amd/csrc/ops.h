@@ -95,7 +95,8 @@ void scale_cols(ccz_ctx* c, int64_t rows, int64_t cols, double* A, int64_t lda, 
 // make the lower triangle equal to the upper one: A[i][j] = A[j][i] for i > j
 void mirror_upper(ccz_ctx* c, int64_t d, double* A, int64_t lda);
 // out (rows x cols) = alpha * ( G[r0+i][c0+j] - (centre ? s[r0+i] s[c0+j] / n : 0) );
-// G is D x D (ld D) SYMMETRIC-COMPLETE, s has D entries
+// G is D x D (ld D); only its UPPER triangle is read (element (i, j), i > j, comes from (j, i)),
+// so the moments need not be symmetrised first; s has D entries
 void cov_block(ccz_ctx* c, const double* G, int64_t D, const double* s, int64_t n, bool centre,
                double alpha, int64_t r0, int64_t rows, int64_t c0, int64_t cols, double* out,
                int64_t ldo);

@@ -373,8 +373,10 @@ __global__ void k_cov_block(int64_t total, int64_t cols, const double* __restric
                             int64_t c0, double* __restrict__ out, int64_t ldo) {
   for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += int64_t(gridDim.x) * blockDim.x) {
     const int64_t r = i / cols, cc = i - r * cols;
-    double v = G[(r0 + r) * D + (c0 + cc)];
-    if (centre) v -= s[r0 + r] * s[c0 + cc] * inv_n;
+    // K1 fills upper-triangular tiles only: read every element from the upper triangle
+    const int64_t gr = r0 + r, gc = c0 + cc;
+    double v = gr <= gc ? G[gr * D + gc] : G[gc * D + gr];
+    if (centre) v -= s[gr] * s[gc] * inv_n;
     out[r * ldo + cc] = alpha * v;
   }
 }
@@ -702,8 +704,25 @@ __global__ __launch_bounds__(BS) void k_jacobi_round(int64_t p, int64_t pe, int6
 }
 
 // Small problems (the Rayleigh-Ritz blocks of the subspace iteration, p ~ 80): the whole W and Q
-// live in LDS and ONE workgroup runs every round of every sweep, a wavefront per row pair with
-// shuffle reductions for the three inner products -- no launches, no global traffic inside.
+// live in LDS and ONE workgroup runs every round of every sweep.  A row pair is handled by a
+// 16-lane DPP row (64 pairs per pass of the 1024-thread workgroup); the three inner products
+// are reduced with DPP lane permutes (quad_perm, row_half_mirror, row_mirror) -- no LDS round
+// trips, no launches, no global traffic inside the sweeps.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+// sum over the 16 lanes of a DPP row, result in every lane of the row
+__device__ __forceinline__ double row16_sum(double v) {
+  v += dpp_mov_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_mov_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_mov_f64<0x141>(v);   // row_half_mirror
+  v += dpp_mov_f64<0x140>(v);   // row_mirror
+  return v;
+}
+
 __global__ __launch_bounds__(1024) void k_jacobi_lds(int p, int q, double* __restrict__ W, int64_t ldw,
                                                      double* __restrict__ Q, int qc, int64_t ldq, double tol,
                                                      int max_sweeps, int* __restrict__ sweeps_out) {
@@ -714,7 +733,7 @@ __global__ __launch_bounds__(1024) void k_jacobi_lds(int p, int q, double* __res
   // the counter lives at the end of the dynamic region (a static __shared__ object in front of it
   // would shift the region's base off its 16-byte alignment)
   int& rot_count = *reinterpret_cast<int*>(Qs + (Q ? size_t(p) * sqc : 0));
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  const int tid = threadIdx.x, gl = tid & 15, grp = tid >> 4, ngrp = blockDim.x >> 4;
   for (int i = tid; i < p * q; i += blockDim.x) Ws[(i / q) * sq + i % q] = W[int64_t(i / q) * ldw + i % q];
   if (Q) for (int i = tid; i < p * qc; i += blockDim.x) Qs[(i / qc) * sqc + i % qc] = Q[int64_t(i / qc) * ldq + i % qc];
   const int pe = (p + 1) & ~1, m1 = pe - 1;
@@ -725,26 +744,27 @@ __global__ __launch_bounds__(1024) void k_jacobi_lds(int p, int q, double* __res
     if (tid == 0) rot_count = 0;
     __syncthreads();
     for (int round = 0; round < m1; ++round) {
-      for (int k = wave; k < pe / 2; k += nw) {
+      for (int k = grp; k < pe / 2; k += ngrp) {
         int a, b;
         if (k == 0) { a = m1; b = round; } else { a = (round + k) % m1; b = (round - k + m1) % m1; }
-        if (a >= p || b >= p) continue;
-        double* wa = Ws + a * sq;
-        double* wb = Ws + b * sq;
+        const bool live = a < p && b < p;              // uniform over the 16-lane row
+        double* wa = Ws + (live ? a : 0) * sq;
+        double* wb = Ws + (live ? b : 0) * sq;
         double al = 0.0, be = 0.0, ga = 0.0;
-        for (int t = lane; t < q; t += 64) { const double x = wa[t], y = wb[t]; al += x * x; be += y * y; ga += x * y; }
-        al = wave_sum(al); be = wave_sum(be); ga = wave_sum(ga);
+        if (live)
+          for (int t = gl; t < q; t += 16) { const double x = wa[t], y = wb[t]; al += x * x; be += y * y; ga += x * y; }
+        al = row16_sum(al); be = row16_sum(be); ga = row16_sum(ga);
         const double prod = al * be;
-        if (!(prod > 0.0) || !(fabs(ga) > tol * sqrt(prod))) continue;
-        if (lane == 0) atomicAdd(&rot_count, 1);
+        if (!live || !(prod > 0.0) || !(fabs(ga) > tol * sqrt(prod))) continue;
+        if (gl == 0) atomicAdd(&rot_count, 1);
         const double zeta = (be - al) / (2.0 * ga);
         const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
         const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
-        for (int t = lane; t < q; t += 64) { const double x = wa[t], y = wb[t]; wa[t] = cs * x - sn * y; wb[t] = sn * x + cs * y; }
+        for (int t = gl; t < q; t += 16) { const double x = wa[t], y = wb[t]; wa[t] = cs * x - sn * y; wb[t] = sn * x + cs * y; }
         if (Q) {
           double* qa = Qs + a * sqc;
           double* qb = Qs + b * sqc;
-          for (int t = lane; t < qc; t += 64) { const double x = qa[t], y = qb[t]; qa[t] = cs * x - sn * y; qb[t] = sn * x + cs * y; }
+          for (int t = gl; t < qc; t += 16) { const double x = qa[t], y = qb[t]; qa[t] = cs * x - sn * y; qb[t] = sn * x + cs * y; }
         }
       }
       __syncthreads();

@@ -81,9 +81,9 @@ CCZ_API int ccz_memset0(ccz_handle h, void* dst_dev, size_t bytes);
 
 /* ---- K1: second moments ---------------------------------------------------
  * moments = [ G (D x D, ld = D) | colsum (D) ]  float64, D = sum cols, device.
- *   G      += [X_1..X_m]' [X_1..X_m]   (upper-triangular TILES only; finish with
- *                                        ccz_moments_symmetrize after the last
- *                                        shard / all-reduce)
+ *   G      += [X_1..X_m]' [X_1..X_m]   (upper-triangular TILES only; the solves read
+ *                                        the upper triangle, ccz_moments_symmetrize
+ *                                        completes G for other consumers)
  *   colsum += 1' [X_1..X_m]
  * One call handles one row shard; accumulate=0 zeroes `moments` first.  fp32
  * views are multiplied on the fp32 MFMA pipe in row chunks and accumulated in
@@ -100,7 +100,8 @@ CCZ_API int ccz_moments_symmetrize(ccz_handle h, double* moments_dev, int64_t D)
 CCZ_API int ccz_moments_last_ms(ccz_handle h, double* gram_ms, double* colsum_ms);
 
 /* ---- fused solves on reduced moments (replicated after the all-reduce) ----
- * Inputs: symmetrized moments (device), total rows n, per-view widths.
+ * Inputs: moments (device; only the upper triangle of G is read, so no symmetrisation is
+ * needed), total rows n, per-view widths.
  * Outputs (HOST, float64, row-major): weights packed view after view, each
  * (d_i x k_out); means (D) ; vals (k_out).
  */

@@ -113,7 +113,8 @@ void cov_block(ccz_ctx*, const double* G, int64_t D, const double* s, int64_t n,
                int64_t r0, int64_t rows, int64_t c0, int64_t cols, double* out, int64_t ldo) {
   for (int64_t i = 0; i < rows; ++i)
     for (int64_t j = 0; j < cols; ++j) {
-      double v = G[(r0 + i) * D + (c0 + j)];
+      const int64_t gr = r0 + i, gc = c0 + j;
+      double v = gr <= gc ? G[gr * D + gc] : G[gc * D + gr];   // upper triangle is authoritative
       if (centre) v -= s[r0 + i] * s[c0 + j] / double(n);
       out[i * ldo + j] = alpha * v;
     }
