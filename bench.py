@@ -140,9 +140,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    step_ms = []
     for _ in range(a.steps):
+        ts = time.perf_counter()
         step()
         gram_ms.append(h.moments_last_ms()[0])
+        step_ms.append((time.perf_counter() - ts) * 1e3)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -164,6 +167,7 @@ def main():
             "metric": "CCA fit()/sec at n=1e6 d=4096 k=64",
             "value": 1e3 / ms_per_step, "unit": "fit/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
+            "step_ms": [round(x, 2) for x in step_ms],
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic (JointData latent-variable model, generated in HBM)",
             "config": {"workload": f"CCA(latent_dimensions={a.k}).fit on JointData n={a.n}, 2 views x {a.d}, {a.dtype}; "

@@ -64,6 +64,26 @@ typedef const double __attribute__((address_space(1)))* gptr_f64;
 // exactly the zero padding the row tail needs.
 typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
 
+// blockIdx -> (tile, row chunk), XCD-aware.  The dispatcher is observed to place block b on XCD b % 8
+// (a speed hint only: any placement gives the same result).  Work items are (group of 32 neighbouring
+// tiles, row chunk); consecutive items go to consecutive XCDs, and the 32 workgroups an XCD runs at a
+// time are the 32 tiles of ONE item: a compact 4 x 8 block of tiles that touches 12 panels instead of
+// ~32, so the panels are shared through that XCD's 4 MiB L2 instead of being re-fetched over the fabric.
+constexpr int TGROUP = 32;
+struct WorkItem { int tile; int64_t chunk; bool valid; };
+__device__ __forceinline__ WorkItem locate_work(unsigned bid, int ntiles, int ngroups, int64_t nitems) {
+  const unsigned x = bid & 7u, m = bid >> 3;
+  const unsigned w = m & (TGROUP - 1), q = m / TGROUP;
+  const int64_t sidx = int64_t(q) * 8 + x;
+  WorkItem it;
+  it.valid = sidx < nitems;
+  const int g = int(sidx % ngroups);
+  it.chunk = sidx / ngroups;
+  it.tile = g * TGROUP + int(w);
+  it.valid = it.valid && it.tile < ntiles;
+  return it;
+}
+
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t panel_rsrc(const void* base, int64_t bytes) {
   const uint64_t p = reinterpret_cast<uint64_t>(base);
   const unsigned lo = __builtin_amdgcn_readfirstlane(unsigned(p));
@@ -97,14 +117,15 @@ __device__ __forceinline__ v4f32 load4_f32(gptr_f32 base, int64_t row, int64_t l
 }
 
 template <bool FAST>
-__global__ __launch_bounds__(256, 1) void k_gram_f32(const GramTile* __restrict__ tiles, int ntiles, int64_t n,
-                                                     int64_t rows_per_wg, double* __restrict__ G, int64_t ldg) {
+__global__ __launch_bounds__(256, 1) void k_gram_f32(const GramTile* __restrict__ tiles, int ntiles, int ngroups,
+                                                     int64_t nitems, int64_t n, int64_t rows_per_wg,
+                                                     double* __restrict__ G, int64_t ldg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* lds = reinterpret_cast<float*>(smem);  // [2 buffers][A | B][BK][256]
-  const int tile_id = int(blockIdx.x % unsigned(ntiles));
-  const int64_t ks = blockIdx.x / unsigned(ntiles);
-  const GramTile t = tiles[tile_id];
-  const int64_t k_begin = ks * rows_per_wg;
+  const WorkItem wi = locate_work(blockIdx.x, ntiles, ngroups, nitems);
+  if (!wi.valid) return;
+  const GramTile t = tiles[wi.tile];
+  const int64_t k_begin = wi.chunk * rows_per_wg;
   const int64_t k_end = min(n, k_begin + rows_per_wg);
   if (k_begin >= k_end) return;
   gptr_f32 A = (gptr_f32)(t.a);
@@ -245,13 +266,14 @@ constexpr int FR = 4;        // ring slots per wave
 constexpr int FSLAB = FB * 128 * 4;       // bytes of one slab (A or B) in a slot
 constexpr int FSLOT = 2 * FSLAB;          // bytes per slot: A slab + B slab
 
-__global__ __launch_bounds__(256, 1) void k_gram_f32_fifo(const GramTile* __restrict__ tiles, int ntiles, int64_t n,
-                                                          int64_t rows_per_wg, double* __restrict__ G, int64_t ldg) {
+__global__ __launch_bounds__(256, 1) void k_gram_f32_fifo(const GramTile* __restrict__ tiles, int ntiles, int ngroups,
+                                                          int64_t nitems, int64_t n, int64_t rows_per_wg,
+                                                          double* __restrict__ G, int64_t ldg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tile_id = int(blockIdx.x % unsigned(ntiles));
-  const int64_t ks_id = blockIdx.x / unsigned(ntiles);
-  const GramTile t = tiles[tile_id];
-  const int64_t k_begin = ks_id * rows_per_wg;
+  const WorkItem wi = locate_work(blockIdx.x, ntiles, ngroups, nitems);
+  if (!wi.valid) return;
+  const GramTile t = tiles[wi.tile];
+  const int64_t k_begin = wi.chunk * rows_per_wg;
   const int64_t k_end = min(n, k_begin + rows_per_wg);
   if (k_begin >= k_end) return;
   const int64_t nrows = k_end - k_begin;
@@ -378,14 +400,15 @@ __device__ __forceinline__ v2f64 load2_f64(gptr_f64 base, int64_t row, int64_t l
 }
 
 template <bool FAST>
-__global__ __launch_bounds__(256, 1) void k_gram_f64(const GramTile* __restrict__ tiles, int ntiles, int64_t n,
-                                                     int64_t rows_per_wg, double* __restrict__ G, int64_t ldg) {
+__global__ __launch_bounds__(256, 1) void k_gram_f64(const GramTile* __restrict__ tiles, int ntiles, int ngroups,
+                                                     int64_t nitems, int64_t n, int64_t rows_per_wg,
+                                                     double* __restrict__ G, int64_t ldg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* lds = reinterpret_cast<double*>(smem);  // [2 buffers][A | B][BK][128]
-  const int tile_id = int(blockIdx.x % unsigned(ntiles));
-  const int64_t ks = blockIdx.x / unsigned(ntiles);
-  const GramTile t = tiles[tile_id];
-  const int64_t k_begin = ks * rows_per_wg;
+  const WorkItem wi = locate_work(blockIdx.x, ntiles, ngroups, nitems);
+  if (!wi.valid) return;
+  const GramTile t = tiles[wi.tile];
+  const int64_t k_begin = wi.chunk * rows_per_wg;
   const int64_t k_end = min(n, k_begin + rows_per_wg);
   if (k_begin >= k_end) return;
   gptr_f64 A = (gptr_f64)(t.a);
@@ -544,8 +567,15 @@ void launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
   }
   std::vector<GramTile> tiles;
   const int np = int(panels.size());
-  for (int i = 0; i < np; ++i)
-    for (int j = i; j < np; ++j) {
+  // supertile order: 4 x 8 blocks of tiles, so that 32 consecutive tiles share 12 panels
+  std::vector<std::pair<int, int>> order;
+  for (int I = 0; I < np; I += 4)
+    for (int J = (I / 8) * 8; J < np; J += 8)
+      for (int i = I; i < std::min(np, I + 4); ++i)
+        for (int j = std::max(i, J); j < std::min(np, J + 8); ++j) order.emplace_back(i, j);
+  for (const auto& ij : order) {
+    const int i = ij.first, j = ij.second;
+    {
       const Panel& a = panels[i];
       const Panel& b = panels[j];
       GramTile t;
@@ -561,6 +591,7 @@ void launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
       t.pad_ = 0;
       tiles.push_back(t);
     }
+  }
   const int ntiles = int(tiles.size());
   GramTile* d_tiles = static_cast<GramTile*>(dev_alloc(c, tiles.size() * sizeof(GramTile)));
   h2d(c, d_tiles, tiles.data(), tiles.size() * sizeof(GramTile));
@@ -578,7 +609,9 @@ void launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
   rows_per_wg = std::max<int64_t>(256, std::min<int64_t>(max_rows, rows_per_wg));
   rows_per_wg = (rows_per_wg + BK - 1) / BK * BK;
   const int64_t ksplit = (n + rows_per_wg - 1) / rows_per_wg;
-  const int64_t nblocks = ksplit * ntiles;
+  const int ngroups = (ntiles + TGROUP - 1) / TGROUP;
+  const int64_t nitems = int64_t(ngroups) * ksplit;
+  const int64_t nblocks = (nitems + 7) / 8 * 8 * TGROUP;
   if (nblocks > 0x7fffffffLL) fail(CCZ_EUNSUP, "gram: grid too large");
   const size_t lds_bytes = size_t(2) * 2 * BK * tile * sizeof(T);  // 64 KiB either way
 
@@ -588,21 +621,21 @@ void launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
     if (fast && impl_sel != 0) {
       const size_t fifo_bytes = size_t(4) * FR * FSLOT;   // 128 KiB: four wave-private rings
       CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_f32_fifo), hipFuncAttributeMaxDynamicSharedMemorySize, int(fifo_bytes)));
-      hipLaunchKernelGGL(k_gram_f32_fifo, dim3((unsigned)nblocks), dim3(256), fifo_bytes, st, d_tiles, ntiles, n, rows_per_wg, G, D);
+      hipLaunchKernelGGL(k_gram_f32_fifo, dim3((unsigned)nblocks), dim3(256), fifo_bytes, st, d_tiles, ntiles, ngroups, nitems, n, rows_per_wg, G, D);
     } else if (fast) {
       CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_f32<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
-      hipLaunchKernelGGL(k_gram_f32<true>, dim3((unsigned)nblocks), dim3(256), lds_bytes, st, d_tiles, ntiles, n, rows_per_wg, G, D);
+      hipLaunchKernelGGL(k_gram_f32<true>, dim3((unsigned)nblocks), dim3(256), lds_bytes, st, d_tiles, ntiles, ngroups, nitems, n, rows_per_wg, G, D);
     } else {
       CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_f32<false>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
-      hipLaunchKernelGGL(k_gram_f32<false>, dim3((unsigned)nblocks), dim3(256), lds_bytes, st, d_tiles, ntiles, n, rows_per_wg, G, D);
+      hipLaunchKernelGGL(k_gram_f32<false>, dim3((unsigned)nblocks), dim3(256), lds_bytes, st, d_tiles, ntiles, ngroups, nitems, n, rows_per_wg, G, D);
     }
   } else {
     if (fast) {
       CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_f64<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
-      hipLaunchKernelGGL(k_gram_f64<true>, dim3((unsigned)nblocks), dim3(256), lds_bytes, st, d_tiles, ntiles, n, rows_per_wg, G, D);
+      hipLaunchKernelGGL(k_gram_f64<true>, dim3((unsigned)nblocks), dim3(256), lds_bytes, st, d_tiles, ntiles, ngroups, nitems, n, rows_per_wg, G, D);
     } else {
       CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_f64<false>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
-      hipLaunchKernelGGL(k_gram_f64<false>, dim3((unsigned)nblocks), dim3(256), lds_bytes, st, d_tiles, ntiles, n, rows_per_wg, G, D);
+      hipLaunchKernelGGL(k_gram_f64<false>, dim3((unsigned)nblocks), dim3(256), lds_bytes, st, d_tiles, ntiles, ngroups, nitems, n, rows_per_wg, G, D);
     }
   }
   CCZ_LAUNCH_CHECK();
