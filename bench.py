@@ -163,6 +163,16 @@ def main():
         g_ms = float(np.mean(gram_ms))
         achieved = flop / (g_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[a.dtype]
+        # HBM/fabric bytes per launch from the committed PMC pass (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
+        # profiles/r01_b_gram_pmc.md), measured at n=262144 on the same kernel/shape and linear in the rows
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_b_gram_traffic.json")) as f:
+                tj = json.load(f)
+            if a.dtype == "f32" and tj.get("D") == D:
+                traffic = tj["bytes_per_row"] * n_local
+        except Exception:
+            traffic = None
         out = {
             "metric": "CCA fit()/sec at n=1e6 d=4096 k=64",
             "value": 1e3 / ms_per_step, "unit": "fit/s",
@@ -174,7 +184,8 @@ def main():
                                    f"rows sharded over {world} GPU(s)", "n": a.n, "d": a.d, "k": a.k,
                        "device": info["name"], "arch": info["arch"], "compute_units": info["compute_units"]},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": None,
+                         "frac": achieved / peak, "traffic": traffic,
+                         "traffic_source": "profiles/r01_b_gram_pmc.md (PMC pass at n=262144, scaled by rows)" if traffic else None,
                          "kernel": "k_gram_f32_fifo" if a.dtype == "f32" else "k_gram_f64",
                          "kernel_ms": g_ms, "flop_per_launch": flop,
                          "bytes_per_launch": float(n_local) * D * (4 if a.dtype == "f32" else 8),
