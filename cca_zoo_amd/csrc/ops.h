@@ -73,6 +73,12 @@ class DBuf {
 void gemm(ccz_ctx* c, bool tA, bool tB, int64_t M, int64_t N, int64_t K, double alpha,
           const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C,
           int64_t ldc);
+// gemm with extras used by the blocked factorisations:
+//   C2 (optional, ldc2): second destination receiving the same values as C
+//   lower_only: skip 64x64 output tiles strictly above the diagonal (C square, symmetric update)
+void gemm_ex(ccz_ctx* c, bool tA, bool tB, int64_t M, int64_t N, int64_t K, double alpha,
+             const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C,
+             int64_t ldc, double* C2, int64_t ldc2, bool lower_only);
 // in-place lower Cholesky of the d x d leading block (upper part left untouched).
 // returns 0, or j+1 if pivot j was not positive (matrix content then undefined).
 int potrf_lower(ccz_ctx* c, double* A, int64_t d, int64_t lda);

@@ -108,18 +108,26 @@ constexpr int GK = 16;   // k-step
 constexpr int GP = 4;    // LDS row padding (elements)
 
 // C = alpha * (op(A) op(B) - bias) + beta * C ;  A, C are T ; B is TB (converted on load)
+// Extras: C2 = optional second destination; lower_only skips tiles strictly above the diagonal;
+// gridDim.z > 1 = split-K (each z-slice accumulates its K range into C with fp64/fp32 atomics; the
+// launcher has already applied beta to C).
 template <typename T, typename TBs, bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_kernel(int64_t M, int64_t N, int64_t K, T alpha,
                                                    const T* __restrict__ A, int64_t lda,
                                                    const TBs* __restrict__ B, int64_t ldb, T beta,
                                                    T* __restrict__ C, int64_t ldc,
-                                                   const double* __restrict__ bias) {
+                                                   const double* __restrict__ bias, T* __restrict__ C2,
+                                                   int64_t ldc2, int lower_only, int64_t k_per_split) {
   __shared__ T As[2][GK][GB + GP];
   __shared__ T Bs[2][GK][GB + GP];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int64_t m0 = int64_t(blockIdx.y) * GB, n0 = int64_t(blockIdx.x) * GB;
+  if (lower_only && n0 > m0 + (GB - 1)) return;
+  const int64_t kz0 = int64_t(blockIdx.z) * k_per_split;
+  const int64_t kz1 = min(K, kz0 + k_per_split);
+  const bool split = gridDim.z > 1;
 
   typename Mfma16<T>::acc_t acc[2][2];
 #pragma unroll
@@ -137,13 +145,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(int64_t M, int64_t N, int64_t
       if (TA) { m = tid & 63; k = (tid >> 6) + 4 * i; } else { k = tid & 15; m = (tid >> 4) + 16 * i; }
       const int64_t gm = m0 + m, gk = k0 + k;
       T v = T(0);
-      if (gm < M && gk < K) v = TA ? A[gk * lda + gm] : A[gm * lda + gk];
+      if (gm < M && gk < kz1) v = TA ? A[gk * lda + gm] : A[gm * lda + gk];
       ra[i] = v;
       int n, kb;
       if (TB) { kb = tid & 15; n = (tid >> 4) + 16 * i; } else { n = tid & 63; kb = (tid >> 6) + 4 * i; }
       const int64_t gn = n0 + n, gkb = k0 + kb;
       T w = T(0);
-      if (gn < N && gkb < K) w = T(TB ? B[gn * ldb + gkb] : B[gkb * ldb + gn]);
+      if (gn < N && gkb < kz1) w = T(TB ? B[gn * ldb + gkb] : B[gkb * ldb + gn]);
       rb[i] = w;
     }
   };
@@ -159,13 +167,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(int64_t M, int64_t N, int64_t
     }
   };
 
-  const int64_t nk = (K + GK - 1) / GK;
-  load_regs(0);
+  const int64_t nk = (kz1 - kz0 + GK - 1) / GK;
+  if (nk <= 0) return;
+  load_regs(kz0);
   store_regs(0);
   __syncthreads();
   for (int64_t kt = 0; kt < nk; ++kt) {
     const int cur = int(kt & 1);
-    if (kt + 1 < nk) load_regs((kt + 1) * GK);
+    if (kt + 1 < nk) load_regs(kz0 + (kt + 1) * GK);
 #pragma unroll
     for (int kk = 0; kk < GK / 4; ++kk) {
       const int kr = 4 * kk + (lane >> 4);
@@ -193,25 +202,57 @@ __global__ __launch_bounds__(256) void gemm_kernel(int64_t M, int64_t N, int64_t
         const int64_t gn = n0 + wc * 32 + j * 16 + (lane & 15);
         if (gm < M && gn < N) {
           T v = acc[i][j][r];
-          if (bias) v -= T(bias[gn]);
+          if (bias && blockIdx.z == 0) v -= T(bias[gn]);
           v *= alpha;
-          if (beta != T(0)) v += beta * C[gm * ldc + gn];
-          C[gm * ldc + gn] = v;
+          if (split) {
+            unsafeAtomicAdd(&C[gm * ldc + gn], v);
+          } else {
+            if (beta != T(0)) v += beta * C[gm * ldc + gn];
+            C[gm * ldc + gn] = v;
+            if (C2) C2[gm * ldc2 + gn] = v;
+          }
         }
       }
 }
 
+template <typename T>
+__global__ void k_scale2d(int64_t total, int64_t cols, T* __restrict__ A, int64_t lda, T beta) {
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += int64_t(gridDim.x) * blockDim.x) {
+    const int64_t r = i / cols, cc = i - r * cols;
+    A[r * lda + cc] = beta == T(0) ? T(0) : beta * A[r * lda + cc];
+  }
+}
+
 template <typename T, typename TBs>
 static void gemm_launch(ccz_ctx* c, bool tA, bool tB, int64_t M, int64_t N, int64_t K, T alpha, const T* A,
-                        int64_t lda, const TBs* B, int64_t ldb, T beta, T* C, int64_t ldc, const double* bias) {
+                        int64_t lda, const TBs* B, int64_t ldb, T beta, T* C, int64_t ldc, const double* bias,
+                        T* C2 = nullptr, int64_t ldc2 = 0, bool lower_only = false) {
   if (M <= 0 || N <= 0) return;
-  dim3 grid((unsigned)((N + GB - 1) / GB), (unsigned)((M + GB - 1) / GB));
-  if (grid.y > 65535) fail(CCZ_EUNSUP, "gemm: M=%lld too large for one launch", (long long)M);
+  const int64_t tm = (M + GB - 1) / GB, tn = (N + GB - 1) / GB;
+  if (tm > 65535) fail(CCZ_EUNSUP, "gemm: M=%lld too large for one launch", (long long)M);
   hipStream_t st = stream(c);
-  if (!tA && !tB) hipLaunchKernelGGL((gemm_kernel<T, TBs, false, false>), grid, dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias);
-  else if (tA && !tB) hipLaunchKernelGGL((gemm_kernel<T, TBs, true, false>), grid, dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias);
-  else if (!tA && tB) hipLaunchKernelGGL((gemm_kernel<T, TBs, false, true>), grid, dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias);
-  else hipLaunchKernelGGL((gemm_kernel<T, TBs, true, true>), grid, dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias);
+  // split-K when the output has too few tiles to fill the chip and K is deep (skinny products of the
+  // subspace iteration: 4096 x 80 outputs over K = 4096)
+  int splits = 1;
+  const int ncu = std::max(1, impl(c)->props.multiProcessorCount);
+  if (!C2 && !lower_only && tm * tn * 2 <= ncu && K >= 1024) {
+    splits = int(std::min<int64_t>({int64_t(32), (2 * ncu) / (tm * tn), K / 256}));
+    if (splits < 2) splits = 1;
+  }
+  int64_t kps = K;
+  if (splits > 1) {
+    kps = ((K + splits - 1) / splits + GK - 1) / GK * GK;
+    splits = int((K + kps - 1) / kps);
+    const int64_t total = M * N;
+    hipLaunchKernelGGL(k_scale2d<T>, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 1 << 20)), dim3(256), 0, st,
+                       total, N, C, ldc, beta);
+  }
+  dim3 grid((unsigned)tn, (unsigned)tm, (unsigned)splits);
+  const int lo = lower_only ? 1 : 0;
+  if (!tA && !tB) hipLaunchKernelGGL((gemm_kernel<T, TBs, false, false>), grid, dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, C2, ldc2, lo, kps);
+  else if (tA && !tB) hipLaunchKernelGGL((gemm_kernel<T, TBs, true, false>), grid, dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, C2, ldc2, lo, kps);
+  else if (!tA && tB) hipLaunchKernelGGL((gemm_kernel<T, TBs, false, true>), grid, dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, C2, ldc2, lo, kps);
+  else hipLaunchKernelGGL((gemm_kernel<T, TBs, true, true>), grid, dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, C2, ldc2, lo, kps);
   CCZ_LAUNCH_CHECK();
 }
 
@@ -224,6 +265,14 @@ void gemm(ccz_ctx* c, bool tA, bool tB, int64_t M, int64_t N, int64_t K, double 
     const double* Ap = tA ? A + m : A + m * lda;
     gemm_launch<double, double>(c, tA, tB, mm, N, K, alpha, Ap, lda, B, ldb, beta, C + m * ldc, ldc, nullptr);
   }
+}
+
+void gemm_ex(ccz_ctx* c, bool tA, bool tB, int64_t M, int64_t N, int64_t K, double alpha, const double* A,
+             int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, double* C2,
+             int64_t ldc2, bool lower_only) {
+  const int64_t maxM = int64_t(65535) * GB;
+  if (M > maxM) fail(CCZ_EUNSUP, "gemm_ex: M too large");
+  gemm_launch<double, double>(c, tA, tB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, nullptr, C2, ldc2, lower_only);
 }
 
 void gemm_mixed(ccz_ctx* c, int dtype, int64_t M, int64_t N, int64_t K, double alpha, const void* A, int64_t lda,
@@ -614,9 +663,10 @@ int potrf_lower(ccz_ctx* c, double* A, int64_t d, int64_t lda) {
     CCZ_LAUNCH_CHECK();
     if (rem > 0) {
       double* A21 = A + (j + nb) * lda + j;
-      gemm(c, false, false, rem, nb, nb, 1.0, A21, lda, invT, NB, 0.0, tmp, NB);          // L21 = A21 L11^-T
-      copy2d(c, rem, nb, tmp, NB, A21, lda);
-      gemm(c, false, true, rem, rem, nb, -1.0, tmp, NB, tmp, NB, 1.0, A + (j + nb) * lda + (j + nb), lda);
+      // L21 = A21 L11^-T, written to the scratch panel and (second destination) back in place; safe in place:
+      // a workgroup reads only its own 64 rows of A21 (all of K) before it writes them
+      gemm_ex(c, false, false, rem, nb, nb, 1.0, A21, lda, invT, NB, 0.0, tmp, NB, A21, lda, false);
+      gemm_ex(c, false, true, rem, rem, nb, -1.0, tmp, NB, tmp, NB, 1.0, A + (j + nb) * lda + (j + nb), lda, nullptr, 0, true);
     }
   }
   int info = 0;
@@ -635,8 +685,7 @@ void trsm_right_lower(ccz_ctx* c, bool trans, int64_t r, int64_t d, const double
     for (int64_t bj = 0; bj < nblk; ++bj) {
       const int64_t j = bj * NB;
       const int nb = int(std::min<int64_t>(NB, d - j));
-      gemm(c, false, false, r, nb, nb, 1.0, X + j, ldx, invT.get() + bj * NB * NB, NB, 0.0, tmp, NB);
-      copy2d(c, r, nb, tmp, NB, X + j, ldx);
+      gemm_ex(c, false, false, r, nb, nb, 1.0, X + j, ldx, invT.get() + bj * NB * NB, NB, 0.0, tmp, NB, X + j, ldx, false);
       const int64_t rem = d - j - nb;
       if (rem > 0)  // X[:, j+nb:] -= X_j  L[j+nb:, j]'
         gemm(c, false, true, r, rem, nb, -1.0, tmp, NB, L + (j + nb) * ldl + j, ldl, 1.0, X + j + nb, ldx);
@@ -646,8 +695,7 @@ void trsm_right_lower(ccz_ctx* c, bool trans, int64_t r, int64_t d, const double
     for (int64_t bj = nblk - 1; bj >= 0; --bj) {
       const int64_t j = bj * NB;
       const int nb = int(std::min<int64_t>(NB, d - j));
-      gemm(c, false, true, r, nb, nb, 1.0, X + j, ldx, invT.get() + bj * NB * NB, NB, 0.0, tmp, NB);
-      copy2d(c, r, nb, tmp, NB, X + j, ldx);
+      gemm_ex(c, false, true, r, nb, nb, 1.0, X + j, ldx, invT.get() + bj * NB * NB, NB, 0.0, tmp, NB, X + j, ldx, false);
       if (j > 0)  // X[:, :j] -= X_j L[j:j+nb, :j]
         gemm(c, false, false, r, j, nb, -1.0, tmp, NB, L + j * ldl, ldl, 1.0, X, ldx);
     }

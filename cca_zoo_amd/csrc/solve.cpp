@@ -227,12 +227,23 @@ void topk_symmetric(ccz_ctx* c, const SymOp& op, int k, std::vector<double>& the
   DBuf X(c, p * b), Y(c, p * b), Z(c, p * b);
   randn_fill(c, p, b, X, b, 0x9E3779B97F4A7C15ull);
   orthonormalize(c, p, b, X, b);
+  // warm start: two power steps on the shifted operator S - lower I (positive semi-definite, so the
+  // top of the spectrum dominates even for indefinite S); a random block has Ritz values that all sit
+  // at the spectral mean and would tell the first filter nothing about the gap
+  if (b < p) {
+    for (int it = 0; it < 2; ++it) {
+      op.apply(X, b, b, Y, b);
+      if (op.lower != 0.0) axpby2d(c, p, b, 1.0, Y, b, -op.lower, X, b);
+      d2d(c, X, Y, size_t(p) * b * 8);
+      orthonormalize(c, p, b, X, b);
+    }
+  }
   RitzState st;
   rayleigh_ritz(c, op, b, X, Y, Z, st);
   const double tol = 1e-11;
   const int max_cycles = 200;
-  int degree = 8;
   double prev_worst = 1e300;
+  int boost = 0;
   for (int cycle = 0; cycle < max_cycles; ++cycle) {
     const double scale = std::max({std::fabs(st.theta.front()), std::fabs(st.theta.back()), 1e-300});
     double worst = 0.0;
@@ -243,14 +254,23 @@ void topk_symmetric(ccz_ctx* c, const SymOp& op, int k, std::vector<double>& the
       return;
     }
     if (b == p) break;  // the block spans everything: Rayleigh-Ritz was already exact
-    // slow progress -> raise the filter degree
-    if (worst > 0.1 * prev_worst && degree < 40) degree += 4;
+    if (worst > 0.1 * prev_worst) boost += 4;   // slow progress -> raise the filter degree
     prev_worst = worst;
     double aL = st.theta.front();
     double cut = st.theta.back();
     double a = std::min(op.lower, cut - 1e-3 * std::max(aL - cut, 1e-12 * scale));
     if (!(aL > cut)) aL = cut + 1e-8 * scale;
     if (!(cut > a)) cut = a + 1e-8 * scale;
+    // degree from the gap: a degree-m filter damps the unwanted part relative to the k-th wanted
+    // value by ~ 1 / cosh(m acosh(x)), x = (theta_k - centre) / half-width of the damped interval
+    const double e = 0.5 * (cut - a), c0 = 0.5 * (cut + a);
+    const double x = (st.theta[k - 1] - c0) / e;
+    int degree = 30;
+    if (x > 1.0 + 1e-12) {
+      const double need = std::max(worst / (tol * scale), 2.0) * 10.0;
+      degree = int(std::ceil(std::acosh(need) / std::acosh(x)));
+    }
+    degree = std::min(40, std::max(2, degree) + boost);
     chebyshev_filter(c, op, b, degree, a, cut, aL, X, Y, Z);
     orthonormalize(c, p, b, X, b);
     rayleigh_ritz(c, op, b, X, Y, Z, st);

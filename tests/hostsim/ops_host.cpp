@@ -16,6 +16,8 @@
 
 namespace ccz {
 
+void copy2d(ccz_ctx*, int64_t rows, int64_t cols, const double* in, int64_t ldi, double* out, int64_t ldo);
+
 void* dev_alloc(ccz_ctx*, size_t bytes) {
   void* p = std::malloc(bytes ? bytes : 8);
   if (!p) fail(CCZ_ENOMEM, "malloc(%zu) failed", bytes);
@@ -40,6 +42,13 @@ void gemm(ccz_ctx*, bool tA, bool tB, int64_t M, int64_t N, int64_t K, double al
   for (int64_t i = 0; i < M; ++i)
     for (int64_t j = 0; j < N; ++j)
       C[i * ldc + j] = alpha * acc[i * N + j] + (beta == 0.0 ? 0.0 : beta * C[i * ldc + j]);
+}
+
+void gemm_ex(ccz_ctx* c, bool tA, bool tB, int64_t M, int64_t N, int64_t K, double alpha, const double* A,
+             int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, double* C2,
+             int64_t ldc2, bool) {
+  gemm(c, tA, tB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
+  if (C2) copy2d(c, M, N, C, ldc, C2, ldc2);
 }
 
 int potrf_lower(ccz_ctx*, double* A, int64_t d, int64_t lda) {
