@@ -56,14 +56,34 @@ static void cca_loss_impl(ccz_ctx* c, int dtype, const void* z1, const void* z2,
   if (potrf_lower(c, L1, d1, d1) != 0) fail(CCZ_ENOTSPD, "cca_loss: S11 + eps I is not positive definite");
   if (potrf_lower(c, L2, d2, d2) != 0) fail(CCZ_ENOTSPD, "cca_loss: S22 + eps I is not positive definite");
 
-  DBuf A(c, d1 * d2), Bm(c, d2 * d1), Bmt(c, d1 * d2);
-  d2d(c, A, S12, size_t(d1) * d2 * 8);
-  chol_solve_inplace(c, d1, d2, L1, d1, A, d2);              // A  = S11^-1 S12
-  transpose(c, d1, d2, S12, d2, Bm, d1);
-  chol_solve_inplace(c, d2, d1, L2, d2, Bm, d1);             // Bm = S22^-1 S21
-  transpose(c, d2, d1, Bm, d1, Bmt, d2);
+  // Explicit triangular inverses Li = L^-1 (one blocked TRSM on the identity per factor): every
+  // S^-1 product below is then two MFMA GEMMs instead of two blocked triangular solves -- the loss is
+  // launch-latency bound at DCCA batch shapes (d ~ 512), and S + eps I keeps this well conditioned in fp64.
+  auto tri_inverse = [&](const double* L, int64_t d) {
+    DBuf Li(c, d * d);
+    fill2d(c, d, d, Li, d, 0.0);
+    add_diag(c, d, Li, d, 1.0);
+    trsm_right_lower(c, false, d, d, L, d, Li, d);            // I L^-1
+    return Li;
+  };
+  DBuf Li1 = tri_inverse(L1, d1), Li2 = tri_inverse(L2, d2);
+  // left  solve: S^-1 M = Li' (Li M)      right solve: M S^-1 = (M Li') Li
+  auto solve_left = [&](const double* Li, int64_t d, bool transM, const double* M, int64_t ldm, int64_t r, double alpha, double* out) {
+    DBuf t(c, d * r);
+    gemm(c, false, transM, d, r, d, 1.0, Li, d, M, ldm, 0.0, t, r);
+    gemm(c, true, false, d, r, d, alpha, Li, d, t, r, 0.0, out, r);
+  };
+  auto solve_right = [&](const double* Li, int64_t d, const double* M, int64_t ldm, int64_t r, double alpha, double* out) {
+    DBuf t(c, r * d);
+    gemm(c, false, true, r, d, d, 1.0, M, ldm, Li, d, 0.0, t, d);
+    gemm(c, false, false, r, d, d, alpha, t, d, Li, d, 0.0, out, d);
+  };
+
+  DBuf A(c, d1 * d2), Bmt(c, d1 * d2);
+  solve_left(Li1, d1, false, S12, d2, d2, 1.0, A);            // A   = S11^-1 S12           (d1 x d2)
+  solve_right(Li2, d2, S12, d2, d1, 1.0, Bmt);                // Bm' = S12 S22^-1           (d1 x d2)
   DBuf rd(c, d1);
-  row_dots(c, d1, d2, A, d2, Bmt, d2, rd);
+  row_dots(c, d1, d2, A, d2, Bmt, d2, rd);                    // tr(A Bm) = sum A o Bm'
   std::vector<double> rh(d1);
   d2h(c, rh.data(), rd, size_t(d1) * 8);
   double loss = 0.0;
@@ -72,46 +92,35 @@ static void cca_loss_impl(ccz_ctx* c, int dtype, const void* z1, const void* z2,
   else h2d(c, loss_dev, &loss, 8);
   if (!g1 && !g2) return;
 
-  // G12' = -2 S22^-1 A'   (d2 x d1)
-  DBuf G12t(c, d2 * d1), G12(c, d1 * d2);
-  transpose(c, d1, d2, A, d2, G12t, d1);
-  chol_solve_inplace(c, d2, d1, L2, d2, G12t, d1);
-  axpby2d(c, d2, d1, -2.0, G12t, d1, 0.0, nullptr, 0);
-  transpose(c, d2, d1, G12t, d1, G12, d2);
+  // G12 = -2 S11^-1 S12 S22^-1 = -2 A S22^-1 (d1 x d2) and its transpose
+  DBuf G12(c, d1 * d2), G12t(c, d2 * d1);
+  solve_right(Li2, d2, A, d2, d1, -2.0, G12);
+  transpose(c, d1, d2, G12, d2, G12t, d1);
   // mean row vector
   DBuf mu(c, D);
   d2d(c, mu, s, size_t(D) * 8);
   axpby2d(c, 1, D, 1.0 / double(n), mu, D, 0.0, nullptr, 0);
 
-  auto sym_grad = [&](int64_t da, const double* P /*da x da*/, const double* L, DBuf& out) {
-    // out = P S^-1 + (P S^-1)'  with S = L L'
-    DBuf Pt(c, da * da);
-    transpose(c, da, da, P, da, Pt, da);
-    chol_solve_inplace(c, da, da, L, da, Pt, da);           // S^-1 P' = (P S^-1)'
-    out = DBuf(c, da * da);
-    transpose(c, da, da, Pt, da, out, da);
-    axpby2d(c, da, da, 1.0, out, da, 1.0, Pt, da);
-  };
   if (g1) {
-    DBuf P(c, d1 * d1), G11s, bias(c, d1);
-    gemm(c, false, false, d1, d1, d2, 1.0, A, d2, Bm, d1, 0.0, P, d1);
-    sym_grad(d1, P, L1, G11s);
+    // G11 = A Bm S11^-1 = S11^-1 (S12 S22^-1 S21) S11^-1 is symmetric, so G11 + G11' = 2 G11
+    DBuf P(c, d1 * d1), G11s(c, d1 * d1), bias(c, d1);
+    gemm(c, false, true, d1, d1, d2, 1.0, A, d2, Bmt, d2, 0.0, P, d1);          // A Bm
+    solve_right(Li1, d1, P, d1, d1, 2.0, G11s);
     gemm(c, false, false, 1, d1, d1, 1.0, mu, D, G11s, d1, 0.0, bias, d1);
     gemm(c, false, false, 1, d1, d2, 1.0, mu.get() + d1, D, G12t, d1, 1.0, bias, d1);
     gemm_mixed(c, dtype, n, d1, d1, inv, z1, ld1, G11s, d1, 0.0, g1, ldg1, bias);
     gemm_mixed(c, dtype, n, d1, d2, inv, z2, ld2, G12t, d1, 1.0, g1, ldg1, nullptr);
-    sync(c);   // G11s / bias are pooled scratch: finish before they are recycled
   }
   if (g2) {
-    DBuf P(c, d2 * d2), G22s, bias(c, d2);
-    gemm(c, false, false, d2, d2, d1, 1.0, Bm, d1, A, d2, 0.0, P, d2);
-    sym_grad(d2, P, L2, G22s);
+    DBuf P(c, d2 * d2), G22s(c, d2 * d2), bias(c, d2);
+    gemm(c, true, false, d2, d2, d1, 1.0, Bmt, d2, A, d2, 0.0, P, d2);          // Bm A
+    solve_right(Li2, d2, P, d2, d2, 2.0, G22s);
     gemm(c, false, false, 1, d2, d2, 1.0, mu.get() + d1, D, G22s, d2, 0.0, bias, d2);
     gemm(c, false, false, 1, d2, d1, 1.0, mu, D, G12, d2, 1.0, bias, d2);
     gemm_mixed(c, dtype, n, d2, d2, inv, z2, ld2, G22s, d2, 0.0, g2, ldg2, bias);
     gemm_mixed(c, dtype, n, d2, d1, inv, z1, ld1, G12, d2, 1.0, g2, ldg2, nullptr);
-    sync(c);
   }
+  sync(c);
 }
 
 // out = (X - mean) W     reference: cca_zoo/_base.py:108-123

@@ -72,6 +72,14 @@ typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
 constexpr int TGROUP = 32;
 struct WorkItem { int tile; int64_t chunk; bool valid; };
 __device__ __forceinline__ WorkItem locate_work(unsigned bid, int ntiles, int ngroups, int64_t nitems) {
+  if (ngroups == 0) {   // small grid: plain chunk-major order, one workgroup per CU matters more than L2 sharing
+    WorkItem it;
+    it.tile = int(bid % unsigned(ntiles));
+    it.chunk = bid / unsigned(ntiles);
+    it.valid = int64_t(bid) < nitems;
+    return it;
+  }
+  const int gsize = (ntiles + ngroups - 1) / ngroups;   // equal-sized groups (<= TGROUP): balanced XCDs
   const unsigned x = bid & 7u, m = bid >> 3;
   const unsigned w = m & (TGROUP - 1), q = m / TGROUP;
   const int64_t sidx = int64_t(q) * 8 + x;
@@ -79,8 +87,8 @@ __device__ __forceinline__ WorkItem locate_work(unsigned bid, int ntiles, int ng
   it.valid = sidx < nitems;
   const int g = int(sidx % ngroups);
   it.chunk = sidx / ngroups;
-  it.tile = g * TGROUP + int(w);
-  it.valid = it.valid && it.tile < ntiles;
+  it.tile = g * gsize + int(w);
+  it.valid = it.valid && int(w) < gsize && it.tile < ntiles;
   return it;
 }
 
@@ -605,13 +613,29 @@ void launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
       cap = std::min<int64_t>(cap, ((int64_t(1) << 31) - 1) / (views[v].ld * int64_t(sizeof(T))) - 128);
     if (cap < 256) fast = false; else max_rows = cap;
   }
-  int64_t rows_per_wg = (n * ntiles + int64_t(ncu) * 8 - 1) / (int64_t(ncu) * 8);
-  rows_per_wg = std::max<int64_t>(256, std::min<int64_t>(max_rows, rows_per_wg));
-  rows_per_wg = (rows_per_wg + BK - 1) / BK * BK;
+  // Row-chunk length: minimise (rounds of workgroups over the CUs) x (rows per workgroup + fixed cost).
+  // Every workgroup pays ~45 us to flush its tile (~210 rows of MFMA time) plus the pipeline prologue,
+  // and a grid that overshoots a multiple of the CU count by a few workgroups wastes a whole round.
+  int64_t rows_per_wg;
+  {
+    const int64_t kmin = std::max<int64_t>(1, (n + max_rows - 1) / max_rows);
+    const int64_t kmax = std::max<int64_t>(kmin, std::min<int64_t>(n / 256, 8192));
+    double best = 1e300;
+    int64_t best_k = kmin;
+    for (int64_t ks = kmin; ks <= kmax; ++ks) {
+      const int64_t rows = ((n + ks - 1) / ks + BK - 1) / BK * BK;
+      const int64_t rounds = (int64_t(ntiles) * ks + ncu - 1) / ncu;
+      const double cost = double(rounds) * double(rows + 320);
+      if (cost < best) { best = cost; best_k = ks; }
+    }
+    rows_per_wg = ((n + best_k - 1) / best_k + BK - 1) / BK * BK;
+  }
   const int64_t ksplit = (n + rows_per_wg - 1) / rows_per_wg;
-  const int ngroups = (ntiles + TGROUP - 1) / TGROUP;
-  const int64_t nitems = int64_t(ngroups) * ksplit;
-  const int64_t nblocks = (nitems + 7) / 8 * 8 * TGROUP;
+  // XCD-aware grouping needs many items per XCD to stay balanced; small grids keep the plain order
+  const bool grouped = int64_t(ntiles) * ksplit >= 16 * int64_t(ncu);
+  const int ngroups = grouped ? (ntiles + TGROUP - 1) / TGROUP : 0;
+  const int64_t nitems = grouped ? int64_t(ngroups) * ksplit : int64_t(ntiles) * ksplit;
+  const int64_t nblocks = grouped ? (nitems + 7) / 8 * 8 * TGROUP : nitems;
   if (nblocks > 0x7fffffffLL) fail(CCZ_EUNSUP, "gram: grid too large");
   const size_t lds_bytes = size_t(2) * 2 * BK * tile * sizeof(T);  // 64 KiB either way
 
@@ -645,8 +669,11 @@ void launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
   }
   int64_t off = 0;
   for (int v = 0; v < n_views; ++v) {
-    const int64_t rpb = 2048;
-    dim3 grid((unsigned)((views[v].cols + 255) / 256), (unsigned)((n + rpb - 1) / rpb));
+    // enough row blocks to cover the chip even for narrow / short views
+    const int64_t colblocks = (views[v].cols + 255) / 256;
+    int64_t rpb = 2048;
+    while (rpb > 64 && colblocks * ((n + rpb - 1) / rpb) < 4 * int64_t(ncu)) rpb /= 2;
+    dim3 grid((unsigned)colblocks, (unsigned)((n + rpb - 1) / rpb));
     hipLaunchKernelGGL(k_colsum<T>, grid, dim3(256), 0, st, static_cast<const T*>(views[v].data), n, views[v].cols,
                        views[v].ld, s + off, rpb);
     off += views[v].cols;

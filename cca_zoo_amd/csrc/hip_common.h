@@ -46,4 +46,10 @@ void gemm_mixed(ccz_ctx* c, int dtype, int64_t M, int64_t N, int64_t K, double a
                 int64_t lda, const double* B, int64_t ldb, double beta, void* C, int64_t ldc,
                 const double* bias_row /* N, subtracted before alpha; may be null */);
 
+// gemm_big.hip: 256x256-tile fp32 GEMM for sample-side products (loss backward, wide transforms)
+bool gemm_f32_big_eligible(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, const void* A,
+                           const void* C);
+void gemm_f32_big(ccz_ctx* c, int64_t M, int64_t N, int64_t K, double alpha, const float* A, int64_t lda,
+                  const double* B, int64_t ldb, double beta, float* C, int64_t ldc, const double* bias_row);
+
 }  // namespace ccz

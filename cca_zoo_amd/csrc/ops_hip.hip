@@ -277,6 +277,10 @@ void gemm_ex(ccz_ctx* c, bool tA, bool tB, int64_t M, int64_t N, int64_t K, doub
 
 void gemm_mixed(ccz_ctx* c, int dtype, int64_t M, int64_t N, int64_t K, double alpha, const void* A, int64_t lda,
                 const double* B, int64_t ldb, double beta, void* C, int64_t ldc, const double* bias_row) {
+  if (dtype == CCZ_F32 && gemm_f32_big_eligible(M, N, K, lda, ldb, ldc, A, C)) {
+    gemm_f32_big(c, M, N, K, alpha, static_cast<const float*>(A), lda, B, ldb, beta, static_cast<float*>(C), ldc, bias_row);
+    return;
+  }
   const int64_t maxM = int64_t(65535) * GB;
   for (int64_t m = 0; m < M; m += maxM) {
     const int64_t mm = std::min(maxM, M - m);

@@ -206,3 +206,45 @@ def test_config2_shape_reduced_rows_fp32_bar():
     for u, r in zip(model.weights_, W):
         assert u.dtype == np.float32
         assert col_rel_err(u, r) < TOL32
+
+
+def test_config2_full_size_properties():
+    """BASELINE configs[1] at FULL size (rCCA n=100k, 2 x 1024, k=32, float32): size-independent
+    properties instead of an O(n d^2) oracle -- normalisation w'R w = 1, uncorrelated variates,
+    training score == singular values for c=0, shard additivity of the moments, CCA == MCCA scores."""
+    import torch
+
+    from cca_zoo_amd import _backend
+    from cca_zoo_amd._moments import compute_moments
+    from cca_zoo_amd.datasets import JointData
+    from cca_zoo_amd.linear import CCA, MCCA, rCCA
+
+    n, d, k = 100_000, 1024, 32
+    jd = JointData(n_views=2, n_samples=n, n_features=[d, d], latent_dimensions=k, random_state=3,
+                   latent_scales=list(np.linspace(2.0, 0.5, k)))
+    views = jd.sample_device(device="cuda", dtype=torch.float32, n_samples=n, seed=3)
+    h = _backend.default_handle(0)
+    # shard additivity (the multi-GPU identity): moments(all rows) == moments(shard A) + moments(shard B)
+    mom, keep, nt, dims, kind = compute_moments(views, h)
+    full = h.to_host(mom, (2 * d * 2 * d + 2 * d,))
+    ma, ka, _, _, _ = compute_moments([v[:37_001] for v in views], h)
+    mb, kb, _, _, _ = compute_moments([v[37_001:] for v in views], h)
+    parts = h.to_host(ma, full.shape) + h.to_host(mb, full.shape)
+    scale = np.abs(full).max()
+    assert np.max(np.abs(parts - full)) < 2e-6 * scale
+    # rCCA(c=0.1): every weight column satisfies w' ((1-c) C_ii + c I) w = 1
+    m = rCCA(latent_dimensions=k, c=0.1).fit(views)
+    assert m.weights_[0].dtype == np.float32 and m.weights_[0].shape == (d, k)
+    X = views[0].double()
+    C11 = torch.cov(X.T).cpu().numpy()
+    W1 = m.weights_[0].astype(np.float64)
+    np.testing.assert_allclose(np.diag(W1.T @ (0.9 * C11 + 0.1 * np.eye(d)) @ W1), 1.0, atol=2e-3)
+    # CCA: variates uncorrelated within a view, unit variance, train score == singular values, MCCA agrees
+    cca = CCA(latent_dimensions=k).fit(views)
+    z1, z2 = cca.transform(views)
+    c = torch.cov(z1.double().T).cpu().numpy()
+    np.testing.assert_allclose(c, np.eye(k), atol=2e-3)
+    sc = cca.score(views)
+    np.testing.assert_allclose(sc, cca.singular_values_, atol=1e-3)
+    assert np.all(np.diff(sc) <= 1e-6) and sc[0] > 0.9
+    np.testing.assert_allclose(MCCA(latent_dimensions=k).fit(views).score(views), sc, atol=1e-3)
