@@ -66,6 +66,8 @@ SIGNATURES = {
     "ccz_memset0": (_int, [_vp, _vp, C.c_size_t]),
     "ccz_moments": (_int, [_vp, _int, C.POINTER(View), _int, _i64, _int, _vp, _int]),
     "ccz_moments_symmetrize": (_int, [_vp, _vp, _i64]),
+    "ccz_moments_pack": (_int, [_vp, _vp, _i64, _vp]),
+    "ccz_moments_unpack": (_int, [_vp, _vp, _i64, _vp]),
     "ccz_moments_last_ms": (_int, [_vp, _pdbl, _pdbl]),
     "ccz_rcca_solve": (_int, [_vp, _vp, _i64, _pi64, _pdbl, _int, _int, _vp, _vp, _vp, _pint]),
     "ccz_mcca_solve": (_int, [_vp, _vp, _i64, _pi64, _int, _pdbl, _dbl, _int, _int, _vp, _vp, _vp, _pint]),
@@ -230,6 +232,12 @@ class Handle:
 
     def moments_symmetrize(self, moments_ptr, D):
         self.check(self.lib.ccz_moments_symmetrize(self._h, _ptr(moments_ptr), int(D)))
+
+    def moments_pack(self, moments_ptr, D, packed_ptr):
+        self.check(self.lib.ccz_moments_pack(self._h, _ptr(moments_ptr), int(D), _ptr(packed_ptr)))
+
+    def moments_unpack(self, packed_ptr, D, moments_ptr):
+        self.check(self.lib.ccz_moments_unpack(self._h, _ptr(packed_ptr), int(D), _ptr(moments_ptr)))
 
     def moments_last_ms(self):
         g, s = C.c_double(), C.c_double()

@@ -69,7 +69,15 @@ def compute_moments(views, handle=None):
     h.moments(descr, n, _backend.F32 if kind == "f32" else _backend.F64, on_device, mom_ptr, accumulate=False)
     n_total = n
     if sharded:
+        # the one collective of the path: packed upper triangle + column sums + row count
+        import torch
+
+        packed = torch.empty(D * (D + 1) // 2 + D, dtype=torch.float64, device=mom_t.device)
+        h.moments_pack(mom_ptr, D, packed.data_ptr())
         h.sync()
-        n_total = _dist.allreduce_moments(mom_t, n, _dist.active_group())
+        n_total = _dist.allreduce_moments(packed, n, _dist.active_group())
+        torch.cuda.current_stream(mom_t.device).synchronize()
+        h.moments_unpack(packed.data_ptr(), D, mom_ptr)
+        keep.append(packed)
     # no symmetrisation pass: the solvers read the upper triangle (authoritative) on both sides
     return mom_ptr, keep, n_total, dims, kind

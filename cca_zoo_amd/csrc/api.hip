@@ -53,8 +53,14 @@ static void cca_loss_impl(ccz_ctx* c, int dtype, const void* z1, const void* z2,
   cov_block(c, G, D, s, n, true, inv, d1, d2, d1, d2, L2, d2);
   add_diag(c, d2, L2, d2, eps);
   cov_block(c, G, D, s, n, true, inv, 0, d1, d1, d2, S12, d2);
-  if (potrf_lower(c, L1, d1, d1) != 0) fail(CCZ_ENOTSPD, "cca_loss: S11 + eps I is not positive definite");
-  if (potrf_lower(c, L2, d2, d2) != 0) fail(CCZ_ENOTSPD, "cca_loss: S22 + eps I is not positive definite");
+  {
+    double* Lp[2] = {L1.get(), L2.get()};
+    const int64_t dd[2] = {d1, d2};
+    int info[2] = {0, 0};
+    potrf_lower_batched(c, 2, Lp, dd, dd, info);
+    if (info[0] != 0) fail(CCZ_ENOTSPD, "cca_loss: S11 + eps I is not positive definite");
+    if (info[1] != 0) fail(CCZ_ENOTSPD, "cca_loss: S22 + eps I is not positive definite");
+  }
 
   // Explicit triangular inverses Li = L^-1 (one blocked TRSM on the identity per factor): every
   // S^-1 product below is then two MFMA GEMMs instead of two blocked triangular solves -- the loss is
@@ -239,6 +245,22 @@ int ccz_moments_symmetrize(ccz_handle h, double* moments_dev, int64_t D) {
   CCZ_GUARD(h, {
     if (!moments_dev || D < 1) fail(CCZ_EINVAL, "bad argument");
     mirror_upper(h, D, moments_dev, D);
+  })
+}
+
+int ccz_moments_pack(ccz_handle h, const double* moments_dev, int64_t D, double* packed_dev) {
+  CCZ_GUARD(h, {
+    if (!moments_dev || !packed_dev || D < 1) fail(CCZ_EINVAL, "bad argument");
+    pack_upper(h, D, moments_dev, D, packed_dev);
+    d2d(h, packed_dev + D * (D + 1) / 2, moments_dev + D * D, size_t(D) * 8);
+  })
+}
+
+int ccz_moments_unpack(ccz_handle h, const double* packed_dev, int64_t D, double* moments_dev) {
+  CCZ_GUARD(h, {
+    if (!moments_dev || !packed_dev || D < 1) fail(CCZ_EINVAL, "bad argument");
+    unpack_upper(h, D, packed_dev, moments_dev, D);
+    d2d(h, moments_dev + D * D, packed_dev + D * (D + 1) / 2, size_t(D) * 8);
   })
 }
 

@@ -65,30 +65,24 @@ typedef const double __attribute__((address_space(1)))* gptr_f64;
 typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
 
 // blockIdx -> (tile, row chunk), XCD-aware.  The dispatcher is observed to place block b on XCD b % 8
-// (a speed hint only: any placement gives the same result).  Work items are (group of 32 neighbouring
-// tiles, row chunk); consecutive items go to consecutive XCDs, and the 32 workgroups an XCD runs at a
-// time are the 32 tiles of ONE item: a compact 4 x 8 block of tiles that touches 12 panels instead of
-// ~32, so the panels are shared through that XCD's 4 MiB L2 instead of being re-fetched over the fabric.
-constexpr int TGROUP = 32;
+// (a speed hint only: any placement gives the same result).  The tile list is in supertile order
+// (4 x 8 blocks of tiles); XCD x owns the contiguous slice [x * per_xcd, (x+1) * per_xcd) of it and walks
+// that slice chunk after chunk, so the ~32 workgroups an XCD runs at any time are neighbouring tiles that
+// share panels through that XCD's 4 MiB L2, while all XCDs stream the same row chunk (Infinity Cache).
+// per_xcd == 0 selects the plain chunk-major order (small grids: one workgroup per CU matters more).
 struct WorkItem { int tile; int64_t chunk; bool valid; };
-__device__ __forceinline__ WorkItem locate_work(unsigned bid, int ntiles, int ngroups, int64_t nitems) {
-  if (ngroups == 0) {   // small grid: plain chunk-major order, one workgroup per CU matters more than L2 sharing
-    WorkItem it;
+__device__ __forceinline__ WorkItem locate_work(unsigned bid, int ntiles, int per_xcd, int64_t ksplit) {
+  WorkItem it;
+  if (per_xcd == 0) {
     it.tile = int(bid % unsigned(ntiles));
     it.chunk = bid / unsigned(ntiles);
-    it.valid = int64_t(bid) < nitems;
+    it.valid = it.chunk < ksplit;
     return it;
   }
-  const int gsize = (ntiles + ngroups - 1) / ngroups;   // equal-sized groups (<= TGROUP): balanced XCDs
   const unsigned x = bid & 7u, m = bid >> 3;
-  const unsigned w = m & (TGROUP - 1), q = m / TGROUP;
-  const int64_t sidx = int64_t(q) * 8 + x;
-  WorkItem it;
-  it.valid = sidx < nitems;
-  const int g = int(sidx % ngroups);
-  it.chunk = sidx / ngroups;
-  it.tile = g * gsize + int(w);
-  it.valid = it.valid && int(w) < gsize && it.tile < ntiles;
+  it.chunk = m / unsigned(per_xcd);
+  it.tile = int(x) * per_xcd + int(m % unsigned(per_xcd));
+  it.valid = it.chunk < ksplit && it.tile < ntiles;
   return it;
 }
 
@@ -125,12 +119,12 @@ __device__ __forceinline__ v4f32 load4_f32(gptr_f32 base, int64_t row, int64_t l
 }
 
 template <bool FAST>
-__global__ __launch_bounds__(256, 1) void k_gram_f32(const GramTile* __restrict__ tiles, int ntiles, int ngroups,
-                                                     int64_t nitems, int64_t n, int64_t rows_per_wg,
+__global__ __launch_bounds__(256, 1) void k_gram_f32(const GramTile* __restrict__ tiles, int ntiles, int per_xcd,
+                                                     int64_t ksplit, int64_t n, int64_t rows_per_wg,
                                                      double* __restrict__ G, int64_t ldg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* lds = reinterpret_cast<float*>(smem);  // [2 buffers][A | B][BK][256]
-  const WorkItem wi = locate_work(blockIdx.x, ntiles, ngroups, nitems);
+  const WorkItem wi = locate_work(blockIdx.x, ntiles, per_xcd, ksplit);
   if (!wi.valid) return;
   const GramTile t = tiles[wi.tile];
   const int64_t k_begin = wi.chunk * rows_per_wg;
@@ -274,11 +268,11 @@ constexpr int FR = 4;        // ring slots per wave
 constexpr int FSLAB = FB * 128 * 4;       // bytes of one slab (A or B) in a slot
 constexpr int FSLOT = 2 * FSLAB;          // bytes per slot: A slab + B slab
 
-__global__ __launch_bounds__(256, 1) void k_gram_f32_fifo(const GramTile* __restrict__ tiles, int ntiles, int ngroups,
-                                                          int64_t nitems, int64_t n, int64_t rows_per_wg,
+__global__ __launch_bounds__(256, 1) void k_gram_f32_fifo(const GramTile* __restrict__ tiles, int ntiles, int per_xcd,
+                                                          int64_t ksplit, int64_t n, int64_t rows_per_wg,
                                                           double* __restrict__ G, int64_t ldg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const WorkItem wi = locate_work(blockIdx.x, ntiles, ngroups, nitems);
+  const WorkItem wi = locate_work(blockIdx.x, ntiles, per_xcd, ksplit);
   if (!wi.valid) return;
   const GramTile t = tiles[wi.tile];
   const int64_t k_begin = wi.chunk * rows_per_wg;
@@ -408,12 +402,12 @@ __device__ __forceinline__ v2f64 load2_f64(gptr_f64 base, int64_t row, int64_t l
 }
 
 template <bool FAST>
-__global__ __launch_bounds__(256, 1) void k_gram_f64(const GramTile* __restrict__ tiles, int ntiles, int ngroups,
-                                                     int64_t nitems, int64_t n, int64_t rows_per_wg,
+__global__ __launch_bounds__(256, 1) void k_gram_f64(const GramTile* __restrict__ tiles, int ntiles, int per_xcd,
+                                                     int64_t ksplit, int64_t n, int64_t rows_per_wg,
                                                      double* __restrict__ G, int64_t ldg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* lds = reinterpret_cast<double*>(smem);  // [2 buffers][A | B][BK][128]
-  const WorkItem wi = locate_work(blockIdx.x, ntiles, ngroups, nitems);
+  const WorkItem wi = locate_work(blockIdx.x, ntiles, per_xcd, ksplit);
   if (!wi.valid) return;
   const GramTile t = tiles[wi.tile];
   const int64_t k_begin = wi.chunk * rows_per_wg;
@@ -624,18 +618,19 @@ void launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
     int64_t best_k = kmin;
     for (int64_t ks = kmin; ks <= kmax; ++ks) {
       const int64_t rows = ((n + ks - 1) / ks + BK - 1) / BK * BK;
-      const int64_t rounds = (int64_t(ntiles) * ks + ncu - 1) / ncu;
+      const int64_t rounds = int64_t(ntiles) * ks >= 16 * int64_t(ncu)
+                                 ? (int64_t((ntiles + 7) / 8) * ks + ncu / 8 - 1) / (ncu / 8)   // per-XCD slice
+                                 : (int64_t(ntiles) * ks + ncu - 1) / ncu;
       const double cost = double(rounds) * double(rows + 320);
       if (cost < best) { best = cost; best_k = ks; }
     }
     rows_per_wg = ((n + best_k - 1) / best_k + BK - 1) / BK * BK;
   }
   const int64_t ksplit = (n + rows_per_wg - 1) / rows_per_wg;
-  // XCD-aware grouping needs many items per XCD to stay balanced; small grids keep the plain order
-  const bool grouped = int64_t(ntiles) * ksplit >= 16 * int64_t(ncu);
-  const int ngroups = grouped ? (ntiles + TGROUP - 1) / TGROUP : 0;
-  const int64_t nitems = grouped ? int64_t(ngroups) * ksplit : int64_t(ntiles) * ksplit;
-  const int64_t nblocks = grouped ? (nitems + 7) / 8 * 8 * TGROUP : nitems;
+  // XCD-aware slicing needs many workgroups per XCD to stay balanced; small grids keep the plain order
+  const bool sliced = int64_t(ntiles) * ksplit >= 16 * int64_t(ncu);
+  const int per_xcd = sliced ? (ntiles + 7) / 8 : 0;
+  const int64_t nblocks = sliced ? int64_t(8) * per_xcd * ksplit : int64_t(ntiles) * ksplit;
   if (nblocks > 0x7fffffffLL) fail(CCZ_EUNSUP, "gram: grid too large");
   const size_t lds_bytes = size_t(2) * 2 * BK * tile * sizeof(T);  // 64 KiB either way
 
@@ -645,21 +640,21 @@ void launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
     if (fast && impl_sel != 0) {
       const size_t fifo_bytes = size_t(4) * FR * FSLOT;   // 128 KiB: four wave-private rings
       CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_f32_fifo), hipFuncAttributeMaxDynamicSharedMemorySize, int(fifo_bytes)));
-      hipLaunchKernelGGL(k_gram_f32_fifo, dim3((unsigned)nblocks), dim3(256), fifo_bytes, st, d_tiles, ntiles, ngroups, nitems, n, rows_per_wg, G, D);
+      hipLaunchKernelGGL(k_gram_f32_fifo, dim3((unsigned)nblocks), dim3(256), fifo_bytes, st, d_tiles, ntiles, per_xcd, ksplit, n, rows_per_wg, G, D);
     } else if (fast) {
       CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_f32<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
-      hipLaunchKernelGGL(k_gram_f32<true>, dim3((unsigned)nblocks), dim3(256), lds_bytes, st, d_tiles, ntiles, ngroups, nitems, n, rows_per_wg, G, D);
+      hipLaunchKernelGGL(k_gram_f32<true>, dim3((unsigned)nblocks), dim3(256), lds_bytes, st, d_tiles, ntiles, per_xcd, ksplit, n, rows_per_wg, G, D);
     } else {
       CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_f32<false>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
-      hipLaunchKernelGGL(k_gram_f32<false>, dim3((unsigned)nblocks), dim3(256), lds_bytes, st, d_tiles, ntiles, ngroups, nitems, n, rows_per_wg, G, D);
+      hipLaunchKernelGGL(k_gram_f32<false>, dim3((unsigned)nblocks), dim3(256), lds_bytes, st, d_tiles, ntiles, per_xcd, ksplit, n, rows_per_wg, G, D);
     }
   } else {
     if (fast) {
       CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_f64<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
-      hipLaunchKernelGGL(k_gram_f64<true>, dim3((unsigned)nblocks), dim3(256), lds_bytes, st, d_tiles, ntiles, ngroups, nitems, n, rows_per_wg, G, D);
+      hipLaunchKernelGGL(k_gram_f64<true>, dim3((unsigned)nblocks), dim3(256), lds_bytes, st, d_tiles, ntiles, per_xcd, ksplit, n, rows_per_wg, G, D);
     } else {
       CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_f64<false>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
-      hipLaunchKernelGGL(k_gram_f64<false>, dim3((unsigned)nblocks), dim3(256), lds_bytes, st, d_tiles, ntiles, ngroups, nitems, n, rows_per_wg, G, D);
+      hipLaunchKernelGGL(k_gram_f64<false>, dim3((unsigned)nblocks), dim3(256), lds_bytes, st, d_tiles, ntiles, per_xcd, ksplit, n, rows_per_wg, G, D);
     }
   }
   CCZ_LAUNCH_CHECK();

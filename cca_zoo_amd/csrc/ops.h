@@ -82,6 +82,10 @@ void gemm_ex(ccz_ctx* c, bool tA, bool tB, int64_t M, int64_t N, int64_t K, doub
 // in-place lower Cholesky of the d x d leading block (upper part left untouched).
 // returns 0, or j+1 if pivot j was not positive (matrix content then undefined).
 int potrf_lower(ccz_ctx* c, double* A, int64_t d, int64_t lda);
+// the same for `count` independent matrices at once: the 64-column panel factorisations (the
+// sequential critical path) of all matrices share one launch per panel step.  info[b] as above.
+void potrf_lower_batched(ccz_ctx* c, int count, double* const* A, const int64_t* d, const int64_t* lda,
+                         int* info);
 // X (r x d) <- X L^-T (trans) or X L^-1 (!trans); L lower triangular d x d
 void trsm_right_lower(ccz_ctx* c, bool trans, int64_t r, int64_t d, const double* L, int64_t ldl,
                       double* X, int64_t ldx);
@@ -100,6 +104,9 @@ void scale_cols(ccz_ctx* c, int64_t rows, int64_t cols, double* A, int64_t lda, 
                 int mode);
 // make the lower triangle equal to the upper one: A[i][j] = A[j][i] for i > j
 void mirror_upper(ccz_ctx* c, int64_t d, double* A, int64_t lda);
+// packed[off(i) + j - i] <-> A[i][j] for j >= i, off(i) = i d - i (i - 1) / 2   (row-major upper triangle)
+void pack_upper(ccz_ctx* c, int64_t d, const double* A, int64_t lda, double* packed);
+void unpack_upper(ccz_ctx* c, int64_t d, const double* packed, double* A, int64_t lda);
 // out (rows x cols) = alpha * ( G[r0+i][c0+j] - (centre ? s[r0+i] s[c0+j] / n : 0) );
 // G is D x D (ld D); only its UPPER triangle is read (element (i, j), i > j, comes from (j, i)),
 // so the moments need not be symmetrised first; s has D entries

@@ -421,6 +421,29 @@ void mirror_upper(ccz_ctx* c, int64_t d, double* A, int64_t lda) {
   CCZ_LAUNCH_CHECK();
 }
 
+template <bool PACK>
+__global__ void k_pack_upper(int64_t d, double* __restrict__ A, int64_t lda, double* __restrict__ packed) {
+  const int64_t i = blockIdx.y;
+  const int64_t j = i + int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (j >= d) return;
+  const int64_t off = i * d - (i * (i - 1)) / 2 + (j - i);
+  if (PACK) packed[off] = A[i * lda + j]; else A[i * lda + j] = packed[off];
+}
+void pack_upper(ccz_ctx* c, int64_t d, const double* A, int64_t lda, double* packed) {
+  if (d <= 0) return;
+  if (d > 65535) fail(CCZ_EUNSUP, "pack_upper: d too large");
+  hipLaunchKernelGGL(k_pack_upper<true>, dim3((unsigned)((d + 255) / 256), (unsigned)d), dim3(256), 0, stream(c), d,
+                     const_cast<double*>(A), lda, packed);
+  CCZ_LAUNCH_CHECK();
+}
+void unpack_upper(ccz_ctx* c, int64_t d, const double* packed, double* A, int64_t lda) {
+  if (d <= 0) return;
+  if (d > 65535) fail(CCZ_EUNSUP, "unpack_upper: d too large");
+  hipLaunchKernelGGL(k_pack_upper<false>, dim3((unsigned)((d + 255) / 256), (unsigned)d), dim3(256), 0, stream(c), d, A,
+                     lda, const_cast<double*>(packed));
+  CCZ_LAUNCH_CHECK();
+}
+
 __global__ void k_cov_block(int64_t total, int64_t cols, const double* __restrict__ G, int64_t D,
                             const double* __restrict__ s, double inv_n, int centre, double alpha, int64_t r0,
                             int64_t c0, double* __restrict__ out, int64_t ldo) {
@@ -644,6 +667,76 @@ __global__ __launch_bounds__(64) void k_wave_chol_inv(double* __restrict__ A, in
   }
 }
 
+constexpr int MAXB = 8;
+struct CholBatch {
+  double* A[MAXB];
+  double* invT[MAXB];
+  int64_t lda[MAXB];
+  int64_t d[MAXB];
+};
+
+// one panel step of up to MAXB independent factorisations: block b factors the diagonal block at
+// column j0 of matrix b (if it has one) and forms its L^-T
+__global__ __launch_bounds__(64) void k_wave_chol_inv_batched(CholBatch bt, int64_t j0, int* __restrict__ info) {
+  const int b = blockIdx.x;
+  if (j0 >= bt.d[b]) return;
+  const int lane = threadIdx.x;
+  const int nb = int(min(int64_t(NB), bt.d[b] - j0));
+  const int64_t lda = bt.lda[b];
+  double* Ajj = bt.A[b] + j0 * lda + j0;
+  double a[NB];
+  if (nb == NB) {
+#pragma unroll
+    for (int t = 0; t < NB; ++t) a[t] = Ajj[int64_t(lane) * lda + t];
+  } else {
+#pragma unroll
+    for (int t = 0; t < NB; ++t) {
+      double v = (t == lane) ? 1.0 : 0.0;
+      if (lane < nb && t < nb) v = Ajj[int64_t(lane) * lda + t];
+      a[t] = v;
+    }
+  }
+  int first_bad = 0x7fffffff;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    double piv = lane_bcast(a[j], j);
+    const bool bad = !(piv > 0.0);
+    first_bad = bad ? min(first_bad, j) : first_bad;
+    piv = bad ? 1.0 : piv;
+    const double rinv = 1.0 / sqrt(piv);
+    const double l = a[j] * rinv;
+    a[j] = l;
+#pragma unroll
+    for (int k = j + 1; k < NB; ++k) {
+      a[k] -= l * lane_bcast(a[j], k);
+      if (((k - j) & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (first_bad != 0x7fffffff && lane == 0) atomicMin(info + b, int(j0 + first_bad + 1));
+#pragma unroll
+  for (int t = 0; t < NB; ++t)
+    if (lane < nb && t <= lane) Ajj[int64_t(lane) * lda + t] = a[t];
+  if (j0 + nb >= bt.d[b]) return;          // last panel: no solve against it follows
+#pragma unroll
+  for (int t = 0; t < NB; ++t) asm volatile("" : "+v"(a[t]));
+  double x[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    double v = (i == lane) ? 1.0 : 0.0;
+#pragma unroll
+    for (int t = 0; t < i; ++t) {
+      v -= lane_bcast(a[t], i) * x[t];
+      if ((t & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    }
+    x[i] = v / lane_bcast(a[i], i);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  double* out = bt.invT[b] + int64_t(lane) * NB;
+#pragma unroll
+  for (int i = 0; i < NB; ++i) out[i] = x[i];
+}
+
 // invT[b] = L_bb^-T for every diagonal block b of L (one wave each, all blocks in one launch)
 static void diag_inverses(ccz_ctx* c, const double* L, int64_t ldl, int64_t d, double* invT) {
   const unsigned nblk = (unsigned)((d + NB - 1) / NB);
@@ -652,30 +745,58 @@ static void diag_inverses(ccz_ctx* c, const double* L, int64_t ldl, int64_t d, d
   CCZ_LAUNCH_CHECK();
 }
 
-int potrf_lower(ccz_ctx* c, double* A, int64_t d, int64_t lda) {
+void potrf_lower_batched(ccz_ctx* c, int count, double* const* A, const int64_t* d, const int64_t* lda, int* info) {
   Impl* im = impl(c);
-  const int big = 0x7fffffff;
-  CCZ_HIP(hipMemcpyAsync(im->d_flag, &big, sizeof(int), hipMemcpyHostToDevice, stream(c)));
-  CCZ_HIP(hipStreamSynchronize(stream(c)));
-  DBuf invT(c, NB * NB);
-  DBuf tmp(c, std::max<int64_t>(d - NB, 1) * NB);
-  for (int64_t j = 0; j < d; j += NB) {
-    const int nb = int(std::min<int64_t>(NB, d - j));
-    const int64_t rem = d - j - nb;
-    if (rem > 0) hipLaunchKernelGGL(k_wave_chol_inv<true>, dim3(1), dim3(64), 0, stream(c), A, lda, d, j, im->d_flag, invT.get());
-    else hipLaunchKernelGGL(k_wave_chol_inv<true>, dim3(1), dim3(64), 0, stream(c), A, lda, d, j, im->d_flag, static_cast<double*>(nullptr));
-    CCZ_LAUNCH_CHECK();
-    if (rem > 0) {
-      double* A21 = A + (j + nb) * lda + j;
-      // L21 = A21 L11^-T, written to the scratch panel and (second destination) back in place; safe in place:
-      // a workgroup reads only its own 64 rows of A21 (all of K) before it writes them
-      gemm_ex(c, false, false, rem, nb, nb, 1.0, A21, lda, invT, NB, 0.0, tmp, NB, A21, lda, false);
-      gemm_ex(c, false, true, rem, rem, nb, -1.0, tmp, NB, tmp, NB, 1.0, A + (j + nb) * lda + (j + nb), lda, nullptr, 0, true);
+  for (int b0 = 0; b0 < count; b0 += MAXB) {
+    const int nbt = std::min(MAXB, count - b0);
+    int big[MAXB];
+    for (int i = 0; i < MAXB; ++i) big[i] = 0x7fffffff;
+    CCZ_HIP(hipMemcpyAsync(im->d_flag + 8, big, sizeof(big), hipMemcpyHostToDevice, stream(c)));
+    CCZ_HIP(hipStreamSynchronize(stream(c)));
+    CholBatch bt;
+    std::vector<DBuf> invT, tmp;
+    int64_t dmax = 0;
+    for (int i = 0; i < MAXB; ++i) {
+      const int b = b0 + std::min(i, nbt - 1);     // pad the descriptor with the last matrix (never launched)
+      bt.A[i] = A[b];
+      bt.lda[i] = lda[b];
+      bt.d[i] = i < nbt ? d[b] : 0;
+      bt.invT[i] = nullptr;
     }
+    for (int i = 0; i < nbt; ++i) {
+      invT.emplace_back(c, NB * NB);
+      tmp.emplace_back(c, std::max<int64_t>(d[b0 + i] - NB, 1) * NB);
+      bt.invT[i] = invT.back().get();
+      dmax = std::max(dmax, d[b0 + i]);
+    }
+    for (int64_t j = 0; j < dmax; j += NB) {
+      hipLaunchKernelGGL(k_wave_chol_inv_batched, dim3(nbt), dim3(64), 0, stream(c), bt, j, im->d_flag + 8);
+      CCZ_LAUNCH_CHECK();
+      for (int i = 0; i < nbt; ++i) {
+        const int64_t di = d[b0 + i], ld = lda[b0 + i];
+        if (j >= di) continue;
+        const int nb = int(std::min<int64_t>(NB, di - j));
+        const int64_t rem = di - j - nb;
+        if (rem <= 0) continue;
+        double* Ab = A[b0 + i];
+        double* A21 = Ab + (j + nb) * ld + j;
+        // L21 = A21 L11^-T to the scratch panel and (second destination) back in place: a workgroup reads
+        // only its own 64 rows of A21 (all of K) before it writes them
+        gemm_ex(c, false, false, rem, nb, nb, 1.0, A21, ld, invT[i], NB, 0.0, tmp[i], NB, A21, ld, false);
+        gemm_ex(c, false, true, rem, rem, nb, -1.0, tmp[i], NB, tmp[i], NB, 1.0, Ab + (j + nb) * ld + (j + nb), ld, nullptr, 0, true);
+      }
+    }
+    int got[MAXB];
+    d2h(c, got, im->d_flag + 8, sizeof(got));
+    for (int i = 0; i < nbt; ++i) info[b0 + i] = got[i] == 0x7fffffff ? 0 : got[i];
   }
+}
+
+int potrf_lower(ccz_ctx* c, double* A, int64_t d, int64_t lda) {
   int info = 0;
-  d2h(c, &info, im->d_flag, sizeof(int));
-  return info == big ? 0 : info;
+  double* Ap[1] = {A};
+  potrf_lower_batched(c, 1, Ap, &d, &lda, &info);
+  return info;
 }
 
 void trsm_right_lower(ccz_ctx* c, bool trans, int64_t r, int64_t d, const double* L, int64_t ldl, double* X,

@@ -410,53 +410,86 @@ struct Whitener {
   }
 };
 
-// R (d x d, destroyed) -> Whitener.  allow_floor: on a failed Cholesky fall back to the
-// eigen-floored explicit factor (rCCA c = 0 on rank-deficient data); otherwise ENOTSPD.
-Whitener make_whitener(ccz_ctx* c, double* R, int64_t d, bool allow_floor) {
-  Whitener w;
-  w.d = d;
-  DBuf keep;
-  if (allow_floor) { keep = DBuf(c, d * d); d2d(c, keep, R, size_t(d) * d * 8); }
-  if (potrf_lower(c, R, d, d) == 0) {
-    w.chol = true;
-    w.r = d;
-    w.L = DBuf(c, d * d);
-    d2d(c, w.L, R, size_t(d) * d * 8);
-    return w;
+// R_i (d_i x d_i, consumed) -> Whiteners; the Cholesky panel chains of all blocks run batched.
+// allow_floor: a block whose Cholesky fails falls back to the eigen-floored explicit factor
+// (rCCA c = 0 on rank-deficient data); otherwise ENOTSPD.
+std::vector<Whitener> make_whiteners(ccz_ctx* c, std::vector<DBuf>& R, const std::vector<int64_t>& dims, bool allow_floor) {
+  const int m = int(R.size());
+  std::vector<DBuf> keep(m);
+  std::vector<double*> ptr(m);
+  std::vector<int64_t> ld(dims);
+  std::vector<int> info(m, 0);
+  for (int i = 0; i < m; ++i) {
+    if (allow_floor) { keep[i] = DBuf(c, dims[i] * dims[i]); d2d(c, keep[i], R[i], size_t(dims[i]) * dims[i] * 8); }
+    ptr[i] = R[i].get();
   }
-  if (!allow_floor) fail(CCZ_ENOTSPD, "regularised covariance block (%lld x %lld) is not positive definite", (long long)d, (long long)d);
-  std::vector<double> lam;
-  DBuf V(c, d * d);
-  syev_full_impl(c, keep, d, true, lam, V, d);
-  const double floor_ = kRankTol * double(d) * std::max(lam.empty() ? 0.0 : lam[0], 0.0);
-  int64_t r = 0;
-  while (r < d && lam[r] > floor_) ++r;
-  if (r == 0) fail(CCZ_ENOTSPD, "covariance block is numerically zero");
-  std::vector<int64_t> perm(r);
-  std::vector<double> sc(r);
-  for (int64_t i = 0; i < r; ++i) { perm[i] = i; sc[i] = 1.0 / std::sqrt(lam[i]); }
-  DBuf Ft(c, r * d);
-  gather_rows(c, r, d, V, d, perm.data(), sc.data(), Ft, d);
-  w.chol = false;
-  w.r = r;
-  w.L = DBuf(c, d * r);
-  transpose(c, r, d, Ft, d, w.L, r);
-  return w;
+  potrf_lower_batched(c, m, ptr.data(), dims.data(), ld.data(), info.data());
+  std::vector<Whitener> out(m);
+  for (int i = 0; i < m; ++i) {
+    Whitener& w = out[i];
+    const int64_t d = dims[i];
+    w.d = d;
+    if (info[i] == 0) {
+      w.chol = true;
+      w.r = d;
+      w.L = std::move(R[i]);
+      continue;
+    }
+    if (!allow_floor) fail(CCZ_ENOTSPD, "regularised covariance block %d (%lld x %lld) is not positive definite", i, (long long)d, (long long)d);
+    std::vector<double> lam;
+    DBuf V(c, d * d);
+    syev_full_impl(c, keep[i], d, true, lam, V, d);
+    const double floor_ = kRankTol * double(d) * std::max(lam.empty() ? 0.0 : lam[0], 0.0);
+    int64_t r = 0;
+    while (r < d && lam[r] > floor_) ++r;
+    if (r == 0) fail(CCZ_ENOTSPD, "covariance block %d is numerically zero", i);
+    std::vector<int64_t> perm(r);
+    std::vector<double> sc(r);
+    for (int64_t t = 0; t < r; ++t) { perm[t] = t; sc[t] = 1.0 / std::sqrt(lam[t]); }
+    DBuf Ft(c, r * d);
+    gather_rows(c, r, d, V, d, perm.data(), sc.data(), Ft, d);
+    w.chol = false;
+    w.r = r;
+    w.L = DBuf(c, d * r);
+    transpose(c, r, d, Ft, d, w.L, r);
+    R[i].reset();
+  }
+  return out;
 }
 
-// eps-floor rule of the reference (linear/_mcca.py:170-172, linear/_gcca.py:102-104):
-// returns min eigenvalue info for a set of SPD-ish blocks R_i: shift = eps - min_eig if < eps.
-// Cheap certificate first: R - eps I positive definite  =>  min_eig >= eps  => no shift.
-double min_eig_if_below(ccz_ctx* c, const double* R, int64_t d, double cval, double eps) {
-  if (cval >= eps) return eps;  // (1-c) C + c I with C >= 0  =>  min eig >= c >= eps
-  DBuf T(c, d * d);
-  d2d(c, T, R, size_t(d) * d * 8);
-  add_diag(c, d, T, d, -eps);
-  if (potrf_lower(c, T, d, d) == 0) return eps;  // certified >= eps
-  d2d(c, T, R, size_t(d) * d * 8);
-  std::vector<double> lam;
-  syev_full_impl(c, T, d, true, lam, nullptr, 0);
-  return lam.back();
+// eps-floor rule of the reference (linear/_mcca.py:170-172, linear/_gcca.py:102-104): the minimum
+// eigenvalue of each block if it is below eps, else eps.  Cheap certificates first:
+// c >= eps (ridge) or "R - eps I is positive definite" (one batched Cholesky) => min eig >= eps.
+std::vector<double> min_eigs_if_below(ccz_ctx* c, const std::vector<DBuf>& R, const std::vector<int64_t>& dims,
+                                      const double* cvals, double eps) {
+  const int m = int(R.size());
+  std::vector<double> out(m, eps);
+  std::vector<int> todo;
+  for (int i = 0; i < m; ++i)
+    if (!(cvals[i] >= eps)) todo.push_back(i);      // (1-c) C + c I with C >= 0  =>  min eig >= c
+  if (todo.empty()) return out;
+  std::vector<DBuf> T(todo.size());
+  std::vector<double*> ptr(todo.size());
+  std::vector<int64_t> dd(todo.size());
+  std::vector<int> info(todo.size(), 0);
+  for (size_t t = 0; t < todo.size(); ++t) {
+    const int64_t d = dims[todo[t]];
+    T[t] = DBuf(c, d * d);
+    d2d(c, T[t], R[todo[t]], size_t(d) * d * 8);
+    add_diag(c, d, T[t], d, -eps);
+    ptr[t] = T[t].get();
+    dd[t] = d;
+  }
+  potrf_lower_batched(c, int(todo.size()), ptr.data(), dd.data(), dd.data(), info.data());
+  for (size_t t = 0; t < todo.size(); ++t) {
+    if (info[t] == 0) continue;                       // certified >= eps
+    const int64_t d = dd[t];
+    d2d(c, T[t], R[todo[t]], size_t(d) * d * 8);
+    std::vector<double> lam;
+    syev_full_impl(c, T[t], d, true, lam, nullptr, 0);
+    out[todo[t]] = lam.back();
+  }
+  return out;
 }
 
 void means_out(ccz_ctx* c, const double* s_dev, int64_t D, int64_t n, bool center, double* means_host) {
@@ -516,17 +549,19 @@ static void rcca_solve_impl(ccz_ctx* c, const double* mom, int64_t n, const int6
   // reference: k = min(latent, rank1, rank2); ranks are at most min(n, d)
   int kk = int(std::min<int64_t>({int64_t(k), d1, d2, n}));
 
-  DBuf R1(c, d1 * d1), R2(c, d2 * d2), M12(c, d1 * d2);
-  cov_block(c, G, D, s, n, ctr, (1.0 - cc[0]) * inv, 0, d1, 0, d1, R1, d1);
-  add_diag(c, d1, R1, d1, cc[0]);
-  cov_block(c, G, D, s, n, ctr, (1.0 - cc[1]) * inv, d1, d2, d1, d2, R2, d2);
-  add_diag(c, d2, R2, d2, cc[1]);
+  std::vector<DBuf> Rv(2);
+  Rv[0] = DBuf(c, d1 * d1);
+  Rv[1] = DBuf(c, d2 * d2);
+  DBuf M12(c, d1 * d2);
+  cov_block(c, G, D, s, n, ctr, (1.0 - cc[0]) * inv, 0, d1, 0, d1, Rv[0], d1);
+  add_diag(c, d1, Rv[0], d1, cc[0]);
+  cov_block(c, G, D, s, n, ctr, (1.0 - cc[1]) * inv, d1, d2, d1, d2, Rv[1], d2);
+  add_diag(c, d2, Rv[1], d2, cc[1]);
   cov_block(c, G, D, s, n, ctr, inv, 0, d1, d1, d2, M12, d2);
 
-  Whitener F1 = make_whitener(c, R1, d1, true);
-  Whitener F2 = make_whitener(c, R2, d2, true);
-  R1.reset();
-  R2.reset();
+  std::vector<Whitener> Fv = make_whiteners(c, Rv, {d1, d2}, true);
+  Whitener& F1 = Fv[0];
+  Whitener& F2 = Fv[1];
   const int64_t r1 = F1.r, r2 = F2.r;
   kk = int(std::min<int64_t>({int64_t(kk), r1, r2}));
 
@@ -573,20 +608,18 @@ static void mcca_solve_impl(ccz_ctx* c, const double* mom, int64_t n, const int6
 
   // B blocks (always from the CENTRED covariance: np.cov / PCA re-centre)
   std::vector<DBuf> R(m);
-  double min_eig = eps;
+  const std::vector<int64_t> dimv(dims, dims + m);
   for (int i = 0; i < m; ++i) {
     R[i] = DBuf(c, dims[i] * dims[i]);
     cov_block(c, G, D, s, n, true, (1.0 - cc[i]) * inv, off[i], dims[i], off[i], dims[i], R[i], dims[i]);
     add_diag(c, dims[i], R[i], dims[i], cc[i]);
-    min_eig = std::min(min_eig, min_eig_if_below(c, R[i], dims[i], cc[i], eps));
   }
+  double min_eig = eps;
+  for (double v : min_eigs_if_below(c, R, dimv, cc, eps)) min_eig = std::min(min_eig, v);
   const double shift = min_eig < eps ? eps - min_eig : 0.0;
-  std::vector<Whitener> F(m);
-  for (int i = 0; i < m; ++i) {
-    if (shift > 0.0) add_diag(c, dims[i], R[i], dims[i], shift);
-    F[i] = make_whitener(c, R[i], dims[i], false);
-    R[i].reset();
-  }
+  if (shift > 0.0)
+    for (int i = 0; i < m; ++i) add_diag(c, dims[i], R[i], dims[i], shift);
+  std::vector<Whitener> F = make_whiteners(c, R, dimv, false);
   // S = L^-1 (C - blockdiag C) L^-T,  zero diagonal blocks
   DBuf S(c, D * D);
   fill2d(c, D, D, S, D, 0.0);
@@ -641,15 +674,19 @@ static void gcca_solve_impl(ccz_ctx* c, const double* mom, int64_t n, const int6
     if (!(w >= 0.0)) fail(CCZ_EINVAL, "view weight %d must be non-negative, got %g", i, w);
     rmu[i] = std::sqrt(w);
   }
-  std::vector<Whitener> F(m);
+  std::vector<DBuf> R(m);
+  const std::vector<int64_t> dimv(dims, dims + m);
   for (int i = 0; i < m; ++i) {
-    DBuf R(c, dims[i] * dims[i]);
-    cov_block(c, G, D, s, n, true, (1.0 - cc[i]) * inv, off[i], dims[i], off[i], dims[i], R, dims[i]);
-    add_diag(c, dims[i], R, dims[i], cc[i]);
-    const double lo = min_eig_if_below(c, R, dims[i], cc[i], eps);
-    if (lo < eps) add_diag(c, dims[i], R, dims[i], eps - lo);
-    F[i] = make_whitener(c, R, dims[i], false);
+    R[i] = DBuf(c, dims[i] * dims[i]);
+    cov_block(c, G, D, s, n, true, (1.0 - cc[i]) * inv, off[i], dims[i], off[i], dims[i], R[i], dims[i]);
+    add_diag(c, dims[i], R[i], dims[i], cc[i]);
   }
+  {
+    const std::vector<double> lo = min_eigs_if_below(c, R, dimv, cc, eps);
+    for (int i = 0; i < m; ++i)
+      if (lo[i] < eps) add_diag(c, dims[i], R[i], dims[i], eps - lo[i]);   // per-view floor (_gcca.py:102-104)
+  }
+  std::vector<Whitener> F = make_whiteners(c, R, dimv, false);
   // Z[:, j] = sqrt(mu_j) Gx[:, j] L_j^-T      (Gx: second moments of the data as fitted)
   DBuf Z(c, D * D), K(c, D * D);
   for (int j = 0; j < m; ++j) {

@@ -95,6 +95,11 @@ CCZ_API int ccz_memset0(ccz_handle h, void* dst_dev, size_t bytes);
 CCZ_API int ccz_moments(ccz_handle h, int dtype, const ccz_view* views, int n_views, int64_t n_rows,
                 int views_on_device, double* moments_dev, int accumulate);
 CCZ_API int ccz_moments_symmetrize(ccz_handle h, double* moments_dev, int64_t D);
+/* Packed form for the one collective of the sharded path: [ upper triangle of G, row-major,
+ * D(D+1)/2 | colsum (D) ] -- half the bytes of the full buffer on the wire.  pack: moments -> packed;
+ * unpack: packed -> upper triangle of moments (+ colsum); the lower triangle is left untouched. */
+CCZ_API int ccz_moments_pack(ccz_handle h, const double* moments_dev, int64_t D, double* packed_dev);
+CCZ_API int ccz_moments_unpack(ccz_handle h, const double* packed_dev, int64_t D, double* moments_dev);
 /* kernel timing of the last ccz_moments call on this handle (HIP events on the
  * handle's stream): milliseconds of the Gram kernel(s) and of the column-sum pass */
 CCZ_API int ccz_moments_last_ms(ccz_handle h, double* gram_ms, double* colsum_ms);

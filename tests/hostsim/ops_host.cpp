@@ -67,6 +67,10 @@ int potrf_lower(ccz_ctx*, double* A, int64_t d, int64_t lda) {
   return 0;
 }
 
+void potrf_lower_batched(ccz_ctx* c, int count, double* const* A, const int64_t* d, const int64_t* lda, int* info) {
+  for (int b = 0; b < count; ++b) info[b] = potrf_lower(c, A[b], d[b], lda[b]);
+}
+
 void trsm_right_lower(ccz_ctx*, bool trans, int64_t r, int64_t d, const double* L, int64_t ldl,
                       double* X, int64_t ldx) {
   for (int64_t row = 0; row < r; ++row) {
@@ -117,6 +121,16 @@ void scale_cols(ccz_ctx*, int64_t rows, int64_t cols, double* A, int64_t lda, co
 void mirror_upper(ccz_ctx*, int64_t d, double* A, int64_t lda) {
   for (int64_t i = 0; i < d; ++i)
     for (int64_t j = 0; j < i; ++j) A[i * lda + j] = A[j * lda + i];
+}
+void pack_upper(ccz_ctx*, int64_t d, const double* A, int64_t lda, double* packed) {
+  int64_t o = 0;
+  for (int64_t i = 0; i < d; ++i)
+    for (int64_t j = i; j < d; ++j) packed[o++] = A[i * lda + j];
+}
+void unpack_upper(ccz_ctx*, int64_t d, const double* packed, double* A, int64_t lda) {
+  int64_t o = 0;
+  for (int64_t i = 0; i < d; ++i)
+    for (int64_t j = i; j < d; ++j) A[i * lda + j] = packed[o++];
 }
 void cov_block(ccz_ctx*, const double* G, int64_t D, const double* s, int64_t n, bool centre, double alpha,
                int64_t r0, int64_t rows, int64_t c0, int64_t cols, double* out, int64_t ldo) {

@@ -127,3 +127,24 @@ def test_moments_errors(H):
         H.moments([(np.zeros((4, 2), np.float32), 2, 2)], 4, 7, False, mom.ptr)
     with pytest.raises(ValueError, match="malformed"):
         H.moments([(np.zeros((4, 2), np.float32), 2, 1)], 4, _backend.F32, False, mom.ptr)
+
+
+def test_moments_pack_unpack_roundtrip(H):
+    """Packed upper triangle (the all-reduce operand) round-trips and leaves the lower triangle alone."""
+    rng = np.random.default_rng(0)
+    D = 300
+    G = rng.standard_normal((D, D))
+    s = rng.standard_normal(D)
+    mom = H.to_device(np.concatenate([G.ravel(), s]))
+    packed = H.alloc((D * (D + 1) // 2 + D) * 8)
+    H.moments_pack(mom.ptr, D, packed.ptr)
+    p = H.to_host(packed, (D * (D + 1) // 2 + D,))
+    np.testing.assert_array_equal(p[: D * (D + 1) // 2], G[np.triu_indices(D)])
+    np.testing.assert_array_equal(p[D * (D + 1) // 2:], s)
+    other = H.to_device(np.full(D * D + D, -7.0))
+    H.moments_unpack(packed.ptr, D, other.ptr)
+    o = H.to_host(other, (D * D + D,))
+    O = o[: D * D].reshape(D, D)
+    np.testing.assert_array_equal(np.triu(O), np.triu(G))
+    assert np.all(np.tril(O, -1)[np.tril_indices(D, -1)] == -7.0)
+    np.testing.assert_array_equal(o[D * D:], s)
