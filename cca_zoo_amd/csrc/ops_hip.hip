@@ -833,7 +833,8 @@ void trsm_right_lower(ccz_ctx* c, bool trans, int64_t r, int64_t d, const double
 template <int BS>
 __global__ __launch_bounds__(BS) void k_jacobi_round(int64_t p, int64_t pe, int64_t q, double* __restrict__ W,
                                                      int64_t ldw, double* __restrict__ Q, int64_t qc, int64_t ldq,
-                                                     int64_t round, double tol, int* __restrict__ counter) {
+                                                     int64_t round, double tol, double floor2,
+                                                     int* __restrict__ counter) {
   __shared__ double red[3][BS / 64 > 0 ? BS / 64 : 1];
   const int64_t k = blockIdx.x, m1 = pe - 1;
   int64_t a, b;
@@ -855,7 +856,9 @@ __global__ __launch_bounds__(BS) void k_jacobi_round(int64_t p, int64_t pe, int6
     for (int i = 0; i < BS / 64; ++i) { al += red[0][i]; be += red[1][i]; ga += red[2][i]; }
   }
   const double prod = al * be;
-  if (!(prod > 0.0) || !(fabs(ga) > tol * sqrt(prod))) return;
+  // rows whose norm has sunk below 1e-14 of the largest row are numerically zero: rotating rounding
+  // noise against real rows never meets the relative criterion (rank-deficient inputs)
+  if (!(prod > 0.0) || !(fmin(al, be) > floor2) || !(fabs(ga) > tol * sqrt(prod))) return;
   if (threadIdx.x == 0) atomicAdd(counter, 1);
   const double zeta = (be - al) / (2.0 * ga);
   const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
@@ -898,7 +901,7 @@ __device__ __forceinline__ double row16_sum(double v) {
 
 __global__ __launch_bounds__(1024) void k_jacobi_lds(int p, int q, double* __restrict__ W, int64_t ldw,
                                                      double* __restrict__ Q, int qc, int64_t ldq, double tol,
-                                                     int max_sweeps, int* __restrict__ sweeps_out) {
+                                                     double floor2, int max_sweeps, int* __restrict__ sweeps_out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int sq = q | 1, sqc = qc | 1;                 // odd row strides: conflict-free column walks
   double* Ws = reinterpret_cast<double*>(smem);
@@ -928,7 +931,7 @@ __global__ __launch_bounds__(1024) void k_jacobi_lds(int p, int q, double* __res
           for (int t = gl; t < q; t += 16) { const double x = wa[t], y = wb[t]; al += x * x; be += y * y; ga += x * y; }
         al = row16_sum(al); be = row16_sum(be); ga = row16_sum(ga);
         const double prod = al * be;
-        if (!live || !(prod > 0.0) || !(fabs(ga) > tol * sqrt(prod))) continue;
+        if (!live || !(prod > 0.0) || !(fmin(al, be) > floor2) || !(fabs(ga) > tol * sqrt(prod))) continue;
         if (gl == 0) atomicAdd(&rot_count, 1);
         const double zeta = (be - al) / (2.0 * ga);
         const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
@@ -956,11 +959,21 @@ int jacobi_rows(ccz_ctx* c, int64_t p, int64_t q, double* W, int64_t ldw, double
   Impl* im = impl(c);
   const int64_t pe = (p + 1) & ~int64_t(1);
   const double tol = 2.220446049250313e-16 * std::sqrt(double(q)) * 4.0;
+  double floor2 = 0.0;
+  {
+    DBuf nn(c, p);
+    row_dots(c, p, q, W, ldw, W, ldw, nn);
+    std::vector<double> nh(p);
+    d2h(c, nh.data(), nn, size_t(p) * 8);
+    double mx = 0.0;
+    for (double v : nh) mx = std::max(mx, v);
+    floor2 = mx * 1e-28;
+  }
   const size_t lds_need = (size_t(p) * (q | 1) + (Q ? size_t(p) * (qc | 1) : 0)) * 8;
   if (lds_need <= size_t(144) * 1024) {
     CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jacobi_lds), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_need + 16)));
     hipLaunchKernelGGL(k_jacobi_lds, dim3(1), dim3(1024), lds_need + 16, stream(c), int(p), int(q), W, ldw, Q, int(Q ? qc : 0), ldq,
-                       tol, max_sweeps, im->d_flag + 1);
+                       tol, floor2, max_sweeps, im->d_flag + 1);
     CCZ_LAUNCH_CHECK();
     int sw = 0;
     d2h(c, &sw, im->d_flag + 1, sizeof(int));
@@ -972,8 +985,8 @@ int jacobi_rows(ccz_ctx* c, int64_t p, int64_t q, double* W, int64_t ldw, double
   for (int sweep = 1; sweep <= max_sweeps; ++sweep) {
     CCZ_HIP(hipMemsetAsync(im->d_flag + 1, 0, sizeof(int), stream(c)));
     for (int64_t round = 0; round < pe - 1; ++round) {
-      if (small) hipLaunchKernelGGL(k_jacobi_round<64>, grid, dim3(64), 0, stream(c), p, pe, q, W, ldw, Q, qc, ldq, round, tol, im->d_flag + 1);
-      else hipLaunchKernelGGL(k_jacobi_round<256>, grid, dim3(256), 0, stream(c), p, pe, q, W, ldw, Q, qc, ldq, round, tol, im->d_flag + 1);
+      if (small) hipLaunchKernelGGL(k_jacobi_round<64>, grid, dim3(64), 0, stream(c), p, pe, q, W, ldw, Q, qc, ldq, round, tol, floor2, im->d_flag + 1);
+      else hipLaunchKernelGGL(k_jacobi_round<256>, grid, dim3(256), 0, stream(c), p, pe, q, W, ldw, Q, qc, ldq, round, tol, floor2, im->d_flag + 1);
     }
     CCZ_LAUNCH_CHECK();
     int rot = 0;

@@ -71,6 +71,7 @@ class MCCA(BaseModel):
         h = _backend.default_handle()
         mom, keep, n, dims, _ = compute_moments([np.asarray(v) for v in views], h)
         D = sum(dims)
+        h.moments_symmetrize(mom, D)          # K1 fills upper-triangular tiles only
         flat = h.to_host(mom, (D * D + D,))
         G, s = flat[: D * D].reshape(D, D), flat[D * D:]
         return (G - np.outer(s, s) / n) / (n - 1), dims

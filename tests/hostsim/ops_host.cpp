@@ -164,6 +164,13 @@ double norm_inf(ccz_ctx*, int64_t rows, int64_t cols, const double* A, int64_t l
 int jacobi_rows(ccz_ctx*, int64_t p, int64_t q, double* W, int64_t ldw, double* Q, int64_t qc, int64_t ldq,
                 int max_sweeps) {
   const double tol = 2.220446049250313e-16 * std::sqrt(double(q)) * 4.0;
+  double floor2 = 0.0;
+  for (int64_t a = 0; a < p; ++a) {
+    double al = 0;
+    for (int64_t t = 0; t < q; ++t) al += W[a * ldw + t] * W[a * ldw + t];
+    floor2 = std::max(floor2, al);
+  }
+  floor2 *= 1e-28;
   for (int sweep = 1; sweep <= max_sweeps; ++sweep) {
     int64_t rotations = 0;
     for (int64_t a = 0; a < p - 1; ++a)
@@ -172,7 +179,7 @@ int jacobi_rows(ccz_ctx*, int64_t p, int64_t q, double* W, int64_t ldw, double* 
         double* wb = W + b * ldw;
         double al = 0, be = 0, ga = 0;
         for (int64_t t = 0; t < q; ++t) { al += wa[t] * wa[t]; be += wb[t] * wb[t]; ga += wa[t] * wb[t]; }
-        if (!(std::fabs(ga) > tol * std::sqrt(al * be)) || al * be == 0.0) continue;
+        if (!(std::fabs(ga) > tol * std::sqrt(al * be)) || al * be == 0.0 || !(std::min(al, be) > floor2)) continue;
         ++rotations;
         const double zeta = (be - al) / (2.0 * ga);
         const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
