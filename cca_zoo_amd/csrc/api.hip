@@ -1,6 +1,7 @@
 // libccz C ABI: lifecycle, memory, moments, DCCA loss, transform (HIP build).
 // The solver entry points live in solve.cpp.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -160,6 +161,11 @@ int ccz_create(ccz_handle* out, int device) {
   c->impl = im;
   bool ok = hipGetDeviceProperties(&im->props, device) == hipSuccess;
   for (int i = 0; ok && i < 4; ++i) ok = hipEventCreate(&im->ev[i]) == hipSuccess;
+  // a real (blocking) stream instead of the legacy null stream: it keeps the implicit ordering with
+  // null-stream work (PyTorch's default stream) and, unlike the null stream, can be captured into graphs
+  ok = ok && hipStreamCreate(&im->own_stream) == hipSuccess;
+  if (ok) c->stream = im->own_stream;
+  if (const char* e = getenv("CCZ_GRAPHS")) im->graphs_on = atoi(e);
   ok = ok && hipMalloc(reinterpret_cast<void**>(&im->d_flag), 64 * sizeof(int)) == hipSuccess;
   ok = ok && hipMalloc(reinterpret_cast<void**>(&im->d_small), im->small_cap * sizeof(double)) == hipSuccess;
   if (!ok) { (void)hipGetLastError(); delete im; delete c; return CCZ_EHIP; }
@@ -173,6 +179,8 @@ int ccz_destroy(ccz_handle h) {
   if (im) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
+    for (auto& g : im->graphs) (void)hipGraphExecDestroy(g.exec);
+    if (im->own_stream) (void)hipStreamDestroy(im->own_stream);
     for (auto& b : im->pool) (void)hipFree(b.p);
     for (int i = 0; i < 4; ++i) (void)hipEventDestroy(im->ev[i]);
     (void)hipFree(im->d_flag);

@@ -1,0 +1,201 @@
+// Large fp64 GEMM for the solver stage:  C (M x N) = alpha op(A) op(B) + beta C   on v_mfma_f64_16x16x4_f64.
+//
+// 128 x 128 tile per workgroup, 4 waves (2 x 2), each wave 64 x 64 = 4 x 4 MFMA tiles (128 accumulator
+// registers, two workgroups per CU).  Both operands are staged into LDS as k-major images [k][m] / [k][n]
+// so that a lane's fragment is two ds_read_b128 (four consecutive m or n of row k; the four values feed
+// four MFMA tiles, tile t owning the columns == t mod 4 -- the same strided ownership as K1).
+//   * an operand that is already k-major in memory (A with transA, B without transB) is copied row by row;
+//   * an operand that is m-major (A without transA, B with transB) is transposed while staging: a thread
+//     owns one row, reads 64 contiguous bytes of it and scatters 8 ds_write_b64 (consecutive lanes ->
+//     consecutive addresses).
+// Rows / columns past M / N are clamped on load and masked on store; K must be a multiple of 16.
+// The recursive Cholesky / triangular solves in ops_hip.hip put ~all solver flops through this kernel
+// with K >= 128 (the 64 x 64-tile generic kernel keeps the small and ragged products).
+#include <algorithm>
+#include <cstdlib>
+
+#include "hip_common.h"
+
+namespace ccz {
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+typedef double v2f64 __attribute__((ext_vector_type(2)));
+
+constexpr int DT = 128;   // tile edge
+constexpr int DK = 16;    // k-block
+
+constexpr int DS = DT + 2;   // LDS row stride (doubles): 16-byte aligned rows, transposing writes at most 2-way conflicted
+
+// stage a 16 (k) x 128 (m) block of an operand into `dst` ([16][DS] doubles)
+//   KMAJOR: element (k, m) at P[k * ld + m]: a wave copies one full 1-KiB row per load instruction
+//   else  : element (k, m) at P[m * ld + k]: 8 lanes cover the 16 k (128 contiguous bytes) of a row, a wave
+//           covers 8 rows per load instruction (full cache lines), and the 2 doubles are scattered to [k][m]
+template <bool KMAJOR>
+struct Stager {
+  v2f64 r[4];
+  __device__ __forceinline__ void load(const double* __restrict__ P, int64_t ld, int64_t m0, int64_t mlim, int64_t k0,
+                                       int tid) {
+    if (KMAJOR) {
+      const int64_t m = m0 + 2 * (tid & 63);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const double* p = P + (k0 + (tid >> 6) + 4 * i) * ld;
+        if (m + 1 < mlim) {
+          r[i] = *reinterpret_cast<const v2f64*>(p + m);
+        } else {
+          r[i][0] = m < mlim ? p[m] : 0.0;
+          r[i][1] = 0.0;
+        }
+      }
+    } else {
+      const int kq = tid & 7;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t m = std::min<int64_t>(m0 + (tid >> 3) + 32 * i, mlim - 1);
+        r[i] = *reinterpret_cast<const v2f64*>(P + m * ld + k0 + 2 * kq);
+      }
+    }
+  }
+  __device__ __forceinline__ void store(double* dst, int tid) const {
+    if (KMAJOR) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<v2f64*>(dst + ((tid >> 6) + 4 * i) * DS + 2 * (tid & 63)) = r[i];
+    } else {
+      const int kq = tid & 7;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = (tid >> 3) + 32 * i;
+        dst[(2 * kq) * DS + m] = r[i][0];
+        dst[(2 * kq + 1) * DS + m] = r[i][1];
+      }
+    }
+  }
+};
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void k_gemm_f64_big(int64_t M, int64_t N, int64_t K, double alpha,
+                                                         const double* __restrict__ A, int64_t lda,
+                                                         const double* __restrict__ B, int64_t ldb, double beta,
+                                                         double* __restrict__ C, int64_t ldc, int lower_only) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* lds = reinterpret_cast<double*>(smem);  // [2 buffers][A | B][16][DS]
+  const int64_t m0 = int64_t(blockIdx.y) * DT, n0 = int64_t(blockIdx.x) * DT;
+  if (lower_only && n0 > m0 + (DT - 1)) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+
+  v4f64 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
+
+  // A is k-major in memory iff TA (stored K x M); B is k-major iff !TB (stored K x N)
+  Stager<TA> sa;
+  Stager<!TB> sb;
+  const int64_t nkb = K / DK;
+  sa.load(A, lda, m0, M, 0, tid);
+  sb.load(B, ldb, n0, N, 0, tid);
+  sa.store(lds, tid);
+  sb.store(lds + DK * DS, tid);
+  __syncthreads();
+  for (int64_t kb = 0; kb < nkb; ++kb) {
+    const int cur = int(kb & 1);
+    if (kb + 1 < nkb) {
+      sa.load(A, lda, m0, M, (kb + 1) * DK, tid);
+      sb.load(B, ldb, n0, N, (kb + 1) * DK, tid);
+    }
+    const double* as = lds + cur * (2 * DK * DS);
+    const double* bs = as + DK * DS;
+#pragma unroll
+    for (int kk = 0; kk < DK / 4; ++kk) {
+      const int krow = 4 * kk + (lane >> 4);
+      const double* ap = as + krow * DS + wr * 64 + 4 * (lane & 15);
+      const double* bp = bs + krow * DS + wc * 64 + 4 * (lane & 15);
+      const v2f64 a01 = *reinterpret_cast<const v2f64*>(ap), a23 = *reinterpret_cast<const v2f64*>(ap + 2);
+      const v2f64 b01 = *reinterpret_cast<const v2f64*>(bp), b23 = *reinterpret_cast<const v2f64*>(bp + 2);
+      const double a4[4] = {a01[0], a01[1], a23[0], a23[1]};
+      const double b4[4] = {b01[0], b01[1], b23[0], b23[1]};
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+          acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[ti], b4[tj], acc[ti][tj], 0, 0, 0);
+    }
+    if (kb + 1 < nkb) {
+      double* nx = lds + (cur ^ 1) * (2 * DK * DS);
+      sa.store(nx, tid);
+      sb.store(nx + DK * DS, tid);
+    }
+    __syncthreads();
+  }
+
+  // f64 16x16 C/D layout: col (B side) = lane & 15, row (A side) = (lane >> 4) + 4 * reg
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t m = m0 + wr * 64 + 4 * ((lane >> 4) + 4 * r) + ti;
+      if (m >= M) continue;
+      const int64_t nb = n0 + wc * 64 + 4 * (lane & 15);
+      double* cp = C + m * ldc + nb;
+      if (nb + 3 < N) {
+        v4f64 v = {acc[ti][0][r], acc[ti][1][r], acc[ti][2][r], acc[ti][3][r]};
+        v *= alpha;
+        if (beta != 0.0) {
+          const v2f64 c01 = *reinterpret_cast<const v2f64*>(cp), c23 = *reinterpret_cast<const v2f64*>(cp + 2);
+          v[0] += beta * c01[0]; v[1] += beta * c01[1]; v[2] += beta * c23[0]; v[3] += beta * c23[1];
+        }
+        *reinterpret_cast<v2f64*>(cp) = v2f64{v[0], v[1]};
+        *reinterpret_cast<v2f64*>(cp + 2) = v2f64{v[2], v[3]};
+      } else {
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+          if (nb + tj < N) {
+            double v = alpha * acc[ti][tj][r];
+            if (beta != 0.0) v += beta * cp[tj];
+            cp[tj] = v;
+          }
+      }
+    }
+}
+
+bool gemm_f64_big_eligible(bool tA, bool tB, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
+                           const double* B, int64_t ldb, const double* C, int64_t ldc) {
+  (void)tA; (void)tB;
+  if (K % DK != 0 || K < 64) return false;
+  if (M < 128 || N < 128) return false;
+  static const int64_t min_tiles = [] { const char* e = getenv("CCZ_GEMM_BIG_MIN_TILES"); return e ? atoll(e) : 32LL; }();
+  static const int64_t min_k = [] { const char* e = getenv("CCZ_GEMM_BIG_MIN_K"); return e ? atoll(e) : 64LL; }();
+  if (K < min_k) return false;
+  if ((M + DT - 1) / DT * ((N + DT - 1) / DT) < min_tiles) return false;
+  if ((lda | ldb | ldc) & 1) return false;
+  if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(C)) & 15) return false;
+  if ((M + DT - 1) / DT > 65535) return false;
+  return true;
+}
+
+void gemm_f64_big(ccz_ctx* c, bool tA, bool tB, int64_t M, int64_t N, int64_t K, double alpha, const double* A,
+                  int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, bool lower_only) {
+  const size_t lds_bytes = size_t(2) * 2 * DK * DS * 8;   // 65 KiB
+  dim3 grid((unsigned)((N + DT - 1) / DT), (unsigned)((M + DT - 1) / DT));
+  hipStream_t st = stream(c);
+  const int lo = lower_only ? 1 : 0;
+#define CCZ_LAUNCH_BIG(TA_, TB_)                                                                                  \
+  do {                                                                                                            \
+    CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_f64_big<TA_, TB_>),                         \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));                     \
+    hipLaunchKernelGGL((k_gemm_f64_big<TA_, TB_>), grid, dim3(256), lds_bytes, st, M, N, K, alpha, A, lda, B, ldb, \
+                       beta, C, ldc, lo);                                                                         \
+  } while (0)
+  if (!tA && !tB) CCZ_LAUNCH_BIG(false, false);
+  else if (tA && !tB) CCZ_LAUNCH_BIG(true, false);
+  else if (!tA && tB) CCZ_LAUNCH_BIG(false, true);
+  else CCZ_LAUNCH_BIG(true, true);
+#undef CCZ_LAUNCH_BIG
+  CCZ_LAUNCH_CHECK();
+}
+
+}  // namespace ccz

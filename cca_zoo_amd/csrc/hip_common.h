@@ -15,9 +15,21 @@ struct PoolBlock {
   bool used;
 };
 
+struct GraphEntry {
+  uint64_t key;
+  hipGraphExec_t exec;
+  uint64_t tick;
+};
+
 struct Impl {
   hipDeviceProp_t props;
   std::vector<PoolBlock> pool;
+  // launch-bound fixed-shape sequences (blocked Cholesky / triangular solves: hundreds of tiny kernels)
+  // are captured once per (shape, pointers) into a hipGraph and replayed
+  std::vector<GraphEntry> graphs;
+  uint64_t tick = 0;
+  int graphs_on = 1;
+  hipStream_t own_stream = nullptr;   // the handle's default stream (blocking: ordered with the null stream)
   hipEvent_t ev[4];
   int* d_flag = nullptr;      // small device scratch: ints
   double* d_small = nullptr;  // small device scratch: 64K doubles
@@ -51,5 +63,11 @@ bool gemm_f32_big_eligible(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t
                            const void* C);
 void gemm_f32_big(ccz_ctx* c, int64_t M, int64_t N, int64_t K, double alpha, const float* A, int64_t lda,
                   const double* B, int64_t ldb, double beta, float* C, int64_t ldc, const double* bias_row);
+
+// gemm64_big.hip: 128x128-tile fp64 GEMM (solver stage)
+bool gemm_f64_big_eligible(bool tA, bool tB, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
+                           const double* B, int64_t ldb, const double* C, int64_t ldc);
+void gemm_f64_big(ccz_ctx* c, bool tA, bool tB, int64_t M, int64_t N, int64_t K, double alpha, const double* A,
+                  int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, bool lower_only);
 
 }  // namespace ccz

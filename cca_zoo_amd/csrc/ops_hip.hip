@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "hip_common.h"
@@ -258,6 +259,10 @@ static void gemm_launch(ccz_ctx* c, bool tA, bool tB, int64_t M, int64_t N, int6
 
 void gemm(ccz_ctx* c, bool tA, bool tB, int64_t M, int64_t N, int64_t K, double alpha, const double* A,
           int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc) {
+  if (gemm_f64_big_eligible(tA, tB, M, N, K, A, lda, B, ldb, C, ldc)) {
+    gemm_f64_big(c, tA, tB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, false);
+    return;
+  }
   // split very tall outputs so that grid.y stays legal
   const int64_t maxM = int64_t(65535) * GB;
   for (int64_t m = 0; m < M; m += maxM) {
@@ -270,6 +275,10 @@ void gemm(ccz_ctx* c, bool tA, bool tB, int64_t M, int64_t N, int64_t K, double 
 void gemm_ex(ccz_ctx* c, bool tA, bool tB, int64_t M, int64_t N, int64_t K, double alpha, const double* A,
              int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, double* C2,
              int64_t ldc2, bool lower_only) {
+  if (!C2 && gemm_f64_big_eligible(tA, tB, M, N, K, A, lda, B, ldb, C, ldc)) {
+    gemm_f64_big(c, tA, tB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, lower_only);
+    return;
+  }
   const int64_t maxM = int64_t(65535) * GB;
   if (M > maxM) fail(CCZ_EUNSUP, "gemm_ex: M too large");
   gemm_launch<double, double>(c, tA, tB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, nullptr, C2, ldc2, lower_only);
@@ -745,7 +754,180 @@ static void diag_inverses(ccz_ctx* c, const double* L, int64_t ldl, int64_t d, d
   CCZ_LAUNCH_CHECK();
 }
 
-void potrf_lower_batched(ccz_ctx* c, int count, double* const* A, const int64_t* d, const int64_t* lda, int* info) {
+// ---------------------------------------------------------------------------
+// Recursive blocked Cholesky / triangular solves.  The recursion halves the block until it reaches
+// the 64-column base case (the wave kernel above, which also leaves L_jj^-T in `invT`); every update
+// above the base case is a GEMM whose inner dimension is half the current block, so nearly all flops
+// run at K >= 128 on the 128x128-tile kernel instead of K = 64 rank updates (memory bound).
+// `invT` holds one 64 x 64 block per 64 columns of the matrix.
+// ---------------------------------------------------------------------------
+static int64_t split_point(int64_t n) {   // multiple of NB closest to n / 2 (at least NB)
+  const int64_t blocks = (n + NB - 1) / NB;
+  return std::max<int64_t>(1, blocks / 2) * NB;
+}
+
+// X (r x n) <- X L^-T (trans) or X L^-1 (!trans); L = lower n x n block whose diagonal 64-blocks have their
+// L^-T in invT[0 .. ceil(n/64))
+static void trsm_rec(ccz_ctx* c, bool trans, int64_t r, int64_t n, const double* L, int64_t ldl, const double* invT,
+                     double* X, int64_t ldx, double* tmp) {
+  if (n <= NB) {
+    gemm_ex(c, false, !trans, r, n, n, 1.0, X, ldx, invT, NB, 0.0, tmp, NB, X, ldx, false);
+    return;
+  }
+  const int64_t h = split_point(n), t = n - h;
+  const double* L21 = L + h * ldl;
+  const double* L22 = L + h * ldl + h;
+  const double* inv2 = invT + (h / NB) * NB * NB;
+  if (trans) {   // [X1 X2] [L11' L21'; 0 L22'] = [B1 B2]
+    trsm_rec(c, true, r, h, L, ldl, invT, X, ldx, tmp);
+    gemm(c, false, true, r, t, h, -1.0, X, ldx, L21, ldl, 1.0, X + h, ldx);          // B2 -= X1 L21'
+    trsm_rec(c, true, r, t, L22, ldl, inv2, X + h, ldx, tmp);
+  } else {       // [X1 X2] [L11 0; L21 L22] = [B1 B2]
+    trsm_rec(c, false, r, t, L22, ldl, inv2, X + h, ldx, tmp);
+    gemm(c, false, false, r, h, t, -1.0, X + h, ldx, L21, ldl, 1.0, X, ldx);          // B1 -= X2 L21
+    trsm_rec(c, false, r, h, L, ldl, invT, X, ldx, tmp);
+  }
+}
+
+struct PotrfJob {
+  double* A;
+  int64_t lda, d;
+  double* invT;   // ceil(d / 64) blocks
+  double* tmp;    // d x 64 scratch for the base-case dual-destination products
+};
+
+// factor the diagonal range [j0, j0 + n) of every job (all jobs share the recursion shape of the largest)
+static void potrf_rec(ccz_ctx* c, std::vector<PotrfJob>& jobs, int64_t j0, int64_t n, int* d_info) {
+  if (n <= NB) {
+    CholBatch bt;
+    const int nb = int(jobs.size());
+    for (int i = 0; i < MAXB; ++i) {
+      const PotrfJob& jb = jobs[std::min(i, nb - 1)];
+      bt.A[i] = jb.A;
+      bt.lda[i] = jb.lda;
+      bt.d[i] = i < nb ? jb.d : 0;
+      bt.invT[i] = jb.invT + (j0 / NB) * NB * NB;
+    }
+    hipLaunchKernelGGL(k_wave_chol_inv_batched, dim3(nb), dim3(64), 0, stream(c), bt, j0, d_info);
+    CCZ_LAUNCH_CHECK();
+    return;
+  }
+  const int64_t h = split_point(n), t = n - h;
+  potrf_rec(c, jobs, j0, h, d_info);
+  for (PotrfJob& jb : jobs) {
+    const int64_t hi = std::min(j0 + n, jb.d);
+    if (hi <= j0 + h) continue;
+    const int64_t tt = hi - (j0 + h);
+    double* A11 = jb.A + j0 * jb.lda + j0;
+    double* A21 = jb.A + (j0 + h) * jb.lda + j0;
+    double* A22 = jb.A + (j0 + h) * jb.lda + (j0 + h);
+    trsm_rec(c, true, tt, h, A11, jb.lda, jb.invT + (j0 / NB) * NB * NB, A21, jb.lda, jb.tmp);      // L21 = A21 L11^-T
+    gemm_ex(c, false, true, tt, tt, h, -1.0, A21, jb.lda, A21, jb.lda, 1.0, A22, jb.lda, nullptr, 0, true);  // A22 -= L21 L21'
+  }
+  (void)t;
+  potrf_rec(c, jobs, j0 + h, n - h, d_info);
+}
+
+static void potrf_lower_batched_rec(ccz_ctx* c, int count, double* const* A, const int64_t* d, const int64_t* lda, int* info) {
+  Impl* im = impl(c);
+  for (int b0 = 0; b0 < count; b0 += MAXB) {
+    const int nbt = std::min(MAXB, count - b0);
+    int big[MAXB];
+    for (int i = 0; i < MAXB; ++i) big[i] = 0x7fffffff;
+    CCZ_HIP(hipMemcpyAsync(im->d_flag + 8, big, sizeof(big), hipMemcpyHostToDevice, stream(c)));
+    CCZ_HIP(hipStreamSynchronize(stream(c)));
+    std::vector<DBuf> bufs;
+    std::vector<PotrfJob> jobs;
+    int64_t dmax = 0;
+    for (int i = 0; i < nbt; ++i) {
+      const int64_t di = d[b0 + i];
+      const int64_t nblk = (di + NB - 1) / NB;
+      bufs.emplace_back(c, nblk * NB * NB);
+      double* inv = bufs.back().get();
+      bufs.emplace_back(c, std::max<int64_t>(di, 1) * NB);
+      jobs.push_back({A[b0 + i], lda[b0 + i], di, inv, bufs.back().get()});
+      dmax = std::max(dmax, di);
+    }
+    // jobs narrower than the widest simply run out of columns (the kernel / loops skip them)
+    potrf_rec(c, jobs, 0, (dmax + NB - 1) / NB * NB, im->d_flag + 8);
+    int got[MAXB];
+    d2h(c, got, im->d_flag + 8, sizeof(got));
+    for (int i = 0; i < nbt; ++i) info[b0 + i] = got[i] == 0x7fffffff ? 0 : got[i];
+  }
+}
+
+int potrf_lower(ccz_ctx* c, double* A, int64_t d, int64_t lda) {
+  int info = 0;
+  double* Ap[1] = {A};
+  potrf_lower_batched(c, 1, Ap, &d, &lda, &info);
+  return info;
+}
+
+static void trsm_right_lower_rec(ccz_ctx* c, bool trans, int64_t r, int64_t d, const double* L, int64_t ldl, double* X,
+                                 int64_t ldx) {
+  const int64_t nblk = (d + NB - 1) / NB;
+  DBuf invT(c, nblk * NB * NB), tmp(c, r * NB);
+  diag_inverses(c, L, ldl, d, invT);
+  trsm_rec(c, trans, r, d, L, ldl, invT, X, ldx, tmp);
+}
+
+
+// ---------------------------------------------------------------------------
+// hipGraph replay of fixed-shape launch sequences.  `fn` must only enqueue work on the handle's stream
+// (no allocation, no synchronisation, no host reads); the key must cover every value baked into the
+// kernel arguments (shapes AND pointers).
+// ---------------------------------------------------------------------------
+static inline uint64_t key_mix(uint64_t h, uint64_t v) { return h ^ (v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2)); }
+static inline uint64_t key_ptr(uint64_t h, const void* p) { return key_mix(h, reinterpret_cast<uint64_t>(p)); }
+
+template <typename F>
+static void graph_run(ccz_ctx* c, uint64_t key, F&& fn) {
+  Impl* im = impl(c);
+  hipStream_t st = stream(c);
+  if (!im->graphs_on || st == nullptr) { fn(); return; }
+  for (auto& g : im->graphs)
+    if (g.key == key) {
+      g.tick = ++im->tick;
+      CCZ_HIP(hipGraphLaunch(g.exec, st));
+      return;
+    }
+  if (hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) != hipSuccess) {
+    (void)hipGetLastError();
+    im->graphs_on = 0;
+    fn();
+    return;
+  }
+  hipGraph_t graph = nullptr;
+  try {
+    fn();
+  } catch (...) {
+    (void)hipStreamEndCapture(st, &graph);
+    if (graph) (void)hipGraphDestroy(graph);
+    throw;
+  }
+  CCZ_HIP(hipStreamEndCapture(st, &graph));
+  hipGraphExec_t exec = nullptr;
+  if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipGraphDestroy(graph);
+    im->graphs_on = 0;
+    fn();       // nothing ran during capture: run it for real
+    return;
+  }
+  (void)hipGraphDestroy(graph);
+  if (im->graphs.size() >= 96) {   // evict the least recently used
+    size_t lru = 0;
+    for (size_t i = 1; i < im->graphs.size(); ++i)
+      if (im->graphs[i].tick < im->graphs[lru].tick) lru = i;
+    (void)hipGraphExecDestroy(im->graphs[lru].exec);
+    im->graphs.erase(im->graphs.begin() + lru);
+  }
+  im->graphs.push_back({key, exec, ++im->tick});
+  CCZ_HIP(hipGraphLaunch(exec, st));
+}
+
+// ---- iterative (one 64-column panel at a time) variants: fewer, smaller launches ----
+static void potrf_lower_batched_iter(ccz_ctx* c, int count, double* const* A, const int64_t* d, const int64_t* lda, int* info) {
   Impl* im = impl(c);
   for (int b0 = 0; b0 < count; b0 += MAXB) {
     const int nbt = std::min(MAXB, count - b0);
@@ -769,41 +951,48 @@ void potrf_lower_batched(ccz_ctx* c, int count, double* const* A, const int64_t*
       bt.invT[i] = invT.back().get();
       dmax = std::max(dmax, d[b0 + i]);
     }
-    for (int64_t j = 0; j < dmax; j += NB) {
-      hipLaunchKernelGGL(k_wave_chol_inv_batched, dim3(nbt), dim3(64), 0, stream(c), bt, j, im->d_flag + 8);
-      CCZ_LAUNCH_CHECK();
-      for (int i = 0; i < nbt; ++i) {
-        const int64_t di = d[b0 + i], ld = lda[b0 + i];
-        if (j >= di) continue;
-        const int nb = int(std::min<int64_t>(NB, di - j));
-        const int64_t rem = di - j - nb;
-        if (rem <= 0) continue;
-        double* Ab = A[b0 + i];
-        double* A21 = Ab + (j + nb) * ld + j;
-        // L21 = A21 L11^-T to the scratch panel and (second destination) back in place: a workgroup reads
-        // only its own 64 rows of A21 (all of K) before it writes them
-        gemm_ex(c, false, false, rem, nb, nb, 1.0, A21, ld, invT[i], NB, 0.0, tmp[i], NB, A21, ld, false);
-        gemm_ex(c, false, true, rem, rem, nb, -1.0, tmp[i], NB, tmp[i], NB, 1.0, Ab + (j + nb) * ld + (j + nb), ld, nullptr, 0, true);
-      }
+    uint64_t key = key_mix(0x504f545246ull, uint64_t(nbt));
+    for (int i = 0; i < nbt; ++i) {
+      key = key_ptr(key, A[b0 + i]);
+      key = key_mix(key_mix(key, uint64_t(d[b0 + i])), uint64_t(lda[b0 + i]));
+      key = key_ptr(key_ptr(key, invT[i].get()), tmp[i].get());
     }
+    graph_run(c, key, [&] {
+      for (int64_t j = 0; j < dmax; j += NB) {
+        hipLaunchKernelGGL(k_wave_chol_inv_batched, dim3(nbt), dim3(64), 0, stream(c), bt, j, im->d_flag + 8);
+        CCZ_LAUNCH_CHECK();
+        for (int i = 0; i < nbt; ++i) {
+          const int64_t di = d[b0 + i], ld = lda[b0 + i];
+          if (j >= di) continue;
+          const int nb = int(std::min<int64_t>(NB, di - j));
+          const int64_t rem = di - j - nb;
+          if (rem <= 0) continue;
+          double* Ab = A[b0 + i];
+          double* A21 = Ab + (j + nb) * ld + j;
+          // L21 = A21 L11^-T to the scratch panel and (second destination) back in place: a workgroup reads
+          // only its own 64 rows of A21 (all of K) before it writes them
+          gemm_ex(c, false, false, rem, nb, nb, 1.0, A21, ld, invT[i], NB, 0.0, tmp[i], NB, A21, ld, false);
+          gemm_ex(c, false, true, rem, rem, nb, -1.0, tmp[i], NB, tmp[i], NB, 1.0, Ab + (j + nb) * ld + (j + nb), ld, nullptr, 0, true);
+        }
+      }
+    });
     int got[MAXB];
     d2h(c, got, im->d_flag + 8, sizeof(got));
     for (int i = 0; i < nbt; ++i) info[b0 + i] = got[i] == 0x7fffffff ? 0 : got[i];
   }
 }
 
-int potrf_lower(ccz_ctx* c, double* A, int64_t d, int64_t lda) {
-  int info = 0;
-  double* Ap[1] = {A};
-  potrf_lower_batched(c, 1, Ap, &d, &lda, &info);
-  return info;
-}
 
-void trsm_right_lower(ccz_ctx* c, bool trans, int64_t r, int64_t d, const double* L, int64_t ldl, double* X,
+static void trsm_right_lower_iter(ccz_ctx* c, bool trans, int64_t r, int64_t d, const double* L, int64_t ldl, double* X,
                       int64_t ldx) {
   if (r <= 0 || d <= 0) return;
   const int64_t nblk = (d + NB - 1) / NB;
   DBuf invT(c, nblk * NB * NB), tmp(c, r * NB);
+  uint64_t key = key_mix(0x5452534dull, uint64_t(trans));
+  key = key_mix(key_mix(key, uint64_t(r)), uint64_t(d));
+  key = key_mix(key_mix(key_ptr(key_ptr(key, L), X), uint64_t(ldl)), uint64_t(ldx));
+  key = key_ptr(key_ptr(key, invT.get()), tmp.get());
+  graph_run(c, key, [&] {
   diag_inverses(c, L, ldl, d, invT);
   if (trans) {
     // X L' = B, forward over column blocks:  X_j = (B_j - sum_{t<j} X_t L_jt') L_jj^-T
@@ -825,6 +1014,31 @@ void trsm_right_lower(ccz_ctx* c, bool trans, int64_t r, int64_t d, const double
         gemm(c, false, false, r, j, nb, -1.0, tmp, NB, L + j * ldl, ldl, 1.0, X, ldx);
     }
   }
+  });
+}
+
+
+// Dispatch: the recursive forms put the flops into large-K GEMMs but issue ~40% more (tiny) launches;
+// they pay off once the matrices are big enough for the GEMMs to dominate the launch latency.
+static int solver_mode() {
+  static const int m = [] { const char* e = getenv("CCZ_SOLVER_RECURSIVE"); return e ? atoi(e) : -1; }();
+  return m;   // -1: automatic, 0: iterative, 1: recursive
+}
+
+void potrf_lower_batched(ccz_ctx* c, int count, double* const* A, const int64_t* d, const int64_t* lda, int* info) {
+  int64_t dmax = 0;
+  for (int i = 0; i < count; ++i) dmax = std::max(dmax, d[i]);
+  const int mode = solver_mode();
+  if (mode == 1 || (mode < 0 && dmax >= 6144)) potrf_lower_batched_rec(c, count, A, d, lda, info);
+  else potrf_lower_batched_iter(c, count, A, d, lda, info);
+}
+
+void trsm_right_lower(ccz_ctx* c, bool trans, int64_t r, int64_t d, const double* L, int64_t ldl, double* X,
+                      int64_t ldx) {
+  if (r <= 0 || d <= 0) return;
+  const int mode = solver_mode();
+  if (mode == 1 || (mode < 0 && d >= 2048 && r >= 6144)) trsm_right_lower_rec(c, trans, r, d, L, ldl, X, ldx);
+  else trsm_right_lower_iter(c, trans, r, d, L, ldl, X, ldx);
 }
 
 // ===========================================================================
