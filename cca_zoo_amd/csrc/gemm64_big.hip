@@ -76,7 +76,8 @@ template <bool TA, bool TB>
 __global__ __launch_bounds__(256, 2) void k_gemm_f64_big(int64_t M, int64_t N, int64_t K, double alpha,
                                                          const double* __restrict__ A, int64_t lda,
                                                          const double* __restrict__ B, int64_t ldb, double beta,
-                                                         double* __restrict__ C, int64_t ldc, int lower_only) {
+                                                         double* __restrict__ C, int64_t ldc, int lower_only,
+                                                         int64_t k_per_split) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* lds = reinterpret_cast<double*>(smem);  // [2 buffers][A | B][16][DS]
   const int64_t m0 = int64_t(blockIdx.y) * DT, n0 = int64_t(blockIdx.x) * DT;
@@ -95,17 +96,21 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64_big(int64_t M, int64_t N, i
   // A is k-major in memory iff TA (stored K x M); B is k-major iff !TB (stored K x N)
   Stager<TA> sa;
   Stager<!TB> sb;
-  const int64_t nkb = K / DK;
-  sa.load(A, lda, m0, M, 0, tid);
-  sb.load(B, ldb, n0, N, 0, tid);
+  // split-K: slice z accumulates its K range into C with fp64 atomics (the launcher pre-scaled C by beta)
+  const bool split = gridDim.z > 1;
+  const int64_t kz0 = int64_t(blockIdx.z) * k_per_split;
+  const int64_t nkb = (min(K, kz0 + k_per_split) - kz0) / DK;
+  if (nkb <= 0) return;
+  sa.load(A, lda, m0, M, kz0, tid);
+  sb.load(B, ldb, n0, N, kz0, tid);
   sa.store(lds, tid);
   sb.store(lds + DK * DS, tid);
   __syncthreads();
   for (int64_t kb = 0; kb < nkb; ++kb) {
     const int cur = int(kb & 1);
     if (kb + 1 < nkb) {
-      sa.load(A, lda, m0, M, (kb + 1) * DK, tid);
-      sb.load(B, ldb, n0, N, (kb + 1) * DK, tid);
+      sa.load(A, lda, m0, M, kz0 + (kb + 1) * DK, tid);
+      sb.load(B, ldb, n0, N, kz0 + (kb + 1) * DK, tid);
     }
     const double* as = lds + cur * (2 * DK * DS);
     const double* bs = as + DK * DS;
@@ -141,7 +146,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64_big(int64_t M, int64_t N, i
       if (m >= M) continue;
       const int64_t nb = n0 + wc * 64 + 4 * (lane & 15);
       double* cp = C + m * ldc + nb;
-      if (nb + 3 < N) {
+      if (split) {
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+          if (nb + tj < N) unsafeAtomicAdd(cp + tj, alpha * acc[ti][tj][r]);
+      } else if (nb + 3 < N) {
         v4f64 v = {acc[ti][0][r], acc[ti][1][r], acc[ti][2][r], acc[ti][3][r]};
         v *= alpha;
         if (beta != 0.0) {
@@ -162,33 +171,62 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64_big(int64_t M, int64_t N, i
     }
 }
 
+static int64_t env_ll(const char* name, int64_t dflt) {
+  const char* e = getenv(name);
+  return e ? atoll(e) : dflt;
+}
+
+// Shapes the 128x128-tile kernel takes: products with at least 128 rows and columns and enough tiles.
+// Products with few tiles and deep K (subspace-iteration applies S X with 128 <= N < 256) run split-K.
+// Narrower outputs (N < 128) stay on the 64x64-tile kernel: measured 23 vs 15 TFLOP/s at N = 80.
 bool gemm_f64_big_eligible(bool tA, bool tB, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
                            const double* B, int64_t ldb, const double* C, int64_t ldc) {
   (void)tA; (void)tB;
-  if (K % DK != 0 || K < 64) return false;
-  if (M < 128 || N < 128) return false;
-  static const int64_t min_tiles = [] { const char* e = getenv("CCZ_GEMM_BIG_MIN_TILES"); return e ? atoll(e) : 32LL; }();
-  static const int64_t min_k = [] { const char* e = getenv("CCZ_GEMM_BIG_MIN_K"); return e ? atoll(e) : 64LL; }();
-  if (K < min_k) return false;
-  if ((M + DT - 1) / DT * ((N + DT - 1) / DT) < min_tiles) return false;
+  static const int64_t min_tiles = env_ll("CCZ_GEMM_BIG_MIN_TILES", 32);
+  static const int64_t min_k = env_ll("CCZ_GEMM_BIG_MIN_K", 64);
+  if (K % DK != 0 || K < min_k) return false;
   if ((lda | ldb | ldc) & 1) return false;
   if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(C)) & 15) return false;
   if ((M + DT - 1) / DT > 65535) return false;
-  return true;
+  const int64_t tiles = (M + DT - 1) / DT * ((N + DT - 1) / DT);
+  if (M >= 128 && N >= 128 && tiles >= min_tiles) return true;
+  return false;
+}
+
+__global__ void k_scale2d_f64(int64_t total, int64_t cols, double* __restrict__ A, int64_t lda, double beta) {
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += int64_t(gridDim.x) * blockDim.x) {
+    const int64_t r = i / cols, cc = i - r * cols;
+    A[r * lda + cc] = beta == 0.0 ? 0.0 : beta * A[r * lda + cc];
+  }
 }
 
 void gemm_f64_big(ccz_ctx* c, bool tA, bool tB, int64_t M, int64_t N, int64_t K, double alpha, const double* A,
                   int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, bool lower_only) {
   const size_t lds_bytes = size_t(2) * 2 * DK * DS * 8;   // 65 KiB
-  dim3 grid((unsigned)((N + DT - 1) / DT), (unsigned)((M + DT - 1) / DT));
   hipStream_t st = stream(c);
+  const int64_t tm = (M + DT - 1) / DT, tn = (N + DT - 1) / DT;
+  const int ncu = std::max(1, impl(c)->props.multiProcessorCount);
+  int splits = 1;
+  if (!lower_only && tm * tn < 2 * int64_t(ncu) && K >= 2048) {
+    splits = int(std::min<int64_t>({int64_t(16), (4 * ncu) / (tm * tn), K / 512}));
+    if (splits < 2) splits = 1;
+  }
+  int64_t kps = K;
+  if (splits > 1) {
+    kps = ((K + splits - 1) / splits + DK - 1) / DK * DK;
+    splits = int((K + kps - 1) / kps);
+    const int64_t total = M * N;
+    hipLaunchKernelGGL(k_scale2d_f64, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 1 << 20)), dim3(256), 0, st,
+                       total, N, C, ldc, beta);
+  }
+  dim3 grid((unsigned)tn, (unsigned)tm, (unsigned)splits);
   const int lo = lower_only ? 1 : 0;
 #define CCZ_LAUNCH_BIG(TA_, TB_)                                                                                  \
   do {                                                                                                            \
     CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_f64_big<TA_, TB_>),                         \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));                     \
     hipLaunchKernelGGL((k_gemm_f64_big<TA_, TB_>), grid, dim3(256), lds_bytes, st, M, N, K, alpha, A, lda, B, ldb, \
-                       beta, C, ldc, lo);                                                                         \
+                       beta, C, ldc, lo, kps);                                                                    \
   } while (0)
   if (!tA && !tB) CCZ_LAUNCH_BIG(false, false);
   else if (tA && !tB) CCZ_LAUNCH_BIG(true, false);
