@@ -13,6 +13,7 @@ using namespace ccz;
 #define CCZ_GUARD(h, ...)                   \
   if (!(h)) return CCZ_EINVAL;              \
   try {                                     \
+    ::ccz::activate(h);                     \
     __VA_ARGS__;                            \
     return CCZ_OK;                          \
   } catch (const ccz::Error& e) {           \
@@ -195,7 +196,6 @@ const char* ccz_last_error(ccz_handle h) { return h ? h->err.c_str() : "null han
 
 int ccz_set_stream(ccz_handle h, void* s) {
   CCZ_GUARD(h, {
-    CCZ_HIP(hipSetDevice(h->device));
     CCZ_HIP(hipStreamSynchronize(stream(h)));
     h->stream = s;
   })
@@ -220,7 +220,6 @@ int ccz_device_info(ccz_handle h, ccz_devinfo* out) {
 int ccz_dev_alloc(ccz_handle h, void** out, size_t bytes) {
   CCZ_GUARD(h, {
     if (!out) fail(CCZ_EINVAL, "null argument");
-    CCZ_HIP(hipSetDevice(h->device));
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, bytes ? bytes : 8);
     if (e != hipSuccess) { (void)hipGetLastError(); fail(CCZ_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
@@ -244,7 +243,6 @@ int ccz_memset0(ccz_handle h, void* dst, size_t bytes) { CCZ_GUARD(h, zero(h, ds
 int ccz_moments(ccz_handle h, int dtype, const ccz_view* views, int n_views, int64_t n_rows, int views_on_device,
                 double* moments_dev, int accumulate) {
   CCZ_GUARD(h, {
-    CCZ_HIP(hipSetDevice(h->device));
     moments_impl(h, dtype, views, n_views, n_rows, views_on_device != 0, moments_dev, accumulate != 0);
   })
 }
@@ -283,7 +281,6 @@ int ccz_cca_loss(ccz_handle h, int dtype, const void* z1_dev, const void* z2_dev
                  int64_t ld1, int64_t ld2, double eps, void* loss_dev, void* g1_dev, void* g2_dev, int64_t ldg1,
                  int64_t ldg2) {
   CCZ_GUARD(h, {
-    CCZ_HIP(hipSetDevice(h->device));
     cca_loss_impl(h, dtype, z1_dev, z2_dev, n, d1, d2, ld1, ld2, eps, loss_dev, g1_dev, g2_dev, ldg1, ldg2);
   })
 }
@@ -291,7 +288,6 @@ int ccz_cca_loss(ccz_handle h, int dtype, const void* z1_dev, const void* z2_dev
 int ccz_transform(ccz_handle h, int dtype, const void* X_dev, int64_t n, int64_t d, int64_t ld, const double* mean_dev,
                   const double* W_dev, int64_t k, void* out_dev, int64_t ldo) {
   CCZ_GUARD(h, {
-    CCZ_HIP(hipSetDevice(h->device));
     transform_impl(h, dtype, X_dev, n, d, ld, mean_dev, W_dev, k, out_dev, ldo);
   })
 }

@@ -44,6 +44,7 @@ void d2h(ccz_ctx* c, void* dst, const void* src, size_t bytes);  // synchronises
 void d2d(ccz_ctx* c, void* dst, const void* src, size_t bytes);
 void zero(ccz_ctx* c, void* dst, size_t bytes);
 void sync(ccz_ctx* c);
+void activate(ccz_ctx* c);  // make the handle's device current on the calling thread (every ABI entry)
 
 // RAII device buffer of doubles
 class DBuf {

@@ -79,6 +79,7 @@ void zero(ccz_ctx* c, void* dst, size_t bytes) {
   CCZ_HIP(hipMemsetAsync(dst, 0, bytes, stream(c)));
 }
 void sync(ccz_ctx* c) { CCZ_HIP(hipStreamSynchronize(stream(c))); }
+void activate(ccz_ctx* c) { CCZ_HIP(hipSetDevice(c->device)); }
 
 // ===========================================================================
 // GEMM on the matrix pipe: 64x64 block tile, 4 waves (2x2), each wave 2x2 MFMA 16x16x4
@@ -1198,11 +1199,17 @@ int jacobi_rows(ccz_ctx* c, int64_t p, int64_t q, double* W, int64_t ldw, double
   dim3 grid((unsigned)(pe / 2));
   for (int sweep = 1; sweep <= max_sweeps; ++sweep) {
     CCZ_HIP(hipMemsetAsync(im->d_flag + 1, 0, sizeof(int), stream(c)));
-    for (int64_t round = 0; round < pe - 1; ++round) {
-      if (small) hipLaunchKernelGGL(k_jacobi_round<64>, grid, dim3(64), 0, stream(c), p, pe, q, W, ldw, Q, qc, ldq, round, tol, floor2, im->d_flag + 1);
-      else hipLaunchKernelGGL(k_jacobi_round<256>, grid, dim3(256), 0, stream(c), p, pe, q, W, ldw, Q, qc, ldq, round, tol, floor2, im->d_flag + 1);
-    }
-    CCZ_LAUNCH_CHECK();
+    // one sweep = pe - 1 dependent tiny launches: replayed as a hipGraph after the first sweep
+    uint64_t key = key_mix(key_mix(0x4a41434full, uint64_t(p)), uint64_t(q));
+    key = key_mix(key_mix(key_ptr(key_ptr(key, W), Q), uint64_t(ldw)), uint64_t(ldq));
+    key = key_mix(key_mix(key, uint64_t(qc)), uint64_t(floor2 * 1e300));
+    graph_run(c, key, [&] {
+      for (int64_t round = 0; round < pe - 1; ++round) {
+        if (small) hipLaunchKernelGGL(k_jacobi_round<64>, grid, dim3(64), 0, stream(c), p, pe, q, W, ldw, Q, qc, ldq, round, tol, floor2, im->d_flag + 1);
+        else hipLaunchKernelGGL(k_jacobi_round<256>, grid, dim3(256), 0, stream(c), p, pe, q, W, ldw, Q, qc, ldq, round, tol, floor2, im->d_flag + 1);
+      }
+      CCZ_LAUNCH_CHECK();
+    });
     int rot = 0;
     d2h(c, &rot, im->d_flag + 1, sizeof(int));
     if (rot == 0) return sweep;

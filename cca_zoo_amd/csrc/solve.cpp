@@ -765,6 +765,7 @@ static void gcca_solve_impl(ccz_ctx* c, const double* mom, int64_t n, const int6
 #define CCZ_GUARD(h, ...)                                              \
   if (!(h)) return CCZ_EINVAL;                                         \
   try {                                                                \
+    ::ccz::activate(h);                                                \
     __VA_ARGS__;                                                       \
     return CCZ_OK;                                                     \
   } catch (const ccz::Error& e) {                                      \
