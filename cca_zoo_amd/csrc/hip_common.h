@@ -70,4 +70,10 @@ bool gemm_f64_big_eligible(bool tA, bool tB, int64_t M, int64_t N, int64_t K, co
 void gemm_f64_big(ccz_ctx* c, bool tA, bool tB, int64_t M, int64_t N, int64_t K, double alpha, const double* A,
                   int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, bool lower_only);
 
+// gemm64_skinny.hip: 128-row stripes x all N <= 192 columns (subspace-iteration applies)
+bool gemm_f64_skinny_eligible(bool tA, bool tB, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
+                              const double* B, int64_t ldb);
+void gemm_f64_skinny(ccz_ctx* c, bool tA, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda,
+                     const double* B, int64_t ldb, double beta, double* C, int64_t ldc);
+
 }  // namespace ccz

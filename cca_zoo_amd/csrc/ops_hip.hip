@@ -260,6 +260,10 @@ static void gemm_launch(ccz_ctx* c, bool tA, bool tB, int64_t M, int64_t N, int6
 
 void gemm(ccz_ctx* c, bool tA, bool tB, int64_t M, int64_t N, int64_t K, double alpha, const double* A,
           int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc) {
+  if (gemm_f64_skinny_eligible(tA, tB, M, N, K, A, lda, B, ldb)) {
+    gemm_f64_skinny(c, tA, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
+    return;
+  }
   if (gemm_f64_big_eligible(tA, tB, M, N, K, A, lda, B, ldb, C, ldc)) {
     gemm_f64_big(c, tA, tB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, false);
     return;
@@ -276,6 +280,10 @@ void gemm(ccz_ctx* c, bool tA, bool tB, int64_t M, int64_t N, int64_t K, double 
 void gemm_ex(ccz_ctx* c, bool tA, bool tB, int64_t M, int64_t N, int64_t K, double alpha, const double* A,
              int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, double* C2,
              int64_t ldc2, bool lower_only) {
+  if (!C2 && !lower_only && gemm_f64_skinny_eligible(tA, tB, M, N, K, A, lda, B, ldb)) {
+    gemm_f64_skinny(c, tA, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
+    return;
+  }
   if (!C2 && gemm_f64_big_eligible(tA, tB, M, N, K, A, lda, B, ldb, C, ldc)) {
     gemm_f64_big(c, tA, tB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, lower_only);
     return;

@@ -37,6 +37,22 @@ def test_gemm_f64(H, tA, tB, M, N, K):
     np.testing.assert_allclose(out, ref, rtol=1e-12, atol=1e-12 * K)
 
 
+@pytest.mark.parametrize("tA", [0, 1])
+@pytest.mark.parametrize("M,N,K,beta", [(2048, 160, 2048, 0.0), (1100, 77, 1024, -1.3), (1537, 192, 4096, 0.5),
+                                        (1024, 49, 1040, 0.0), (4096, 80, 8192, 1.0)])
+def test_gemm_f64_tall_skinny(H, tA, M, N, K, beta):
+    """Stripe kernel of the subspace-iteration applies (gemm64_skinny.hip), incl. split-K and ragged M / N."""
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((K, M) if tA else (M, K))
+    B = rng.standard_normal((K, N))
+    Cm = rng.standard_normal((M, N))
+    ref = 0.7 * (A.T if tA else A) @ B + beta * Cm
+    Ad, Bd, Cd = H.to_device(A), H.to_device(B), H.to_device(Cm)
+    call(H, "ccz_gemm_f64", tA, 0, M, N, K, 0.7, vp(Ad), A.shape[1], vp(Bd), N, beta, vp(Cd), N)
+    out = H.to_host(Cd, (M, N))
+    np.testing.assert_allclose(out, ref, rtol=1e-12, atol=1e-12 * K)
+
+
 def test_gemm_strided_views(H):
     rng = np.random.default_rng(0)
     big = rng.standard_normal((40, 50))

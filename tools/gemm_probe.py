@@ -20,5 +20,6 @@ def run(tA, tB, M, N, K, reps=5):
     ref = (A.T if tA else A) @ (B.T if tB else B)
     err = float((Cm - ref).abs().max() / ref.abs().max())
     print(f"tA={tA} tB={tB} M={M} N={N} K={K}: {dt*1e6:.1f} us  {2.0*M*N*K/dt/1e12:.1f} TFLOP/s  err {err:.1e}", flush=True)
-for shp in [(0,1,2048,2048,2048),(0,0,2048,2048,2048),(1,0,2048,2048,2048),(1,1,2048,2048,2048),(0,1,4096,2048,2048),(0,1,4032,4032,64),(0,1,1024,1024,1024),(0,0,4096,80,4096),(1,0,4096,80,4096),(0,1,8192,8192,4096)]:
+shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
+for shp in shapes or [(0,1,2048,2048,2048),(0,0,2048,2048,2048),(1,0,2048,2048,2048),(1,1,2048,2048,2048),(0,1,4096,2048,2048),(0,1,4032,4032,64),(0,1,1024,1024,1024),(0,0,4096,80,4096),(1,0,4096,80,4096),(0,1,8192,8192,4096)]:
     run(*shp)
