@@ -49,7 +49,7 @@ class BaseModel(BaseEstimator, ABC):
         by the concrete ``fit`` from the column sums of the moments pass.
         """
         self._validate_params()
-        validated = validate_views(views)
+        validated = validate_views(views, check_finite=False)   # checked on the moments (compute_moments)
         self.n_views_ = len(validated)
         self.n_features_in_ = [int(v.shape[1]) for v in validated]
         self.n_samples_ = int(validated[0].shape[0])
@@ -69,10 +69,16 @@ class BaseModel(BaseEstimator, ABC):
         """``(X_i - mean_i) @ W_i`` per view.  Host arrays in -> numpy out (device GEMM inside
         libccz); CUDA tensors in -> CUDA tensors out."""
         check_is_fitted(self)
-        validated = validate_views(views)
+        validated = validate_views(views, check_finite=False)
         out = []
         for v, m, w in zip(validated, self.means_, self.weights_):
-            out.append(_device_project(v, m, w) if is_device_tensor(v) else _host_project(v, m, w))
+            if is_device_tensor(v):
+                out.append(_device_project(v, m, w))
+            else:
+                z = _host_project(v, m, w)
+                if not np.all(np.isfinite(z)):   # NaN / inf rows of the input propagate to the n x k output
+                    raise ValueError("Input contains NaN or infinity.")
+                out.append(z)
         return out
 
     def fit_transform(self, views, y=None) -> list:

@@ -79,5 +79,11 @@ def compute_moments(views, handle=None):
         torch.cuda.current_stream(mom_t.device).synchronize()
         h.moments_unpack(packed.data_ptr(), D, mom_ptr)
         keep.append(packed)
+    # non-finite inputs (NaN / inf anywhere in a column) surface in that column's sum: the reference's
+    # check_array(force_all_finite) ValueError without a host pass over the data
+    sums = h.to_host(mom_ptr, (D,), offset_bytes=D * D * 8)
+    if not np.all(np.isfinite(sums)):
+        bad = int(np.flatnonzero(~np.isfinite(sums))[0])
+        raise ValueError(f"Input contains NaN or infinity (first affected stacked column: {bad}).")
     # no symmetrisation pass: the solvers read the upper triangle (authoritative) on both sides
     return mom_ptr, keep, n_total, dims, kind

@@ -21,8 +21,12 @@ def _n_rows(v) -> int:
     return int(v.shape[0])
 
 
-def validate_views(views, min_views: int = 2) -> list:
+def validate_views(views, min_views: int = 2, check_finite: bool = True) -> list:
     """Return the views as 2-D numpy arrays (or untouched 2-D CUDA tensors).
+
+    ``check_finite=False`` skips sklearn's host-side NaN/inf scan (a single-threaded pass over the
+    whole input, 0.2 s per 4 GB): ``fit`` detects non-finite inputs for free from the column sums of
+    the moments pass and ``transform`` from its n x k output, raising the same ``ValueError``.
 
     Raises:
         ValueError: fewer than ``min_views`` views, or unequal numbers of samples.
@@ -40,7 +44,7 @@ def validate_views(views, min_views: int = 2) -> list:
         else:
             if type(v).__module__.startswith("torch"):
                 v = v.detach().cpu().numpy()
-            out.append(check_array(v, ensure_2d=True, allow_nd=False, dtype="numeric"))
+            out.append(check_array(v, ensure_2d=True, allow_nd=False, dtype="numeric", ensure_all_finite=check_finite))
     n = _n_rows(out[0])
     if not all(_n_rows(v) == n for v in out):
         raise ValueError(

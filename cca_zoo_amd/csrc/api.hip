@@ -184,6 +184,9 @@ int ccz_destroy(ccz_handle h) {
     if (im->own_stream) (void)hipStreamDestroy(im->own_stream);
     for (auto& b : im->pool) (void)hipFree(b.p);
     for (int i = 0; i < 4; ++i) (void)hipEventDestroy(im->ev[i]);
+    for (int i = 0; i < 4; ++i) if (im->pipe_ev[i]) (void)hipEventDestroy(im->pipe_ev[i]);
+    for (int i = 0; i < 2; ++i) if (im->pin_buf[i]) (void)hipHostFree(im->pin_buf[i]);
+    if (im->copy_stream) (void)hipStreamDestroy(im->copy_stream);
     (void)hipFree(im->d_flag);
     (void)hipFree(im->d_small);
     delete im;

@@ -27,6 +27,8 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <thread>
 #include <vector>
 
 #include "hip_common.h"
@@ -551,7 +553,7 @@ struct Panel {
 
 template <typename T>
 void launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, double* G, double* s, int64_t D,
-                    bool time_it) {
+                    bool time_it, void** tile_cache = nullptr) {
   Impl* im = impl(c);
   hipStream_t st = stream(c);
   constexpr bool is32 = sizeof(T) == 4;
@@ -595,8 +597,19 @@ void launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
     }
   }
   const int ntiles = int(tiles.size());
-  GramTile* d_tiles = static_cast<GramTile*>(dev_alloc(c, tiles.size() * sizeof(GramTile)));
-  h2d(c, d_tiles, tiles.data(), tiles.size() * sizeof(GramTile));
+  // the tile table depends only on the views (pointers, widths, strides): pipelined callers keep it on
+  // the device across their chunks (*tile_cache) so that a launch enqueues no host copy and never blocks
+  GramTile* d_tiles;
+  if (tile_cache && *tile_cache) {
+    d_tiles = static_cast<GramTile*>(*tile_cache);
+  } else {
+    d_tiles = static_cast<GramTile*>(dev_alloc(c, tiles.size() * sizeof(GramTile)));
+    h2d(c, d_tiles, tiles.data(), tiles.size() * sizeof(GramTile));
+    if (tile_cache) {
+      CCZ_HIP(hipStreamSynchronize(st));   // `tiles` is a pageable temporary
+      *tile_cache = d_tiles;
+    }
+  }
 
   const int ncu = std::max(1, im->props.multiProcessorCount);
   static const int64_t rows_env = [] { const char* e = getenv("CCZ_GRAM_ROWS"); return e ? atoll(e) : 0LL; }();
@@ -684,8 +697,59 @@ void launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
     c->last_colsum_ms += cs;
   }
   // the tile table must outlive the kernel: stream-ordered, so synchronise before recycling it
+  // (pipelined callers own the table and free it after their final synchronise)
+  if (tile_cache) return;
   CCZ_HIP(hipStreamSynchronize(st));
   dev_free(c, d_tiles);
+}
+
+// pinned bounce buffers + copy stream of the host-input pipeline; false if pinned memory is unavailable
+bool ensure_pipe(ccz_ctx* c, size_t bytes) {
+  Impl* im = impl(c);
+  if (!im->copy_stream) {
+    if (hipStreamCreateWithFlags(&im->copy_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); im->copy_stream = nullptr; return false; }
+    for (int i = 0; i < 4; ++i)
+      if (hipEventCreateWithFlags(&im->pipe_ev[i], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
+  }
+  for (int i = 0; i < 4; ++i) if (!im->pipe_ev[i]) return false;
+  if (im->pin_cap >= bytes) return true;
+  for (int i = 0; i < 2; ++i) {
+    if (im->pin_buf[i]) (void)hipHostFree(im->pin_buf[i]);
+    im->pin_buf[i] = nullptr;
+  }
+  im->pin_cap = 0;
+  for (int i = 0; i < 2; ++i)
+    if (hipHostMalloc(&im->pin_buf[i], bytes, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      for (int j = 0; j < 2; ++j) { if (im->pin_buf[j]) (void)hipHostFree(im->pin_buf[j]); im->pin_buf[j] = nullptr; }
+      return false;
+    }
+  im->pin_cap = bytes;
+  return true;
+}
+
+// rows [r0, r0 + rows) of every view, packed densely view after view into `dst`, by `nthreads` host threads
+void pack_rows(char* dst, const ccz_view* views, int n_views, size_t es, int64_t r0, int64_t rows, int nthreads) {
+  auto work = [&](int64_t a, int64_t b) {
+    size_t off = 0;
+    for (int v = 0; v < n_views; ++v) {
+      const size_t rb = size_t(views[v].cols) * es, ldb = size_t(views[v].ld) * es;
+      const char* src = static_cast<const char*>(views[v].data) + size_t(r0 + a) * ldb;
+      char* d = dst + off + size_t(a) * rb;
+      if (rb == ldb) memcpy(d, src, size_t(b - a) * rb);
+      else for (int64_t r = a; r < b; ++r, src += ldb, d += rb) memcpy(d, src, rb);
+      off += size_t(rows) * rb;
+    }
+  };
+  nthreads = int(std::max<int64_t>(1, std::min<int64_t>(nthreads, rows / 64)));
+  if (nthreads == 1) { work(0, rows); return; }
+  std::vector<std::thread> pool;
+  const int64_t per = (rows + nthreads - 1) / nthreads;
+  for (int t = 0; t < nthreads; ++t) {
+    const int64_t a = t * per, b = std::min<int64_t>(rows, a + per);
+    if (a < b) pool.emplace_back(work, a, b);
+  }
+  for (auto& th : pool) th.join();
 }
 
 }  // namespace
@@ -713,36 +777,71 @@ void moments_impl(ccz_ctx* c, int dtype, const ccz_view* views, int n_views, int
     else launch_moments<double>(c, views, n_views, n_rows, G, s, D, true);
     return;
   }
-  // host-resident views: stream row chunks through a dense device staging area
+  // Host-resident (pageable) views: a three-stage pipeline over ~512 MiB row chunks,
+  //   host threads pack chunk i+1 into a pinned bounce buffer  ||  DMA of chunk i (copy stream)  ||  K1 on chunk i-1,
+  // two slots of pinned + device staging, events between the stages.  Small inputs, or a host that
+  // refuses pinned memory, take the plain copy-then-compute loop.
   int64_t row_bytes = 0;
   for (int v = 0; v < n_views; ++v) row_bytes += views[v].cols * int64_t(es);
-  int64_t chunk = std::max<int64_t>(1, (int64_t(512) << 20) / row_bytes);
+  const int64_t chunk_mb = [] { const char* e = getenv("CCZ_H2D_CHUNK_MB"); return e ? std::max<int64_t>(1, atoll(e)) : 512LL; }();
+  const int n_threads = [] {
+    const char* e = getenv("CCZ_H2D_THREADS");
+    if (e) return std::max(1, atoi(e));
+    return int(std::max(1u, std::min(8u, std::thread::hardware_concurrency())));
+  }();
+  int64_t chunk = std::max<int64_t>(64, (chunk_mb << 20) / row_bytes / 64 * 64);
   chunk = std::min(chunk, n_rows);
-  std::vector<void*> stage(n_views, nullptr);
-  std::vector<ccz_view> dv(n_views);
+  const bool piped = n_rows * row_bytes >= (int64_t(64) << 20) && n_rows > chunk / 2 && ensure_pipe(c, size_t(chunk) * row_bytes);
+  const int nslots = piped ? 2 : 1;
+  Impl* im = impl(c);
+  std::vector<void*> stage(size_t(nslots) * n_views, nullptr);
+  std::vector<ccz_view> dv(size_t(nslots) * n_views);
+  void* tile_tab[2] = {nullptr, nullptr};
+  auto cleanup = [&] {
+    (void)hipStreamSynchronize(stream(c));
+    if (piped) (void)hipStreamSynchronize(im->copy_stream);
+    for (void* p : stage) if (p) dev_free(c, p);
+    for (void* p : tile_tab) if (p) dev_free(c, p);
+  };
   try {
-    for (int v = 0; v < n_views; ++v) {
-      stage[v] = dev_alloc(c, size_t(chunk) * views[v].cols * es);
-      dv[v].data = stage[v];
-      dv[v].cols = views[v].cols;
-      dv[v].ld = views[v].cols;
-    }
-    for (int64_t r0 = 0; r0 < n_rows; r0 += chunk) {
-      const int64_t rows = std::min(chunk, n_rows - r0);
+    for (int sl = 0; sl < nslots; ++sl)
       for (int v = 0; v < n_views; ++v) {
-        const char* src = static_cast<const char*>(views[v].data) + size_t(r0) * views[v].ld * es;
-        CCZ_HIP(hipMemcpy2DAsync(stage[v], size_t(views[v].cols) * es, src, size_t(views[v].ld) * es,
-                                 size_t(views[v].cols) * es, size_t(rows), hipMemcpyHostToDevice, stream(c)));
+        stage[sl * n_views + v] = dev_alloc(c, size_t(chunk) * views[v].cols * es);
+        dv[sl * n_views + v] = ccz_view{stage[sl * n_views + v], views[v].cols, views[v].cols};
       }
-      CCZ_HIP(hipStreamSynchronize(stream(c)));
-      if (dtype == CCZ_F32) launch_moments<float>(c, dv.data(), n_views, rows, G, s, D, true);
-      else launch_moments<double>(c, dv.data(), n_views, rows, G, s, D, true);
+    int64_t ci = 0;
+    for (int64_t r0 = 0; r0 < n_rows; r0 += chunk, ++ci) {
+      const int64_t rows = std::min(chunk, n_rows - r0);
+      const int sl = piped ? int(ci & 1) : 0;
+      if (piped) {
+        if (ci >= 2) CCZ_HIP(hipEventSynchronize(im->pipe_ev[sl]));          // DMA of chunk ci-2 has drained this bounce buffer
+        pack_rows(static_cast<char*>(im->pin_buf[sl]), views, n_views, es, r0, rows, n_threads);
+        if (ci >= 2) CCZ_HIP(hipStreamWaitEvent(im->copy_stream, im->pipe_ev[2 + sl], 0));   // K1 of chunk ci-2 done with this staging slot
+        size_t off = 0;
+        for (int v = 0; v < n_views; ++v) {
+          const size_t bytes = size_t(rows) * views[v].cols * es;
+          CCZ_HIP(hipMemcpyAsync(stage[sl * n_views + v], static_cast<char*>(im->pin_buf[sl]) + off, bytes, hipMemcpyHostToDevice, im->copy_stream));
+          off += bytes;
+        }
+        CCZ_HIP(hipEventRecord(im->pipe_ev[sl], im->copy_stream));
+        CCZ_HIP(hipStreamWaitEvent(stream(c), im->pipe_ev[sl], 0));
+      } else {
+        for (int v = 0; v < n_views; ++v) {
+          const char* src = static_cast<const char*>(views[v].data) + size_t(r0) * views[v].ld * es;
+          CCZ_HIP(hipMemcpy2DAsync(stage[v], size_t(views[v].cols) * es, src, size_t(views[v].ld) * es,
+                                   size_t(views[v].cols) * es, size_t(rows), hipMemcpyHostToDevice, stream(c)));
+        }
+        CCZ_HIP(hipStreamSynchronize(stream(c)));
+      }
+      if (dtype == CCZ_F32) launch_moments<float>(c, &dv[sl * n_views], n_views, rows, G, s, D, false, &tile_tab[sl]);
+      else launch_moments<double>(c, &dv[sl * n_views], n_views, rows, G, s, D, false, &tile_tab[sl]);
+      if (piped) CCZ_HIP(hipEventRecord(im->pipe_ev[2 + sl], stream(c)));
     }
   } catch (...) {
-    for (void* p : stage) dev_free(c, p);
+    cleanup();
     throw;
   }
-  for (void* p : stage) dev_free(c, p);
+  cleanup();
 }
 
 }  // namespace ccz

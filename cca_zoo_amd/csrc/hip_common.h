@@ -34,6 +34,12 @@ struct Impl {
   int* d_flag = nullptr;      // small device scratch: ints
   double* d_small = nullptr;  // small device scratch: 64K doubles
   size_t small_cap = 65536;
+  // host -> device streaming of pageable inputs (gram.hip): two pinned bounce buffers, a copy stream and
+  // per-slot events; created on first use, kept for the life of the handle
+  void* pin_buf[2] = {nullptr, nullptr};
+  size_t pin_cap = 0;
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t pipe_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // h2d done [2], compute done [2]
 };
 
 inline Impl* impl(ccz_ctx* c) { return static_cast<Impl*>(c->impl); }

@@ -71,6 +71,32 @@ def test_moments_host_views(H, dtype, n, dims):
     assert np.array_equal(G, G.T)
 
 
+@pytest.mark.parametrize("dtype,threads", [(np.float32, "4"), (np.float64, "1")])
+def test_moments_host_views_pipelined(H, dtype, threads, monkeypatch):
+    """Pageable host inputs above 64 MiB go through the pack -> DMA -> K1 pipeline (7+ chunks here, a ragged
+    last chunk, one strided view)."""
+    monkeypatch.setenv("CCZ_H2D_CHUNK_MB", "12")
+    monkeypatch.setenv("CCZ_H2D_THREADS", threads)
+    from cca_zoo_amd import _backend
+
+    n = 30011 if dtype == np.float32 else 14007
+    rng = np.random.default_rng(5)
+    wide = (rng.standard_normal((n, 700)) + 0.5).astype(dtype)
+    a = wide[:, 10:522]                                       # 512 columns, row stride 700
+    b = (rng.standard_normal((n, 384)) * (1.0 + np.arange(384) / 384.0)).astype(dtype)
+    assert (a.nbytes + b.nbytes) >= 64 << 20
+    D = 512 + 384
+    mom = H.alloc((D * D + D) * 8)
+    H.moments([(a, 512, 700), (b, 384, 384)], n, _backend.F32 if dtype == np.float32 else _backend.F64, False, mom.ptr)
+    H.moments_symmetrize(mom.ptr, D)
+    flat = H.to_host(mom, (D * D + D,))
+    G, s = flat[: D * D].reshape(D, D), flat[D * D:]
+    Gr, sr = _ref([a, b])
+    scale = np.sqrt(np.outer(np.diag(Gr), np.diag(Gr)))
+    assert np.max(np.abs(G - Gr) / scale) < (2e-6 if dtype == np.float32 else 1e-13)
+    np.testing.assert_allclose(s, sr, rtol=1e-12, atol=1e-8)
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_moments_device_views_and_upper_only(H, dtype):
     views = [_structured(3000, 512, dtype, 1), _structured(3000, 256, dtype, 2)]
