@@ -37,13 +37,15 @@ def parse():
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dcca", action="store_true")
-    ap.add_argument("--cpu-sample-rows", type=int, default=6144)
+    ap.add_argument("--cpu-sample-rows", type=int, default=2048)
     return ap.parse_args()
 
 
 def cpu_baseline(n_full, d, k, sample_rows):
     """Reference-structured NumPy path (thin SVD of each n x d view, oracle.reference_form) on a
-    bounded row sample of the same workload; its cost is linear in n."""
+    bounded row sample of the same workload, extrapolated linearly in n.  The thin SVD costs O(n d^2)
+    for n >= d and less per row below that, so a sample shorter than d UNDER-estimates the CPU time:
+    the reported CPU rate is an upper bound (in the CPU's favour)."""
     import numpy as np
 
     from oracle import reference_form as rf
@@ -64,20 +66,24 @@ def cpu_baseline(n_full, d, k, sample_rows):
         "value": 1.0 / full, "unit": "fit/s", "cores": int(threads), "kind": "port",
         "sample": (f"oracle.reference_form.rcca_weights (thin SVD per view, as cca_zoo/linear/_rcca.py) on "
                    f"{sample_rows} of {n_full} rows, 2x{d} fp32, k={k}: {dt:.2f} s measured; value = 1/(t * n/n_sample) "
-                   f"(reference cost is linear in n); host has {os.cpu_count()} logical cores"),
+                   f"(linear extrapolation; for n_sample < d it under-estimates the CPU time, i.e. favours the CPU); "
+                   f"host has {os.cpu_count()} logical cores"),
         "measured_s": dt,
     }
 
 
-def dcca_extra(steps=20, warmup=3):
-    """BASELINE configs[3]: CCALoss fwd+bwd, batch 8192, 2 x 512, fp32."""
+def dcca_extra(steps=20, warmup=3, batch=8192, d=512, label="BASELINE configs[3]"):
+    """CCALoss forward + backward (ccz_cca_loss through the autograd Function), fp32 embeddings resident in HBM.
+    Called twice: configs[3] (batch 8192, 2 x 512) and the metric's own shape (n = 1e6, d = 4096)."""
     import torch
 
     from cca_zoo_amd.deep.objectives import CCALoss
 
     torch.manual_seed(0)
-    z1 = torch.randn(8192, 512, device="cuda", requires_grad=True)
-    z2 = (0.5 * z1.detach() + torch.randn(8192, 512, device="cuda")).requires_grad_(True)
+    z1 = torch.randn(batch, d, device="cuda", requires_grad=True)
+    z2 = torch.randn(batch, d, device="cuda")
+    z2.add_(z1.detach(), alpha=0.5)
+    z2.requires_grad_(True)
     obj = CCALoss(eps=1e-6)
     for _ in range(warmup):
         obj([z1, z2]).backward()
@@ -89,7 +95,10 @@ def dcca_extra(steps=20, warmup=3):
         obj([z1, z2]).backward()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    return {"metric": "DCCA CCALoss fwd+bwd/sec (batch 8192, 2x512, fp32)", "value": 1.0 / dt, "ms": dt * 1e3}
+    # forward Gram n D (D + 1) with D = 2 d, backward two (n x 2d) @ (2d x d) products
+    flops = float(batch) * (2 * d) * (2 * d + 1) + 2.0 * 2.0 * batch * (2 * d) * d
+    return {"metric": f"DCCA CCALoss fwd+bwd/sec (batch {batch}, 2x{d}, fp32; {label})", "value": 1.0 / dt, "ms": dt * 1e3,
+            "tflops": flops / dt / 1e12}
 
 
 def main():
@@ -164,10 +173,10 @@ def main():
         achieved = flop / (g_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[a.dtype]
         # HBM/fabric bytes per launch from the committed PMC pass (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
-        # profiles/r01_b_gram_pmc.md), measured at n=262144 on the same kernel/shape and linear in the rows
+        # profiles/r01_c_gram_pmc.md), measured at n=262144 on the same kernel/shape and linear in the rows
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_b_gram_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r01_c_gram_traffic.json")) as f:
                 tj = json.load(f)
             if a.dtype == "f32" and tj.get("D") == D:
                 traffic = tj["bytes_per_row"] * n_local
@@ -185,7 +194,7 @@ def main():
                        "device": info["name"], "arch": info["arch"], "compute_units": info["compute_units"]},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
-                         "traffic_source": "profiles/r01_b_gram_pmc.md (PMC pass at n=262144, scaled by rows)" if traffic else None,
+                         "traffic_source": "profiles/r01_c_gram_pmc.md (PMC pass at n=262144, scaled by rows)" if traffic else None,
                          "kernel": "k_gram_f32_fifo" if a.dtype == "f32" else "k_gram_f64",
                          "kernel_ms": g_ms, "flop_per_launch": flop,
                          "bytes_per_launch": float(n_local) * D * (4 if a.dtype == "f32" else 8),
@@ -195,6 +204,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(a.n, a.d, a.k, a.cpu_sample_rows)
         if world == 1 and not a.no_dcca:
             out["extra"] = {"dcca_loss": dcca_extra()}
+            if a.n * a.d * 4 * 4 < 200e9:   # z1, z2 and their gradients must fit in HBM next to the views
+                del views
+                torch.cuda.empty_cache()
+                out["extra"]["dcca_loss_metric_shape"] = dcca_extra(steps=2, warmup=1, batch=a.n, d=a.d, label="metric shape")
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

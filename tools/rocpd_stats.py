@@ -18,7 +18,19 @@ def short(name):
     return name[:90]
 
 
-def main(path):
+def by_grid(con, pattern):
+    """Per launch-shape breakdown of the kernels matching ``pattern`` (same kernel, different problem sizes)."""
+    rows = con.execute(
+        "select name, grid_x, grid_y, grid_z, count(*), avg(duration), min(duration), max(duration) from kernels "
+        "where name like ? group by name, grid_x, grid_y, grid_z order by avg(duration) desc", (f"%{pattern}%",)).fetchall()
+    print(f"\nlaunch shapes of `*{pattern}*`:\n")
+    print("| kernel | grid (threads) | calls | avg us | min us | max us |")
+    print("|---|---|---:|---:|---:|---:|")
+    for name, gx, gy, gz, calls, avg, mn, mx in rows:
+        print(f"| `{short(name)}` | {gx} x {gy} x {gz} | {calls} | {avg / 1e3:.1f} | {mn / 1e3:.1f} | {mx / 1e3:.1f} |")
+
+
+def main(path, patterns=()):
     con = sqlite3.connect(path)
     rows = con.execute(
         "select name, count(*), sum(duration), avg(duration), min(duration), max(duration) "
@@ -30,7 +42,9 @@ def main(path):
     print("|---|---:|---:|---:|---:|---:|---:|")
     for name, calls, tot, avg, mn, mx in rows:
         print(f"| `{short(name)}` | {calls} | {tot / 1e6:.3f} | {avg / 1e3:.1f} | {mn / 1e3:.1f} | {mx / 1e3:.1f} | {100 * tot / total:.2f} |")
+    for pat in patterns:
+        by_grid(con, pat)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], sys.argv[2:])
