@@ -80,6 +80,7 @@ SIGNATURES = {
     "ccz_inv_sqrtm": (_int, [_vp, _vp, _i64, _dbl, _vp]),
     "ccz_potrf_lower": (_int, [_vp, _vp, _i64, _i64]),
     "ccz_trsm_right_lower": (_int, [_vp, _int, _i64, _i64, _vp, _i64, _vp, _i64]),
+    "ccz_moments_axpby": (_int, [_vp, _i64, _dbl, _vp, _dbl, _vp]),
     "ccz_gemm_f64": (_int, [_vp, _int, _int, _i64, _i64, _i64, _dbl, _vp, _i64, _vp, _i64, _dbl, _vp, _i64]),
     "ccz_cca_loss": (_int, [_vp, _int, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _dbl, _vp, _vp, _vp, _i64, _i64]),
     "ccz_transform": (_int, [_vp, _int, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _i64]),
@@ -210,6 +211,9 @@ class Handle:
         buf.shape, buf.dtype = arr.shape, arr.dtype
         return buf
 
+    def memset0(self, ptr, nbytes):
+        self.check(self.lib.ccz_memset0(self._h, _ptr(ptr), int(nbytes)))
+
     def to_host(self, buf, shape, dtype=np.float64, offset_bytes=0):
         out = np.empty(shape, dtype=dtype)
         self.check(self.lib.ccz_memcpy_d2h(self._h, _ptr(out), _ptr(buf.ptr + offset_bytes if isinstance(buf, DeviceBuffer) else int(buf) + offset_bytes), out.nbytes))
@@ -238,6 +242,14 @@ class Handle:
 
     def moments_unpack(self, packed_ptr, D, moments_ptr):
         self.check(self.lib.ccz_moments_unpack(self._h, _ptr(packed_ptr), int(D), _ptr(moments_ptr)))
+
+    def moments_axpby(self, D, alpha, x_ptr, beta, y_ptr):
+        """y <- alpha x + beta y over two moment buffers (moments are additive over disjoint row sets)."""
+        self.check(self.lib.ccz_moments_axpby(self._h, int(D), float(alpha), _ptr(x_ptr), float(beta), _ptr(y_ptr)))
+
+    def gemm(self, tA, tB, M, N, K, alpha, A_ptr, lda, B_ptr, ldb, beta, C_ptr, ldc):
+        self.check(self.lib.ccz_gemm_f64(self._h, int(tA), int(tB), int(M), int(N), int(K), float(alpha), _ptr(A_ptr), int(lda),
+                                         _ptr(B_ptr), int(ldb), float(beta), _ptr(C_ptr), int(ldc)))
 
     def moments_last_ms(self):
         g, s = C.c_double(), C.c_double()

@@ -79,7 +79,11 @@ void zero(ccz_ctx* c, void* dst, size_t bytes) {
   CCZ_HIP(hipMemsetAsync(dst, 0, bytes, stream(c)));
 }
 void sync(ccz_ctx* c) { CCZ_HIP(hipStreamSynchronize(stream(c))); }
-void activate(ccz_ctx* c) { CCZ_HIP(hipSetDevice(c->device)); }
+void wave_kernels_init();
+void activate(ccz_ctx* c) {
+  CCZ_HIP(hipSetDevice(c->device));
+  wave_kernels_init();
+}
 
 // ===========================================================================
 // GEMM on the matrix pipe: 64x64 block tile, 4 waves (2x2), each wave 2x2 MFMA 16x16x4
@@ -601,11 +605,19 @@ void gather_rows(ccz_ctx* c, int64_t rows, int64_t cols, const double* in, int64
 constexpr int NB = 64;
 
 // ---------------------------------------------------------------------------
-// 64 x 64 diagonal block on ONE wavefront: lane i owns row i in registers, columns are
-// exchanged with v_readlane broadcasts (no LDS, no barriers).  Optionally factors the
-// block (right-looking Cholesky), then forms invT = L^-T (lane c solves L x = e_c),
-// which turns every triangular solve against this block into an MFMA GEMM.
-// Blocks narrower than 64 are padded with the identity.
+// 64 x 64 diagonal block on ONE wavefront, no barriers.  Lane i owns row i of the current Schur
+// complement in 64 registers and the block is consumed as a SHIFT REGISTER: at step j register a[0]
+// is column j, the rank-1 update writes its result one register down (a[k-1] = a[k] - l_i l_{j+k}),
+// so every register index is a compile-time constant while j is a run-time loop counter
+// (v_readlane with an SGPR lane index broadcasts l_{j+k}).  The loop body is ~200 instructions;
+// four bodies of decreasing width (63, 47, 31, 15 live columns) keep ~2/3 of the triangular saving.
+// The first version unrolled all 2016 (j, k) pairs with static register indices: 134 KB of
+// straight-line code for one wavefront -- larger than the instruction cache, so its run time was
+// set by where the code happened to be cached (46 us ... 210 us for the same block; rocprofv3).
+// The finished column goes to LDS (Ls[j][i], stride 65); the second phase forms invT = L^-T by
+// forward substitution in the same shift-register form (lane c solves L x = e_c, the multipliers
+// L[t+k][t] are wave-uniform LDS broadcasts).  Global loads / stores are whole 512-byte rows,
+// transposed through LDS.  Blocks narrower than 64 are padded with the identity.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ double lane_bcast(double v, int src) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
@@ -613,76 +625,104 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 
+constexpr int WLD = NB + 1;   // LDS tile stride (doubles): column and row accesses both conflict-free
+
+template <int KMAX>
+__device__ __forceinline__ void chol_steps(double (&a)[NB], int j_begin, int j_end, int lane, double* Ls, int& first_bad) {
+#pragma unroll 1
+  for (int j = j_begin; j < j_end; ++j) {
+    const double col = a[0];
+    double piv = lane_bcast(col, j);
+    const bool bad = !(piv > 0.0);                 // wave-uniform
+    first_bad = bad ? min(first_bad, j) : first_bad;
+    piv = bad ? 1.0 : piv;
+    const double l = col * (1.0 / sqrt(piv));      // lanes >= j: L[lane][j]; lanes < j hold junk that nobody reads
+    double* lcol = Ls + j * WLD;
+    lcol[lane] = lane >= j ? l : 0.0;
+    // l_{j+k} comes back as a wave-uniform LDS broadcast (one ds_read_b64 with an immediate offset instead of
+    // two v_readlane + an SALU add); reads past row 63 land in junk that only feeds junk registers
+    const double* lrow = lcol + j;
+#pragma unroll
+    for (int k = 1; k <= KMAX; ++k) {
+      a[k - 1] = a[k] - l * lrow[k];
+      if ((k & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int KMAX>
+__device__ __forceinline__ void inv_steps(double (&v)[NB], int t_begin, int t_end, int lane, const double* Ls, double* Xs) {
+#pragma unroll 1
+  for (int t = t_begin; t < t_end; ++t) {
+    const double* lcol = Ls + t * WLD + t;         // L[t][t], L[t+1][t], ... (wave-uniform addresses)
+    const double x = v[0] / lcol[0];
+    Xs[lane * WLD + t] = x;                        // (L^-1)[t][lane] = (L^-T)[lane][t]
+#pragma unroll
+    for (int k = 1; k <= KMAX; ++k) {
+      v[k - 1] = v[k] - lcol[k] * x;               // rows past 63: junk into registers that are never read
+      if ((k & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// Ajj: the diagonal block (row stride lda), nb valid rows/columns.  do_chol: factor it in place (lower
+// triangle written back) else it already holds L.  invT (may be null): 64 x 64 row-major L^-T.
+// Returns the first non-positive pivot (0-based) or 0x7fffffff.
+__device__ __forceinline__ int wave_block(double* __restrict__ Ajj, int64_t lda, int nb, bool do_chol,
+                                          double* __restrict__ invT, double* lds) {
+  const int lane = threadIdx.x;
+  double* Ls = lds;                 // Ls[t * WLD + i] = L[i][t]
+  double* Xs = lds + NB * WLD;      // input tile first, then Xs[c * WLD + t] = (L^-T)[c][t]
+  int first_bad = 0x7fffffff;
+  if (do_chol) {
+    // rows arrive as full 512-byte lines (lane = column), each lane then picks up its own row
+    for (int r = 0; r < NB; ++r) {
+      double v = (r == lane) ? 1.0 : 0.0;
+      if (r < nb && lane < nb) v = Ajj[int64_t(r) * lda + lane];
+      Xs[r * WLD + lane] = v;
+    }
+    double a[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) a[k] = Xs[lane * WLD + k];
+    chol_steps<63>(a, 0, 16, lane, Ls, first_bad);
+    chol_steps<47>(a, 16, 32, lane, Ls, first_bad);
+    chol_steps<31>(a, 32, 48, lane, Ls, first_bad);
+    chol_steps<15>(a, 48, 64, lane, Ls, first_bad);
+    for (int r = 0; r < nb; ++r)
+      if (lane <= r && lane < nb) Ajj[int64_t(r) * lda + lane] = Ls[lane * WLD + r];
+  } else {
+    for (int r = 0; r < NB; ++r) {
+      double v = (r == lane) ? 1.0 : 0.0;
+      if (r < nb && lane < nb) v = lane <= r ? Ajj[int64_t(r) * lda + lane] : 0.0;
+      Ls[lane * WLD + r] = v;
+    }
+  }
+  if (invT) {
+    double v[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) v[k] = (k == lane) ? 1.0 : 0.0;
+    inv_steps<63>(v, 0, 16, lane, Ls, Xs);
+    inv_steps<47>(v, 16, 32, lane, Ls, Xs);
+    inv_steps<31>(v, 32, 48, lane, Ls, Xs);
+    inv_steps<15>(v, 48, 64, lane, Ls, Xs);
+    for (int r = 0; r < NB; ++r) invT[r * NB + lane] = Xs[r * WLD + lane];
+  }
+  return first_bad;
+}
+
+constexpr size_t WAVE_BLOCK_LDS = (size_t(2) * NB * WLD + 2 * NB) * sizeof(double);   // two tiles + slack for the over-reads
+
 template <bool DO_CHOL>
 __global__ __launch_bounds__(64) void k_wave_chol_inv(double* __restrict__ A, int64_t lda, int64_t d, int64_t j_first,
                                                       int* __restrict__ info, double* __restrict__ invT) {
-  const int lane = threadIdx.x;
+  extern __shared__ __attribute__((aligned(16))) char wave_smem[];
   const int64_t j0 = j_first + int64_t(blockIdx.x) * NB;
   const int nb = int(min(int64_t(NB), d - j0));
-  double* Ajj = A + j0 * lda + j0;
-  double a[NB];
-  if (nb == NB) {
-    // full block: plain row loads (the strictly upper part is loaded but never read)
-#pragma unroll
-    for (int t = 0; t < NB; ++t) a[t] = Ajj[int64_t(lane) * lda + t];
-  } else {
-    // ragged last block: pad with the identity
-#pragma unroll
-    for (int t = 0; t < NB; ++t) {
-      double v = (t == lane) ? 1.0 : 0.0;
-      if (lane < nb && t < nb) v = Ajj[int64_t(lane) * lda + t];
-      a[t] = v;
-    }
-  }
-  if (DO_CHOL) {
-    int first_bad = 0x7fffffff;
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      double piv = lane_bcast(a[j], j);
-      const bool bad = !(piv > 0.0);                 // wave-uniform
-      first_bad = bad ? min(first_bad, j) : first_bad;
-      piv = bad ? 1.0 : piv;
-      const double root = sqrt(piv);
-      const double rinv = 1.0 / root;
-      const double l = a[j] * rinv;                  // lane j: piv / sqrt(piv) = l_jj (no lane select needed)
-      a[j] = l;
-      // (i, k) -= l_ij l_kj ; only k <= i is ever read back.  Broadcasts are consumed in groups of 8
-      // so that the scalar registers holding them are recycled instead of spilled.
-#pragma unroll
-      for (int k = j + 1; k < NB; ++k) {
-        a[k] -= l * lane_bcast(a[j], k);
-        if (((k - j) & 7) == 0) __builtin_amdgcn_sched_barrier(0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (first_bad != 0x7fffffff && lane == 0) atomicMin(info, int(j0 + first_bad + 1));
-#pragma unroll
-    for (int t = 0; t < NB; ++t)
-      if (lane < nb && t <= lane) Ajj[int64_t(lane) * lda + t] = a[t];
-  }
-  if (invT) {
-    if (DO_CHOL) {
-      // make the factor opaque: otherwise the compiler keeps the ~2000 broadcasts of the factorisation
-      // alive (spilled scalar registers) to reuse them below, which is slower than re-broadcasting
-#pragma unroll
-      for (int t = 0; t < NB; ++t) asm volatile("" : "+v"(a[t]));
-    }
-    double x[NB];
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      double v = (i == lane) ? 1.0 : 0.0;
-#pragma unroll
-      for (int t = 0; t < i; ++t) {
-        v -= lane_bcast(a[t], i) * x[t];                                  // L[i][t] lives in lane i, register t
-        if ((t & 7) == 7) __builtin_amdgcn_sched_barrier(0);
-      }
-      x[i] = v / lane_bcast(a[i], i);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    double* out = invT + (int64_t(blockIdx.x) * NB + lane) * NB;          // row `lane` of L^-T: (L^-1)[i][lane]
-#pragma unroll
-    for (int i = 0; i < NB; ++i) out[i] = x[i];
-  }
+  const int bad = wave_block(A + j0 * lda + j0, lda, nb, DO_CHOL, invT ? invT + int64_t(blockIdx.x) * NB * NB : nullptr,
+                             reinterpret_cast<double*>(wave_smem));
+  if (DO_CHOL && bad != 0x7fffffff && threadIdx.x == 0) atomicMin(info, int(j0 + bad + 1));
 }
 
 constexpr int MAXB = 8;
@@ -696,69 +736,32 @@ struct CholBatch {
 // one panel step of up to MAXB independent factorisations: block b factors the diagonal block at
 // column j0 of matrix b (if it has one) and forms its L^-T
 __global__ __launch_bounds__(64) void k_wave_chol_inv_batched(CholBatch bt, int64_t j0, int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) char wave_smem[];
   const int b = blockIdx.x;
   if (j0 >= bt.d[b]) return;
-  const int lane = threadIdx.x;
   const int nb = int(min(int64_t(NB), bt.d[b] - j0));
   const int64_t lda = bt.lda[b];
-  double* Ajj = bt.A[b] + j0 * lda + j0;
-  double a[NB];
-  if (nb == NB) {
-#pragma unroll
-    for (int t = 0; t < NB; ++t) a[t] = Ajj[int64_t(lane) * lda + t];
-  } else {
-#pragma unroll
-    for (int t = 0; t < NB; ++t) {
-      double v = (t == lane) ? 1.0 : 0.0;
-      if (lane < nb && t < nb) v = Ajj[int64_t(lane) * lda + t];
-      a[t] = v;
-    }
-  }
-  int first_bad = 0x7fffffff;
-#pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    double piv = lane_bcast(a[j], j);
-    const bool bad = !(piv > 0.0);
-    first_bad = bad ? min(first_bad, j) : first_bad;
-    piv = bad ? 1.0 : piv;
-    const double rinv = 1.0 / sqrt(piv);
-    const double l = a[j] * rinv;
-    a[j] = l;
-#pragma unroll
-    for (int k = j + 1; k < NB; ++k) {
-      a[k] -= l * lane_bcast(a[j], k);
-      if (((k - j) & 7) == 0) __builtin_amdgcn_sched_barrier(0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if (first_bad != 0x7fffffff && lane == 0) atomicMin(info + b, int(j0 + first_bad + 1));
-#pragma unroll
-  for (int t = 0; t < NB; ++t)
-    if (lane < nb && t <= lane) Ajj[int64_t(lane) * lda + t] = a[t];
-  if (j0 + nb >= bt.d[b]) return;          // last panel: no solve against it follows
-#pragma unroll
-  for (int t = 0; t < NB; ++t) asm volatile("" : "+v"(a[t]));
-  double x[NB];
-#pragma unroll
-  for (int i = 0; i < NB; ++i) {
-    double v = (i == lane) ? 1.0 : 0.0;
-#pragma unroll
-    for (int t = 0; t < i; ++t) {
-      v -= lane_bcast(a[t], i) * x[t];
-      if ((t & 7) == 7) __builtin_amdgcn_sched_barrier(0);
-    }
-    x[i] = v / lane_bcast(a[i], i);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  double* out = bt.invT[b] + int64_t(lane) * NB;
-#pragma unroll
-  for (int i = 0; i < NB; ++i) out[i] = x[i];
+  const bool last = j0 + nb >= bt.d[b];          // last panel: no solve against it follows
+  const int bad = wave_block(bt.A[b] + j0 * lda + j0, lda, nb, true, last ? nullptr : bt.invT[b],
+                             reinterpret_cast<double*>(wave_smem));
+  if (bad != 0x7fffffff && threadIdx.x == 0) atomicMin(info + b, int(j0 + bad + 1));
+}
+
+// the wave kernels use 65 KiB of dynamic LDS: opt in once per device (never inside a graph capture)
+void wave_kernels_init() {
+  static thread_local int done_for_device = -1;
+  int dev = -1;
+  CCZ_HIP(hipGetDevice(&dev));
+  if (done_for_device == dev) return;
+  CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wave_chol_inv<false>), hipFuncAttributeMaxDynamicSharedMemorySize, int(WAVE_BLOCK_LDS)));
+  CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wave_chol_inv_batched), hipFuncAttributeMaxDynamicSharedMemorySize, int(WAVE_BLOCK_LDS)));
+  done_for_device = dev;
 }
 
 // invT[b] = L_bb^-T for every diagonal block b of L (one wave each, all blocks in one launch)
 static void diag_inverses(ccz_ctx* c, const double* L, int64_t ldl, int64_t d, double* invT) {
   const unsigned nblk = (unsigned)((d + NB - 1) / NB);
-  hipLaunchKernelGGL(k_wave_chol_inv<false>, dim3(nblk), dim3(64), 0, stream(c), const_cast<double*>(L), ldl, d,
+  hipLaunchKernelGGL(k_wave_chol_inv<false>, dim3(nblk), dim3(64), WAVE_BLOCK_LDS, stream(c), const_cast<double*>(L), ldl, d,
                      int64_t(0), static_cast<int*>(nullptr), invT);
   CCZ_LAUNCH_CHECK();
 }
@@ -817,7 +820,7 @@ static void potrf_rec(ccz_ctx* c, std::vector<PotrfJob>& jobs, int64_t j0, int64
       bt.d[i] = i < nb ? jb.d : 0;
       bt.invT[i] = jb.invT + (j0 / NB) * NB * NB;
     }
-    hipLaunchKernelGGL(k_wave_chol_inv_batched, dim3(nb), dim3(64), 0, stream(c), bt, j0, d_info);
+    hipLaunchKernelGGL(k_wave_chol_inv_batched, dim3(nb), dim3(64), WAVE_BLOCK_LDS, stream(c), bt, j0, d_info);
     CCZ_LAUNCH_CHECK();
     return;
   }
@@ -968,7 +971,7 @@ static void potrf_lower_batched_iter(ccz_ctx* c, int count, double* const* A, co
     }
     graph_run(c, key, [&] {
       for (int64_t j = 0; j < dmax; j += NB) {
-        hipLaunchKernelGGL(k_wave_chol_inv_batched, dim3(nbt), dim3(64), 0, stream(c), bt, j, im->d_flag + 8);
+        hipLaunchKernelGGL(k_wave_chol_inv_batched, dim3(nbt), dim3(64), WAVE_BLOCK_LDS, stream(c), bt, j, im->d_flag + 8);
         CCZ_LAUNCH_CHECK();
         for (int i = 0; i < nbt; ++i) {
           const int64_t di = d[b0 + i], ld = lda[b0 + i];

@@ -934,6 +934,14 @@ int ccz_trsm_right_lower(ccz_handle h, int trans, int64_t r, int64_t d, const do
   })
 }
 
+int ccz_moments_axpby(ccz_handle h, int64_t D, double alpha, const double* x_dev, double beta, double* y_dev) {
+  CCZ_GUARD(h, {
+    if (!x_dev || !y_dev || D < 1) ccz::fail(CCZ_EINVAL, "bad argument");
+    const int64_t total = D * D + D;
+    ccz::axpby2d(h, 1, total, beta, y_dev, total, alpha, x_dev, total);
+  })
+}
+
 int ccz_gemm_f64(ccz_handle h, int transA, int transB, int64_t M, int64_t N, int64_t K,
                  double alpha, const double* A_dev, int64_t lda, const double* B_dev, int64_t ldb,
                  double beta, double* C_dev, int64_t ldc) {

@@ -46,14 +46,17 @@ class GCCA(BaseModel):
         self.view_weights = view_weights
         self.eps = eps
 
-    def fit(self, views, y=None):
-        views_ = self._setup_fit(views)
+    def _fit_moments(self, h, mom, n_total, dims, kind) -> None:
         c_ = perview_parameter("c", self.c, 0.0, self.n_views_)
         mu = perview_parameter("view_weights", self.view_weights, 1.0, self.n_views_)
-        h = _backend.default_handle()
-        mom, keep, n_total, dims, kind = compute_moments(views_, h)
         W, means, vals = h.gcca_solve(mom, n_total, dims, c_, mu, self.eps, self.center, self.latent_dimensions)
         self._store(W, means, kind, weights_like_input=False)
         self.eigenvalues_ = vals
+
+    def fit(self, views, y=None):
+        views_ = self._setup_fit(views)
+        h = _backend.default_handle()
+        mom, keep, n_total, dims, kind = compute_moments(views_, h)
+        self._fit_moments(h, mom, n_total, dims, kind)
         del keep
         return self

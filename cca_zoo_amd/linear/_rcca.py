@@ -38,19 +38,25 @@ class rCCA(BaseModel):
         super().__init__(latent_dimensions=latent_dimensions, center=center)
         self.c = c
 
-    def fit(self, views, y=None):
-        views_ = self._setup_fit(views)
+    def _check_n_views(self) -> None:
         if self.n_views_ != 2:
             raise ValueError(
                 f"rCCA requires exactly 2 views, got {self.n_views_}. "
                 "Use MCCA for more than 2 views."
             )
+
+    def _fit_moments(self, h, mom, n_total, dims, kind) -> None:
         c_ = perview_parameter("c", self.c, 0.0, 2)
-        h = _backend.default_handle()
-        mom, keep, n_total, dims, kind = compute_moments(views_, h)
         W, means, vals = h.rcca_solve(mom, n_total, dims, c_, self.center, self.latent_dimensions)
         self._store(W, means, kind, weights_like_input=True)
         self.singular_values_ = vals
+
+    def fit(self, views, y=None):
+        views_ = self._setup_fit(views)
+        self._check_n_views()
+        h = _backend.default_handle()
+        mom, keep, n_total, dims, kind = compute_moments(views_, h)
+        self._fit_moments(h, mom, n_total, dims, kind)
         del keep
         return self
 

@@ -100,6 +100,11 @@ CCZ_API int ccz_moments_symmetrize(ccz_handle h, double* moments_dev, int64_t D)
  * unpack: packed -> upper triangle of moments (+ colsum); the lower triangle is left untouched. */
 CCZ_API int ccz_moments_pack(ccz_handle h, const double* moments_dev, int64_t D, double* packed_dev);
 CCZ_API int ccz_moments_unpack(ccz_handle h, const double* packed_dev, int64_t D, double* moments_dev);
+/* Moments are additive over disjoint row sets: y <- alpha x + beta y over the D*D + D doubles of two
+ * moment buffers.  With (alpha, beta) = (-1, 1) it turns the moments of all rows into those of the rows
+ * outside a cross-validation fold -- the Gram reuse behind cca_zoo_amd.model_selection.GridSearchCV
+ * (the reference refits from the data for every fold and setting: cca_zoo/model_selection/_search.py:211-262). */
+CCZ_API int ccz_moments_axpby(ccz_handle h, int64_t D, double alpha, const double* x_dev, double beta, double* y_dev);
 /* kernel timing of the last ccz_moments call on this handle (HIP events on the
  * handle's stream): milliseconds of the Gram kernel(s) and of the column-sum pass */
 CCZ_API int ccz_moments_last_ms(ccz_handle h, double* gram_ms, double* colsum_ms);

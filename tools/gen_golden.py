@@ -218,3 +218,39 @@ store["inv_sqrtm/out_eps1e-5"] = _inv_sqrtm(spd, 1e-5).numpy()
 store["inv_sqrtm/out_eps0.5"] = _inv_sqrtm(spd, 0.5).numpy()      # clamp active
 np.savez_compressed(os.path.join(OUT, "losses.npz"), **store)
 print("losses", len(store), "arrays")
+
+# ------------------------------------------------------------------------------------------------
+# model selection: the reference's GridSearchCV, one refit per (setting, fold)
+# ------------------------------------------------------------------------------------------------
+from cca_zoo.model_selection import GridSearchCV  # noqa: E402
+
+store = {}
+rng = np.random.default_rng(11)
+z = rng.standard_normal((240, 3)) * np.array([2.0, 1.3, 0.8])
+gv = [z @ rng.standard_normal((3, p)) + 0.9 * rng.standard_normal((240, p)) + off
+      for p, off in ((12, 0.5), (9, -1.0), (7, 0.0))]
+for i, v in enumerate(gv):
+    store[f"view{i}"] = v
+
+
+def grid_case(tag, est, grid, views, cv):
+    gs = GridSearchCV(est, param_grid=grid, cv=cv).fit(views)
+    res = gs.cv_results_
+    store[f"{tag}/mean_test_score"] = np.asarray(res["mean_test_score"], dtype=np.float64)
+    store[f"{tag}/std_test_score"] = np.asarray(res["std_test_score"], dtype=np.float64)
+    store[f"{tag}/rank_test_score"] = np.asarray(res["rank_test_score"], dtype=np.int64)
+    for f in range(cv):
+        store[f"{tag}/split{f}_test_score"] = np.asarray(res[f"split{f}_test_score"], dtype=np.float64)
+    store[f"{tag}/best_score"] = np.float64(gs.best_score_)
+    store[f"{tag}/best_index"] = np.int64(gs._inner_cv.best_index_)
+    for i, w in enumerate(gs.best_estimator_.weights_):
+        store[f"{tag}/best_w{i}"] = np.asarray(w)
+    store[f"{tag}/score_all"] = np.float64(gs.score(views))
+    store[f"{tag}/params"] = np.array([repr(sorted(p.items())) for p in res["params"]])
+
+
+grid_case("rcca", rCCA(), {"c": [0.0, 0.01, 0.1, 0.5, 0.9], "latent_dimensions": [1, 2]}, gv[:2], 4)
+grid_case("mcca", MCCA(), {"c": [0.0, 0.1, 0.7], "latent_dimensions": [2]}, gv, 3)
+grid_case("gcca", GCCA(), {"c": [0.05, 0.3], "latent_dimensions": [1, 2]}, gv, 3)
+np.savez_compressed(os.path.join(OUT, "grid_search.npz"), **store)
+print("grid_search", len(store), "arrays")
