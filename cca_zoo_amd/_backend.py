@@ -81,6 +81,7 @@ SIGNATURES = {
     "ccz_potrf_lower": (_int, [_vp, _vp, _i64, _i64]),
     "ccz_trsm_right_lower": (_int, [_vp, _int, _i64, _i64, _vp, _i64, _vp, _i64]),
     "ccz_moments_axpby": (_int, [_vp, _i64, _dbl, _vp, _dbl, _vp]),
+    "ccz_moments_subset": (_int, [_vp, _vp, _i64, _i64, _i64, _vp]),
     "ccz_gemm_f64": (_int, [_vp, _int, _int, _i64, _i64, _i64, _dbl, _vp, _i64, _vp, _i64, _dbl, _vp, _i64]),
     "ccz_cca_loss": (_int, [_vp, _int, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _dbl, _vp, _vp, _vp, _i64, _i64]),
     "ccz_transform": (_int, [_vp, _int, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _i64]),
@@ -211,6 +212,11 @@ class Handle:
         buf.shape, buf.dtype = arr.shape, arr.dtype
         return buf
 
+    def h2d(self, dst_ptr, arr):
+        """Copy a host array into device memory at ``dst_ptr`` (any device address, e.g. inside a moments buffer)."""
+        arr = np.ascontiguousarray(arr)
+        self.check(self.lib.ccz_memcpy_h2d(self._h, _ptr(dst_ptr), _ptr(arr), arr.nbytes))
+
     def memset0(self, ptr, nbytes):
         self.check(self.lib.ccz_memset0(self._h, _ptr(ptr), int(nbytes)))
 
@@ -246,6 +252,9 @@ class Handle:
     def moments_axpby(self, D, alpha, x_ptr, beta, y_ptr):
         """y <- alpha x + beta y over two moment buffers (moments are additive over disjoint row sets)."""
         self.check(self.lib.ccz_moments_axpby(self._h, int(D), float(alpha), _ptr(x_ptr), float(beta), _ptr(y_ptr)))
+
+    def moments_subset(self, moments_ptr, D, col0, D_sub, out_ptr):
+        self.check(self.lib.ccz_moments_subset(self._h, _ptr(moments_ptr), int(D), int(col0), int(D_sub), _ptr(out_ptr)))
 
     def gemm(self, tA, tB, M, N, K, alpha, A_ptr, lda, B_ptr, ldb, beta, C_ptr, ldc):
         self.check(self.lib.ccz_gemm_f64(self._h, int(tA), int(tB), int(M), int(N), int(K), float(alpha), _ptr(A_ptr), int(lda),

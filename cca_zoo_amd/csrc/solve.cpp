@@ -942,6 +942,16 @@ int ccz_moments_axpby(ccz_handle h, int64_t D, double alpha, const double* x_dev
   })
 }
 
+int ccz_moments_subset(ccz_handle h, const double* moments_dev, int64_t D, int64_t col0, int64_t D_sub,
+                       double* subset_dev) {
+  CCZ_GUARD(h, {
+    if (!moments_dev || !subset_dev || D < 1 || D_sub < 1 || col0 < 0 || col0 + D_sub > D)
+      ccz::fail(CCZ_EINVAL, "bad argument");
+    ccz::copy2d(h, D_sub, D_sub, moments_dev + col0 * D + col0, D, subset_dev, D_sub);
+    ccz::copy2d(h, 1, D_sub, moments_dev + D * D + col0, D, subset_dev + D_sub * D_sub, D_sub);
+  })
+}
+
 int ccz_gemm_f64(ccz_handle h, int transA, int transB, int64_t M, int64_t N, int64_t K,
                  double alpha, const double* A_dev, int64_t lda, const double* B_dev, int64_t ldb,
                  double beta, double* C_dev, int64_t ldc) {

@@ -105,6 +105,12 @@ CCZ_API int ccz_moments_unpack(ccz_handle h, const double* packed_dev, int64_t D
  * outside a cross-validation fold -- the Gram reuse behind cca_zoo_amd.model_selection.GridSearchCV
  * (the reference refits from the data for every fold and setting: cca_zoo/model_selection/_search.py:211-262). */
 CCZ_API int ccz_moments_axpby(ccz_handle h, int64_t D, double alpha, const double* x_dev, double beta, double* y_dev);
+/* Moments of a contiguous subset [col0, col0 + D_sub) of the stacked columns: the D_sub x D_sub block of G
+ * (upper triangle authoritative, as produced by ccz_moments) and the matching column sums, repacked into a
+ * [G | s] buffer of width D_sub.  Lets one K1 pass over [confounds | views] serve PartialCCA
+ * (cca_zoo/linear/_partialcca.py:67-103: the views' block is then corrected by a rank-(1 + dz) GEMM). */
+CCZ_API int ccz_moments_subset(ccz_handle h, const double* moments_dev, int64_t D, int64_t col0, int64_t D_sub,
+                               double* subset_dev);
 /* kernel timing of the last ccz_moments call on this handle (HIP events on the
  * handle's stream): milliseconds of the Gram kernel(s) and of the column-sum pass */
 CCZ_API int ccz_moments_last_ms(ccz_handle h, double* gram_ms, double* colsum_ms);

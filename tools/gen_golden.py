@@ -254,3 +254,47 @@ grid_case("mcca", MCCA(), {"c": [0.0, 0.1, 0.7], "latent_dimensions": [2]}, gv, 
 grid_case("gcca", GCCA(), {"c": [0.05, 0.3], "latent_dimensions": [1, 2]}, gv, 3)
 np.savez_compressed(os.path.join(OUT, "grid_search.npz"), **store)
 print("grid_search", len(store), "arrays")
+
+# ------------------------------------------------------------------------------------------------
+# PartialCCA / GRCCA: MCCA hooks on deconfounded / group-augmented views
+# ------------------------------------------------------------------------------------------------
+from cca_zoo.linear import GRCCA, PartialCCA  # noqa: E402
+
+store = {}
+rng = np.random.default_rng(21)
+n = 180
+conf = rng.standard_normal((n, 3)) + np.array([0.5, -0.2, 1.0])          # confounds with non-zero means
+lat = rng.standard_normal((n, 2)) * np.array([1.8, 1.1])
+pv = [lat @ rng.standard_normal((2, p)) + conf @ rng.standard_normal((3, p)) + 0.8 * rng.standard_normal((n, p)) + off
+      for p, off in ((10, 1.0), (7, -0.5), (6, 0.0))]
+store["partials"] = conf
+for i, v in enumerate(pv):
+    store[f"view{i}"] = v
+for tag, kw, vs in (("pcca_2v", dict(latent_dimensions=2), pv[:2]),
+                    ("pcca_3v_ridge", dict(latent_dimensions=2, c=[0.1, 0.3, 0.0]), pv),
+                    ("pcca_nocenter", dict(latent_dimensions=1, center=False, c=0.2), pv[:2])):
+    m = PartialCCA(**kw).fit(vs, partials=conf)
+    for i, w in enumerate(m.weights_):
+        store[f"{tag}/w{i}"] = np.asarray(w)
+    for i, b in enumerate(m.confound_betas_):
+        store[f"{tag}/beta{i}"] = np.asarray(b)
+    for i, mu in enumerate(m.means_):
+        store[f"{tag}/mean{i}"] = np.asarray(mu)
+    for i, t in enumerate(m.transform(vs, partials=conf)):
+        store[f"{tag}/transform_partials{i}"] = t[:6]
+    for i, t in enumerate(m.transform(vs)):
+        store[f"{tag}/transform_plain{i}"] = t[:6]
+    store[f"{tag}/score"] = m.score(vs)
+groups = [np.array([0, 0, 0, 1, 1, 2, 2, 2, 2, 3]), np.array([5, 5, 7, 7, 7, 9, 9]), np.array([1, 1, 1, 2, 2, 2])]
+for i, gidx in enumerate(groups):
+    store[f"groups{i}"] = gidx
+for tag, kw, vs, gs in (("grcca_2v", dict(latent_dimensions=2, c=[0.5, 0.8], mu=[0.3, 0.0]), pv[:2], groups[:2]),
+                        ("grcca_3v_mixed", dict(latent_dimensions=2, c=[0.4, 0.0, 0.9], mu=[1.5, 0.2, 0.0]), pv, groups)):
+    m = GRCCA(**kw).fit(vs, feature_groups=gs)
+    for i, w in enumerate(m.weights_):
+        store[f"{tag}/w{i}"] = np.asarray(w)
+    store[f"{tag}/score"] = m.score(vs)
+    for i, t in enumerate(m.transform(vs)):
+        store[f"{tag}/transform{i}"] = t[:6]
+np.savez_compressed(os.path.join(OUT, "partial_group.npz"), **store)
+print("partial_group", len(store), "arrays")
