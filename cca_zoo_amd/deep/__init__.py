@@ -1,5 +1,5 @@
 """Differentiable CCA objectives on the MI355X solver core."""
 
-from cca_zoo_amd.deep.objectives import CCALoss, MCCALoss
+from cca_zoo_amd.deep.objectives import CCALoss, GCCALoss, MCCALoss
 
-__all__ = ["CCALoss", "MCCALoss"]
+__all__ = ["CCALoss", "GCCALoss", "MCCALoss"]

@@ -122,3 +122,103 @@ class MCCALoss(nn.Module):
             for j in range(i + 1, n_views):
                 total = total + self._cca_loss([representations[i], representations[j]])
         return total
+
+
+def _project(x: torch.Tensor, mean64: torch.Tensor, w64: torch.Tensor) -> torch.Tensor:
+    """``(x - mean) @ w`` through ``ccz_transform`` (x: n x d CUDA tensor, mean: d, w: d x k float64 CUDA)."""
+    h = _backend.default_handle(x.device.index or 0)
+    a = x if x.stride(1) == 1 else x.contiguous()
+    out = torch.empty((a.shape[0], w64.shape[1]), dtype=a.dtype, device=a.device)
+    torch.cuda.current_stream(a.device).synchronize()
+    h.check(h.lib.ccz_transform(h.raw, _backend.F32 if a.dtype == torch.float32 else _backend.F64,
+                                C.c_void_p(a.data_ptr()), a.shape[0], a.shape[1], a.stride(0),
+                                C.c_void_p(mean64.data_ptr()), C.c_void_p(w64.data_ptr()), w64.shape[1],
+                                C.c_void_p(out.data_ptr()), out.stride(0)))
+    h.sync()
+    return out
+
+
+class _GCCALossFn(torch.autograd.Function):
+    """MAX-VAR GCCA loss from second moments (reference: cca_zoo/deep/objectives.py:155-220).
+
+    The reference whitens every view with an eigen inverse square root, forms the n x n Gram of the stacked
+    whitened views and sums its top-k eigenvalues.  The non-zero spectrum of that n x n matrix is
+    ``(n-1) x`` the generalised eigenvalues of ``C u = lambda B u`` with ``C`` the centred covariance of the
+    stacked views and ``B = blockdiag(C_ii) + eps I``: one K1 pass over ``[z_1 .. z_m]``, one D x D
+    generalised top-k eigen-solve (``ccz_gevp_topk``), and the closed-form gradient
+    ``dL/dZ = (Z - mean) Gamma``, ``Gamma = -2 sum_k (u u' - lambda blockdiag(u_i u_i'))`` as one MFMA GEMM.
+    """
+
+    @staticmethod
+    def forward(ctx, eps: float, *zs: torch.Tensor) -> torch.Tensor:
+        import numpy as np
+
+        for z in zs:
+            _require_cuda(z, "GCCALoss")
+            if z.dim() != 2 or z.shape[0] != zs[0].shape[0]:
+                raise ValueError("GCCALoss expects (batch, d_i) tensors with equal batch size")
+        dt = zs[0].dtype
+        zcat = torch.cat([z.to(dt) for z in zs], dim=1).contiguous()
+        n, D = int(zcat.shape[0]), int(zcat.shape[1])
+        dims = [int(z.shape[1]) for z in zs]
+        k = dims[0]
+        dev = zcat.device
+        h = _backend.default_handle(dev.index or 0)
+        mom = torch.empty(D * D + D, dtype=torch.float64, device=dev)
+        torch.cuda.current_stream(dev).synchronize()
+        h.moments([(zcat.data_ptr(), D, D)], n, _backend.F32 if dt == torch.float32 else _backend.F64, True, mom.data_ptr())
+        h.moments_symmetrize(mom.data_ptr(), D)
+        flat = h.to_host(mom.data_ptr(), (D * D + D,))
+        G, s = flat[: D * D].reshape(D, D), flat[D * D:]
+        Cm = (G - np.outer(s, s) / n) / (n - 1)
+        Bm = np.zeros_like(Cm)
+        mask = np.zeros((D, D), dtype=bool)
+        o = 0
+        for d in dims:
+            Bm[o:o + d, o:o + d] = Cm[o:o + d, o:o + d]
+            mask[o:o + d, o:o + d] = True
+            o += d
+        Bm[np.diag_indices(D)] += eps
+        # top-k generalised eigenpairs on the device; all D x D products below are device GEMMs as well
+        Ad, Bd = h.to_device(Cm), h.to_device(Bm)
+        wd, Vd = h.alloc(k * 8), h.alloc(D * k * 8)
+        h.check(h.lib.ccz_gevp_topk(h.raw, C.c_void_p(Ad.ptr), C.c_void_p(Bd.ptr), D, k, C.c_void_p(wd.ptr), C.c_void_p(Vd.ptr)))
+        lam, U = h.to_host(wd, (k,)), h.to_host(Vd, (D, k))
+        BUd = h.alloc(D * k * 8)
+        h.gemm(0, 0, D, k, D, 1.0, Bd.ptr, D, Vd.ptr, k, 0.0, BUd.ptr, k)
+        U = U / np.sqrt((U * h.to_host(BUd, (D, k))).sum(axis=0))[None, :]          # u' B u = 1
+        loss = torch.tensor(-(n - 1) * float(lam.sum()), dtype=dt, device=dev)
+        if any(ctx.needs_input_grad[1:]):
+            Ud, ULd = h.to_device(U), h.to_device(U * lam[None, :])
+            Pd, Qd = h.alloc(D * D * 8), h.alloc(D * D * 8)
+            h.gemm(0, 1, D, D, k, 1.0, Ud.ptr, k, Ud.ptr, k, 0.0, Pd.ptr, D)          # sum_k u u'
+            h.gemm(0, 1, D, D, k, 1.0, ULd.ptr, k, Ud.ptr, k, 0.0, Qd.ptr, D)         # sum_k lambda u u'
+            Gamma = -2.0 * (h.to_host(Pd, (D, D)) - np.where(mask, h.to_host(Qd, (D, D)), 0.0))
+            gam = torch.as_tensor(Gamma, device=dev)
+            mean = torch.as_tensor(s / n, device=dev)
+            ctx.save_for_backward(_project(zcat, mean, gam))
+            ctx.dims = dims
+            ctx.dtypes = [z.dtype for z in zs]
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (gcat,) = ctx.saved_tensors
+        grads = torch.split(gcat, ctx.dims, dim=1)
+        return (None, *[(grad_out * g).to(t) for g, t in zip(grads, ctx.dtypes)])
+
+
+class GCCALoss(nn.Module):
+    r"""MAX-VAR generalised CCA loss for any number of views: ``-sum_{d<=k} lambda_d(sum_i H_i H_i')`` with
+    ``H_i`` the centred, ridge-whitened representation of view i and k the width of the first view.
+
+    Args:
+        eps: ridge added to the within-view batch covariances (default 1e-5).
+    """
+
+    def __init__(self, eps: float = 1e-5) -> None:
+        super().__init__()
+        self.eps = eps
+
+    def forward(self, representations: list[torch.Tensor]) -> torch.Tensor:
+        return _GCCALossFn.apply(self.eps, *representations)

@@ -95,3 +95,72 @@ def mcca_loss_closed_form(zs, eps=1e-5):
             grads[i] += gi
             grads[j] += gj
     return total, grads
+
+
+# --------------------------------------------------------------------------
+# GCCALoss (cca_zoo/deep/objectives.py:155-220) and _BatchWhiten (deep/_dcca_noi.py:12-67)
+# --------------------------------------------------------------------------
+def gcca_loss_autograd(zs, eps: float = 1e-5) -> torch.Tensor:
+    """Reference-structured: whiten every view with the eigen inverse square root, n x n Gram of the
+    stacked whitened views, minus the sum of its top-k eigenvalues (k = width of the first view)."""
+    n = zs[0].shape[0]
+    hs = []
+    for z in zs:
+        zc = z - z.mean(dim=0)
+        cov = zc.T @ zc / (n - 1) + eps * torch.eye(zc.shape[1], dtype=zc.dtype)
+        hs.append(zc @ inv_sqrtm_eigh(cov, eps))
+    m = sum(h @ h.T for h in hs)
+    return -torch.linalg.eigvalsh(m)[-zs[0].shape[1]:].sum()
+
+
+def gcca_loss_closed_form(zs, eps=1e-5):
+    """Second-moment form (what the product computes).
+
+    The non-zero spectrum of ``sum_i H_i H_i'`` (n x n) is that of ``[H_1..H_m]'[H_1..H_m]`` (D x D), which is
+    ``(n-1) B^-1/2 C B^-1/2`` with ``C`` the centred covariance of the stacked views and
+    ``B = blockdiag(C_ii) + eps I`` -- i.e. (n-1) times the generalised eigenvalues of ``C u = lambda B u``
+    (any whitening of the blocks gives the same spectrum).  With ``u' B u = 1``:
+    ``d lambda = u'(dC) u - lambda sum_i u_i'(dC_ii) u_i``, hence
+    ``dL/dZ = Zc Gamma``,  ``Gamma = -2 sum_{top k} (u u' - lambda blockdiag(u_i u_i'))``.
+    Returns (loss, [grad_i]) as float64 numpy arrays.
+    """
+    zs = [np.asarray(z, dtype=np.float64) for z in zs]
+    n = zs[0].shape[0]
+    dims = [z.shape[1] for z in zs]
+    X = np.hstack(zs)
+    Xc = X - X.mean(axis=0)
+    C = Xc.T @ Xc / (n - 1)
+    B = np.zeros_like(C)
+    o = 0
+    for d in dims:
+        B[o:o + d, o:o + d] = C[o:o + d, o:o + d]
+        o += d
+    B += eps * np.eye(B.shape[0])
+    import scipy.linalg
+
+    lam, U = scipy.linalg.eigh(C, B)                       # ascending, U' B U = I
+    k = dims[0]
+    lam, U = lam[-k:], U[:, -k:]
+    loss = -(n - 1) * lam.sum()
+    Gamma = np.zeros_like(C)
+    for j in range(k):
+        u = U[:, j]
+        Gamma += np.outer(u, u)
+        o = 0
+        for d in dims:
+            Gamma[o:o + d, o:o + d] -= lam[j] * np.outer(u[o:o + d], u[o:o + d])
+            o += d
+    Gamma *= -2.0
+    dX = Xc @ Gamma
+    return loss, np.split(dX, np.cumsum(dims)[:-1], axis=1)
+
+
+def batch_whiten_step(x, running, momentum, eps):
+    """One training step of _BatchWhiten: EMA of the UNCENTRED second moment x'x/n, whitening by the eigen
+    inverse square root (eigenvalues clamped at eps) of the updated running matrix; no gradient flows through
+    the whitening matrix.  Returns (y, new_running, w) as float64 numpy arrays."""
+    x = np.asarray(x, dtype=np.float64)
+    running = (1.0 - momentum) * np.asarray(running, dtype=np.float64) + momentum * (x.T @ x / x.shape[0])
+    vals, vecs = np.linalg.eigh(running)
+    w = (vecs / np.sqrt(np.maximum(vals, eps))) @ vecs.T
+    return x @ w, running, w

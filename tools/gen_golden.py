@@ -298,3 +298,54 @@ for tag, kw, vs, gs in (("grcca_2v", dict(latent_dimensions=2, c=[0.5, 0.8], mu=
         store[f"{tag}/transform{i}"] = t[:6]
 np.savez_compressed(os.path.join(OUT, "partial_group.npz"), **store)
 print("partial_group", len(store), "arrays")
+
+# ------------------------------------------------------------------------------------------------
+# GCCALoss and _BatchWhiten
+# ------------------------------------------------------------------------------------------------
+import importlib.machinery  # noqa: E402
+
+from cca_zoo.deep.objectives import GCCALoss  # noqa: E402
+
+if "lightning" not in sys.modules:      # shim: _dcca_noi.py imports the Lightning base class only to subclass it
+    _l = types.ModuleType("lightning")
+    _l.__spec__ = importlib.machinery.ModuleSpec("lightning", None)
+    _lp = types.ModuleType("lightning.pytorch")
+    _lp.__spec__ = importlib.machinery.ModuleSpec("lightning.pytorch", None)
+    _lp.LightningModule = torch.nn.Module
+    _l.pytorch = _lp
+    sys.modules["lightning"] = _l
+    sys.modules["lightning.pytorch"] = _lp
+from cca_zoo.deep._dcca_noi import _BatchWhiten  # noqa: E402
+
+store = {}
+torch.manual_seed(7)
+base = torch.randn(300, 5, dtype=torch.float64)
+for tag, dims, eps in (("gcca3", (5, 5, 5), 1e-5), ("gcca2_eps", (5, 5), 1e-2), ("gcca4", (5, 5, 5, 5), 1e-4)):
+    zs = [(base @ torch.randn(5, d, dtype=torch.float64) + 0.8 * torch.randn(300, d, dtype=torch.float64) + 0.3 * i)
+          .requires_grad_(True) for i, d in enumerate(dims)]
+    loss = GCCALoss(eps=eps)(zs)
+    loss.backward()
+    for i, z in enumerate(zs):
+        store[f"{tag}/z{i}"] = z.detach().numpy()
+        store[f"{tag}/g{i}"] = z.grad.numpy()
+    store[f"{tag}/loss"] = loss.detach().numpy()
+    store[f"{tag}/eps"] = np.float64(eps)
+# _BatchWhiten: three training steps (running covariance EMA), gradient of a fixed functional, eval passthrough
+bw = _BatchWhiten(6, momentum=0.2, eps=1e-4).double()
+bw.train()
+torch.manual_seed(8)
+mix = torch.randn(6, 6, dtype=torch.float64)
+for step in range(3):
+    x = (torch.randn(120, 6, dtype=torch.float64) @ mix + 0.1 * step).requires_grad_(True)
+    y = bw(x)
+    coef = torch.linspace(0.5, 1.5, 6, dtype=torch.float64)
+    ((y * y) @ coef).sum().backward()
+    store[f"bw/x{step}"] = x.detach().numpy()
+    store[f"bw/y{step}"] = y.detach().numpy()
+    store[f"bw/gx{step}"] = x.grad.numpy()
+    store[f"bw/running{step}"] = bw.running_covar.detach().numpy().copy()
+bw.eval()
+store["bw/eval_identity"] = np.float64(float((bw(x.detach()) - x.detach()).abs().max()))
+store["bw/num_batches"] = np.int64(int(bw.num_batches_tracked))
+np.savez_compressed(os.path.join(OUT, "deep_next.npz"), **store)
+print("deep_next", len(store), "arrays")
