@@ -107,21 +107,36 @@ class BaseModel(BaseEstimator, ABC):
         return self.average_pairwise_correlations(views)
 
     def pairwise_correlations(self, views) -> np.ndarray:
-        """(n_views, n_views, k) Pearson correlations between canonical variates."""
-        zs = self.transform(views)
-        if is_device_tensor(zs[0]):
-            import torch
+        """(n_views, n_views, k) Pearson correlations between canonical variates.
 
-            T = torch.stack([z.double() for z in zs], dim=0)
-            T = T - T.mean(dim=1, keepdim=True)
-            nrm = torch.sqrt((T * T).sum(dim=1, keepdim=True))
-            T = T / torch.where(nrm > 1e-12, nrm, torch.ones_like(nrm))
-            return torch.einsum("isd,jsd->ijd", T, T).cpu().numpy()
-        T = np.stack(zs, axis=0)
-        T = T - T.mean(axis=1, keepdims=True)
-        nrm = np.sqrt((T**2).sum(axis=1, keepdims=True))
-        T = T / np.where(nrm > 1e-12, nrm, 1.0)
-        return np.einsum("isd,jsd->ijd", T, T)
+        The reference stacks the n x k variates and reduces them on the host (``_base.py:150-172``); here the
+        variates (host arrays or CUDA tensors, as ``transform`` returned them) go through one K1 pass
+        (``ccz_moments`` on the m*k stacked columns) and the correlations are read off their second moments:
+        ``corr = (G_ab - s_a s_b / n) / (nrm_a nrm_b)``, ``nrm_a^2 = G_aa - s_a^2 / n``, with the reference's
+        guard (``nrm <= 1e-12`` -> divide by 1).  Inside ``row_sharded()`` the moments are all-reduced, i.e. the
+        correlations are those of the global sample."""
+        from cca_zoo_amd import _backend
+        from cca_zoo_amd._moments import compute_moments
+
+        zs = self.transform(views)
+        m, k = len(zs), int(zs[0].shape[1])
+        h = _backend.default_handle()
+        mom, keep, n, _, _ = compute_moments(zs, h)
+        D = m * k
+        h.moments_symmetrize(mom, D)
+        flat = h.to_host(mom, (D * D + D,))
+        del keep
+        G, s = flat[: D * D].reshape(D, D), flat[D * D:]
+        S = G - np.outer(s, s) / n
+        nrm = np.sqrt(np.maximum(np.diag(S), 0.0))
+        nrm = np.where(nrm > 1e-12, nrm, 1.0)
+        R = S / np.outer(nrm, nrm)
+        idx = np.arange(k)
+        out = np.empty((m, m, k))
+        for i in range(m):
+            for j in range(m):
+                out[i, j] = R[i * k + idx, j * k + idx]
+        return out
 
     def average_pairwise_correlations(self, views) -> np.ndarray:
         R = self.pairwise_correlations(views)
