@@ -132,6 +132,127 @@ __global__ __launch_bounds__(256, 1) void k_gemm_f32_nn_big(int64_t M, int64_t N
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Projection shape: N <= 64 outputs per sample (transform / score: (X - mean) W with k <= 64 directions).
+// 2 n d k flop against n d 4 bytes: at k = 64 the MFMA time (3.3 ms per 1e6 x 4096 view) and the HBM time
+// (2.7 ms at 6 TB/s) are about equal, so the kernel has to keep both busy.  256 rows x 64 columns per
+// workgroup, 4 waves x (64 x 64) = 2 x 2 MFMA tiles each, the same LDS-transposed A staging as above,
+// B (converted once to fp32 and zero-padded to 64 columns) staged as [k][64]; 40 KiB of LDS -> three
+// workgroups per CU hide each other's staging.  Fragments are 8-byte reads (two consecutive m / n feed the
+// two tiles of a dimension: the stride-2 version of the ownership trick).
+// ---------------------------------------------------------------------------------------------------
+typedef float v2f32 __attribute__((ext_vector_type(2)));
+constexpr int TN = 64;
+
+__global__ __launch_bounds__(256, 3) void k_gemm_f32_nn_tall(int64_t M, int64_t N, int64_t K, float alpha,
+                                                             const float* __restrict__ A, int64_t lda,
+                                                             const float* __restrict__ B /* K x 64, padded */, float beta,
+                                                             float* __restrict__ C, int64_t ldc,
+                                                             const float* __restrict__ bias /* 64, padded */) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* lds = reinterpret_cast<float*>(smem);   // [2 buffers][A^T 16 x 256 | B 16 x 64]
+  constexpr int STG = BKK * (BT + TN);
+  const int64_t m0 = int64_t(blockIdx.x) * BT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t rows_valid = min<int64_t>(BT, M - m0);
+  const __amdgpu_buffer_rsrc_t srcA = make_rsrc(A + m0 * lda, ((rows_valid - 1) * lda + K) * 4);
+  const __amdgpu_buffer_rsrc_t srcB = make_rsrc(B, K * TN * 4);
+  const int voffA = int(int64_t(tid) * lda * 4);                       // thread t owns sample row m0 + t
+  const int voffB = ((tid >> 4) * TN + 4 * (tid & 15)) * 4;            // 16 rows x 16 float4 per k-block
+
+  v16f32 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  v4f32 ra[4], rb;
+  auto gload = [&](int64_t k0) {
+    const int soffA = __builtin_amdgcn_readfirstlane(int(k0 * 4));
+    const int soffB = __builtin_amdgcn_readfirstlane(int(k0 * TN * 4));
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      ra[i] = __builtin_bit_cast(v4f32, __builtin_amdgcn_raw_buffer_load_b128(srcA, voffA + 16 * i, soffA, 0));
+    rb = __builtin_bit_cast(v4f32, __builtin_amdgcn_raw_buffer_load_b128(srcB, voffB, soffB, 0));
+  };
+  auto lstore = [&](int buf) {
+    float* as = lds + buf * STG;
+    float* bs = as + BKK * BT;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) as[(4 * i + e) * BT + tid] = ra[i][e];          // transpose: [k][m]
+    *reinterpret_cast<v4f32*>(bs + (tid >> 4) * TN + 4 * (tid & 15)) = rb;
+  };
+
+  const int64_t nkb = K / BKK;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int64_t kb = 0; kb < nkb; ++kb) {
+    const int cur = int(kb & 1);
+    if (kb + 1 < nkb) gload((kb + 1) * BKK);
+    const float* as = lds + cur * STG;
+    const float* bs = as + BKK * BT;
+    v2f32 af[2], bf[2];
+    af[0] = *reinterpret_cast<const v2f32*>(as + (lane >> 5) * BT + wave * 64 + 2 * (lane & 31));
+    bf[0] = *reinterpret_cast<const v2f32*>(bs + (lane >> 5) * TN + 2 * (lane & 31));
+#pragma unroll
+    for (int kk = 0; kk < BKK / 2; ++kk) {
+      if (kk + 1 < BKK / 2) {
+        const int krow = 2 * (kk + 1) + (lane >> 5);
+        af[(kk + 1) & 1] = *reinterpret_cast<const v2f32*>(as + krow * BT + wave * 64 + 2 * (lane & 31));
+        bf[(kk + 1) & 1] = *reinterpret_cast<const v2f32*>(bs + krow * TN + 2 * (lane & 31));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const v2f32 a2 = af[kk & 1], b2 = bf[kk & 1];
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+          acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[ti], b2[tj], acc[ti][tj], 0, 0, 0);
+    }
+    if (kb + 1 < nkb) lstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  // lane holds, for every (ti, r), two consecutive n (tj = 0, 1) of sample row m
+  const int nb = 2 * (lane & 31);
+  v2f32 b2 = {0.f, 0.f};
+  if (bias) b2 = *reinterpret_cast<const v2f32*>(bias + nb);
+  const bool pair_ok = (ldc & 1) == 0 && nb + 1 < N;
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int trow = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int64_t m = m0 + wave * 64 + 2 * trow + ti;
+      if (m >= M || nb >= N) continue;
+      float* cp = C + m * ldc + nb;
+      v2f32 v = {acc[ti][0][r], acc[ti][1][r]};
+      v = (v - b2) * alpha;
+      if (pair_ok) {
+        if (beta != 0.f) v += beta * *reinterpret_cast<const v2f32*>(cp);
+        *reinterpret_cast<v2f32*>(cp) = v;
+      } else {
+        cp[0] = beta != 0.f ? v[0] + beta * cp[0] : v[0];
+        if (nb + 1 < N) cp[1] = beta != 0.f ? v[1] + beta * cp[1] : v[1];
+      }
+    }
+}
+
+// fp64 (rows x cols, ld ldi) -> fp32 (rows x cols_pad, zero-padded columns)
+__global__ void k_f64_to_f32_pad(int64_t rows, int64_t cols, int64_t cols_pad, const double* __restrict__ in, int64_t ldi,
+                                 float* __restrict__ out) {
+  const int64_t total = rows * cols_pad;
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += int64_t(gridDim.x) * blockDim.x) {
+    const int64_t r = i / cols_pad, cc = i - r * cols_pad;
+    out[i] = cc < cols ? float(in[r * ldi + cc]) : 0.f;
+  }
+}
+
 __global__ void k_f64_to_f32(int64_t total, int64_t cols, const double* __restrict__ in, int64_t ldi,
                              float* __restrict__ out, int64_t ldo) {
   for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += int64_t(gridDim.x) * blockDim.x) {
@@ -141,8 +262,17 @@ __global__ void k_f64_to_f32(int64_t total, int64_t cols, const double* __restri
 }
 
 // true if the big kernel can take this problem (else the caller uses the generic tiled GEMM)
+static bool tall_eligible(int64_t M, int64_t N, int64_t K, int64_t lda, const void* A, const void* C) {
+  if (N < 1 || N > TN || K % BKK != 0 || K < 256 || M < 8192) return false;
+  if (lda % 4 != 0 || reinterpret_cast<uintptr_t>(A) % 16 != 0 || reinterpret_cast<uintptr_t>(C) % 8 != 0) return false;
+  if (int64_t(BT) * lda * 4 >= (int64_t(1) << 31) || K * TN * 4 >= (int64_t(1) << 31)) return false;
+  if ((M + BT - 1) / BT >= (int64_t(1) << 31)) return false;
+  return true;
+}
+
 bool gemm_f32_big_eligible(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, const void* A,
                            const void* C) {
+  if (tall_eligible(M, N, K, lda, A, C)) return true;
   if (N % BT != 0 || K % BKK != 0 || K < BKK) return false;
   if ((M + BT - 1) / BT * (N / BT) < 256) return false;   // fewer tiles than CUs: the 64x64-tile kernel spreads better
   if (lda % 4 != 0 || ldc % 4 != 0) return false;
@@ -156,6 +286,21 @@ bool gemm_f32_big_eligible(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t
 void gemm_f32_big(ccz_ctx* c, int64_t M, int64_t N, int64_t K, double alpha, const float* A, int64_t lda,
                   const double* B, int64_t ldb, double beta, float* C, int64_t ldc, const double* bias_row) {
   hipStream_t st = stream(c);
+  if (tall_eligible(M, N, K, lda, A, C)) {
+    float* B32 = static_cast<float*>(dev_alloc(c, size_t(K + 1) * TN * 4));
+    float* bias32 = bias_row ? B32 + K * TN : nullptr;
+    hipLaunchKernelGGL(k_f64_to_f32_pad, dim3((unsigned)std::min<int64_t>((K * TN + 255) / 256, 1 << 20)), dim3(256), 0, st, K,
+                       N, int64_t(TN), B, ldb, B32);
+    if (bias_row)
+      hipLaunchKernelGGL(k_f64_to_f32_pad, dim3(1), dim3(256), 0, st, int64_t(1), N, int64_t(TN), bias_row, N, bias32);
+    const size_t lds_bytes = size_t(2) * BKK * (BT + TN) * 4;
+    hipLaunchKernelGGL(k_gemm_f32_nn_tall, dim3((unsigned)((M + BT - 1) / BT)), dim3(256), lds_bytes, st, M, N, K, float(alpha),
+                       A, lda, B32, float(beta), C, ldc, bias32);
+    CCZ_LAUNCH_CHECK();
+    CCZ_HIP(hipStreamSynchronize(st));   // B32 is pooled scratch
+    dev_free(c, B32);
+    return;
+  }
   float* B32 = static_cast<float*>(dev_alloc(c, size_t(K) * N * 4 + (bias_row ? size_t(N) * 4 : 0)));
   float* bias32 = bias_row ? B32 + K * N : nullptr;
   {

@@ -205,3 +205,27 @@ def test_seam_functions(H):
     w, V = gevp(g["A"], g["B"], 5)
     np.testing.assert_allclose(w, g["gevp_gen/w"], rtol=1e-10)
     assert col_rel_err(V, g["gevp_gen/V"]) < 1e-8
+
+
+@pytest.mark.parametrize("n,d,k,ld_extra,ldo_extra", [(9000, 272, 64, 0, 0), (8200, 256, 7, 8, 1), (20000, 1024, 32, 0, 0),
+                                                       (8192, 512, 1, 4, 0), (300, 40, 5, 0, 0)])
+def test_transform_f32_projection_kernel(H, n, d, k, ld_extra, ldo_extra):
+    """(X - mean) W for fp32 samples: the 256 x 64-tile projection kernel (n >= 8192, d % 16 == 0, k <= 64), ragged
+    row tail, padded output columns, strided input / output -- and the generic path for the small case."""
+    from cca_zoo_amd import _backend
+
+    rng = np.random.default_rng(n + d + k)
+    ld, ldo = d + ld_extra, k + ldo_extra
+    Xp = (rng.standard_normal((n, ld)) + 0.3).astype(np.float32)
+    mean = rng.standard_normal(d)
+    W = rng.standard_normal((d, k))
+    Xd, md, Wd = H.to_device(Xp), H.to_device(mean), H.to_device(W)
+    out0 = np.full((n, ldo), 7.0, dtype=np.float32)
+    od = H.to_device(out0)
+    call(H, "ccz_transform", _backend.F32, vp(Xd), n, d, ld, vp(md), vp(Wd), k, vp(od), ldo)
+    got = H.to_host(od, (n, ldo), dtype=np.float32)
+    ref = (Xp[:, :d].astype(np.float64) - mean) @ W
+    scale = np.abs(ref).max()
+    assert np.abs(got[:, :k] - ref).max() < 2e-5 * scale * np.sqrt(d)
+    if ldo_extra:
+        assert np.all(got[:, k:] == 7.0)                  # padding columns untouched
