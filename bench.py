@@ -101,6 +101,42 @@ def dcca_extra(steps=20, warmup=3, batch=8192, d=512, label="BASELINE configs[3]
             "tflops": flops / dt / 1e12}
 
 
+def sharded_dcca_extra(n_local, d, world, steps=2, warmup=1):
+    """DCCA CCALoss fwd+bwd on a batch of n rows sharded over the ranks (metric shape): K1 per shard, one packed
+    all-reduce, replicated d x d solve, local gradient GEMM.  Every rank calls this; returns seconds per step
+    (max over ranks)."""
+    import torch
+    import torch.distributed as dist
+
+    from cca_zoo_amd import row_sharded
+    from cca_zoo_amd.deep.objectives import CCALoss
+
+    torch.manual_seed(100 + dist.get_rank())
+    z1 = torch.randn(n_local, d, device="cuda", requires_grad=True)
+    z2 = torch.randn(n_local, d, device="cuda")
+    z2.add_(z1.detach(), alpha=0.5)
+    z2.requires_grad_(True)
+    obj = CCALoss(eps=1e-6)
+    for _ in range(warmup):
+        with row_sharded():
+            obj([z1, z2]).backward()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        z1.grad = None
+        z2.grad = None
+        with row_sharded():
+            obj([z1, z2]).backward()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t = torch.tensor([(time.perf_counter() - t0) / steps], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def grid_extra(views, k, fit_ms):
     """GridSearchCV over 8 ridge values x 5 folds (+ refit) on the SAME views from one pass
     over the data (moments per fold, training moments by subtraction); the reference refits 41 times."""
@@ -185,6 +221,13 @@ def main():
         elapsed = float(t.item())
     ms_per_step = elapsed / a.steps * 1e3
 
+    sharded_loss_s = None
+    if world > 1 and not a.no_dcca and 8.0 * n_local * a.d * 4 < 150e9:
+        del views
+        torch.cuda.empty_cache()
+        views = None
+        sharded_loss_s = sharded_dcca_extra(n_local, a.d, world)
+
     if rank == 0:
         D = 2 * a.d
         flop = float(n_local) * D * (D + 1)                    # algorithmic flops of ONE Gram launch (this rank)
@@ -219,6 +262,10 @@ def main():
                          "bytes_per_launch": float(n_local) * D * (4 if a.dtype == "f32" else 8),
                          "gram_share_of_step": g_ms / ms_per_step},
         }
+        if sharded_loss_s is not None:
+            out["extra"] = {"dcca_loss_metric_shape_sharded": {
+                "metric": f"DCCA CCALoss fwd+bwd/sec (batch {a.n} sharded over {world} GPUs, 2x{a.d}, fp32)",
+                "value": 1.0 / sharded_loss_s, "ms": sharded_loss_s * 1e3}}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.n, a.d, a.k, a.cpu_sample_rows)
         if world == 1 and not a.no_dcca:

@@ -84,6 +84,7 @@ SIGNATURES = {
     "ccz_moments_subset": (_int, [_vp, _vp, _i64, _i64, _i64, _vp]),
     "ccz_gemm_f64": (_int, [_vp, _int, _int, _i64, _i64, _i64, _dbl, _vp, _i64, _vp, _i64, _dbl, _vp, _i64]),
     "ccz_cca_loss": (_int, [_vp, _int, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _dbl, _vp, _vp, _vp, _i64, _i64]),
+    "ccz_cca_loss_moments": (_int, [_vp, _vp, _i64, _i64, _i64, _dbl, C.POINTER(_dbl), _vp, _vp]),
     "ccz_transform": (_int, [_vp, _int, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _i64]),
 }
 

@@ -34,21 +34,18 @@ namespace ccz {
 // reference: cca_zoo/deep/objectives.py:61-102 (forward) + autograd backward;
 // maths: oracle/losses.py::cca_loss_closed_form
 // ---------------------------------------------------------------------------
-static void cca_loss_impl(ccz_ctx* c, int dtype, const void* z1, const void* z2, int64_t n, int64_t d1, int64_t d2,
-                          int64_t ld1, int64_t ld2, double eps, void* loss_dev, void* g1, void* g2, int64_t ldg1,
-                          int64_t ldg2) {
-  if (dtype != CCZ_F32 && dtype != CCZ_F64) fail(CCZ_EUNSUP, "cca_loss: dtype must be CCZ_F32 or CCZ_F64");
-  if (!z1 || !z2 || !loss_dev) fail(CCZ_EINVAL, "cca_loss: null argument");
-  if (n < 2 || d1 < 1 || d2 < 1 || ld1 < d1 || ld2 < d2) fail(CCZ_EINVAL, "cca_loss: bad shape");
-  if ((g1 && ldg1 < d1) || (g2 && ldg2 < d2)) fail(CCZ_EINVAL, "cca_loss: bad gradient stride");
-  const int64_t D = d1 + d2;
-  DBuf mom(c, D * D + D);
-  ccz_view views[2] = {{z1, d1, ld1}, {z2, d2, ld2}};
-  moments_impl(c, dtype, views, 2, n, true, mom, false);
-  double* G = mom;
-  double* s = mom.get() + D * D;
-  const double inv = 1.0 / double(n - 1);
+// Everything between the batch moments and the sample-side GEMMs: loss value and the four d x d gradient
+// matrices (dz1 = ((z1 - mu1) G11s + (z2 - mu2) G12') / (n-1), dz2 = ((z1 - mu1) G12 + (z2 - mu2) G22s) / (n-1)).
+struct LossCore {
+  DBuf G11s, G22s, G12, G12t, mu;
+  double loss = 0.0;
+};
 
+static LossCore cca_loss_core(ccz_ctx* c, const double* G, const double* s, int64_t n, int64_t d1, int64_t d2, double eps,
+                              bool want1, bool want2) {
+  const int64_t D = d1 + d2;
+  const double inv = 1.0 / double(n - 1);
+  LossCore out;
   DBuf L1(c, d1 * d1), L2(c, d2 * d2), S12(c, d1 * d2);
   cov_block(c, G, D, s, n, true, inv, 0, d1, 0, d1, L1, d1);
   add_diag(c, d1, L1, d1, eps);
@@ -76,15 +73,15 @@ static void cca_loss_impl(ccz_ctx* c, int dtype, const void* z1, const void* z2,
   };
   DBuf Li1 = tri_inverse(L1, d1), Li2 = tri_inverse(L2, d2);
   // left  solve: S^-1 M = Li' (Li M)      right solve: M S^-1 = (M Li') Li
-  auto solve_left = [&](const double* Li, int64_t d, bool transM, const double* M, int64_t ldm, int64_t r, double alpha, double* out) {
+  auto solve_left = [&](const double* Li, int64_t d, bool transM, const double* M, int64_t ldm, int64_t r, double alpha, double* o) {
     DBuf t(c, d * r);
     gemm(c, false, transM, d, r, d, 1.0, Li, d, M, ldm, 0.0, t, r);
-    gemm(c, true, false, d, r, d, alpha, Li, d, t, r, 0.0, out, r);
+    gemm(c, true, false, d, r, d, alpha, Li, d, t, r, 0.0, o, r);
   };
-  auto solve_right = [&](const double* Li, int64_t d, const double* M, int64_t ldm, int64_t r, double alpha, double* out) {
+  auto solve_right = [&](const double* Li, int64_t d, const double* M, int64_t ldm, int64_t r, double alpha, double* o) {
     DBuf t(c, r * d);
     gemm(c, false, true, r, d, d, 1.0, M, ldm, Li, d, 0.0, t, d);
-    gemm(c, false, false, r, d, d, alpha, t, d, Li, d, 0.0, out, d);
+    gemm(c, false, false, r, d, d, alpha, t, d, Li, d, 0.0, o, d);
   };
 
   DBuf A(c, d1 * d2), Bmt(c, d1 * d2);
@@ -94,39 +91,86 @@ static void cca_loss_impl(ccz_ctx* c, int dtype, const void* z1, const void* z2,
   row_dots(c, d1, d2, A, d2, Bmt, d2, rd);                    // tr(A Bm) = sum A o Bm'
   std::vector<double> rh(d1);
   d2h(c, rh.data(), rd, size_t(d1) * 8);
-  double loss = 0.0;
-  for (double v : rh) loss -= v;
-  if (dtype == CCZ_F32) { const float lf = float(loss); h2d(c, loss_dev, &lf, 4); }
-  else h2d(c, loss_dev, &loss, 8);
-  if (!g1 && !g2) return;
+  for (double v : rh) out.loss -= v;
+  if (!want1 && !want2) return out;
 
   // G12 = -2 S11^-1 S12 S22^-1 = -2 A S22^-1 (d1 x d2) and its transpose
-  DBuf G12(c, d1 * d2), G12t(c, d2 * d1);
-  solve_right(Li2, d2, A, d2, d1, -2.0, G12);
-  transpose(c, d1, d2, G12, d2, G12t, d1);
-  // mean row vector
-  DBuf mu(c, D);
-  d2d(c, mu, s, size_t(D) * 8);
-  axpby2d(c, 1, D, 1.0 / double(n), mu, D, 0.0, nullptr, 0);
-
-  if (g1) {
+  out.G12 = DBuf(c, d1 * d2);
+  out.G12t = DBuf(c, d2 * d1);
+  solve_right(Li2, d2, A, d2, d1, -2.0, out.G12);
+  transpose(c, d1, d2, out.G12, d2, out.G12t, d1);
+  out.mu = DBuf(c, D);
+  d2d(c, out.mu, s, size_t(D) * 8);
+  axpby2d(c, 1, D, 1.0 / double(n), out.mu, D, 0.0, nullptr, 0);
+  if (want1) {
     // G11 = A Bm S11^-1 = S11^-1 (S12 S22^-1 S21) S11^-1 is symmetric, so G11 + G11' = 2 G11
-    DBuf P(c, d1 * d1), G11s(c, d1 * d1), bias(c, d1);
+    DBuf P(c, d1 * d1);
+    out.G11s = DBuf(c, d1 * d1);
     gemm(c, false, true, d1, d1, d2, 1.0, A, d2, Bmt, d2, 0.0, P, d1);          // A Bm
-    solve_right(Li1, d1, P, d1, d1, 2.0, G11s);
-    gemm(c, false, false, 1, d1, d1, 1.0, mu, D, G11s, d1, 0.0, bias, d1);
-    gemm(c, false, false, 1, d1, d2, 1.0, mu.get() + d1, D, G12t, d1, 1.0, bias, d1);
-    gemm_mixed(c, dtype, n, d1, d1, inv, z1, ld1, G11s, d1, 0.0, g1, ldg1, bias);
-    gemm_mixed(c, dtype, n, d1, d2, inv, z2, ld2, G12t, d1, 1.0, g1, ldg1, nullptr);
+    solve_right(Li1, d1, P, d1, d1, 2.0, out.G11s);
+  }
+  if (want2) {
+    DBuf P(c, d2 * d2);
+    out.G22s = DBuf(c, d2 * d2);
+    gemm(c, true, false, d2, d2, d1, 1.0, Bmt, d2, A, d2, 0.0, P, d2);          // Bm A
+    solve_right(Li2, d2, P, d2, d2, 2.0, out.G22s);
+  }
+  return out;
+}
+
+static void cca_loss_impl(ccz_ctx* c, int dtype, const void* z1, const void* z2, int64_t n, int64_t d1, int64_t d2,
+                          int64_t ld1, int64_t ld2, double eps, void* loss_dev, void* g1, void* g2, int64_t ldg1,
+                          int64_t ldg2) {
+  if (dtype != CCZ_F32 && dtype != CCZ_F64) fail(CCZ_EUNSUP, "cca_loss: dtype must be CCZ_F32 or CCZ_F64");
+  if (!z1 || !z2 || !loss_dev) fail(CCZ_EINVAL, "cca_loss: null argument");
+  if (n < 2 || d1 < 1 || d2 < 1 || ld1 < d1 || ld2 < d2) fail(CCZ_EINVAL, "cca_loss: bad shape");
+  if ((g1 && ldg1 < d1) || (g2 && ldg2 < d2)) fail(CCZ_EINVAL, "cca_loss: bad gradient stride");
+  const int64_t D = d1 + d2;
+  DBuf mom(c, D * D + D);
+  ccz_view views[2] = {{z1, d1, ld1}, {z2, d2, ld2}};
+  moments_impl(c, dtype, views, 2, n, true, mom, false);
+  const double inv = 1.0 / double(n - 1);
+  LossCore k = cca_loss_core(c, mom, mom.get() + D * D, n, d1, d2, eps, g1 != nullptr, g2 != nullptr);
+  if (dtype == CCZ_F32) { const float lf = float(k.loss); h2d(c, loss_dev, &lf, 4); }
+  else h2d(c, loss_dev, &k.loss, 8);
+  if (!g1 && !g2) return;
+  if (g1) {
+    DBuf bias(c, d1);
+    gemm(c, false, false, 1, d1, d1, 1.0, k.mu, D, k.G11s, d1, 0.0, bias, d1);
+    gemm(c, false, false, 1, d1, d2, 1.0, k.mu.get() + d1, D, k.G12t, d1, 1.0, bias, d1);
+    gemm_mixed(c, dtype, n, d1, d1, inv, z1, ld1, k.G11s, d1, 0.0, g1, ldg1, bias);
+    gemm_mixed(c, dtype, n, d1, d2, inv, z2, ld2, k.G12t, d1, 1.0, g1, ldg1, nullptr);
   }
   if (g2) {
-    DBuf P(c, d2 * d2), G22s(c, d2 * d2), bias(c, d2);
-    gemm(c, true, false, d2, d2, d1, 1.0, Bmt, d2, A, d2, 0.0, P, d2);          // Bm A
-    solve_right(Li2, d2, P, d2, d2, 2.0, G22s);
-    gemm(c, false, false, 1, d2, d2, 1.0, mu.get() + d1, D, G22s, d2, 0.0, bias, d2);
-    gemm(c, false, false, 1, d2, d1, 1.0, mu, D, G12, d2, 1.0, bias, d2);
-    gemm_mixed(c, dtype, n, d2, d2, inv, z2, ld2, G22s, d2, 0.0, g2, ldg2, bias);
-    gemm_mixed(c, dtype, n, d2, d1, inv, z1, ld1, G12, d2, 1.0, g2, ldg2, nullptr);
+    DBuf bias(c, d2);
+    gemm(c, false, false, 1, d2, d2, 1.0, k.mu.get() + d1, D, k.G22s, d2, 0.0, bias, d2);
+    gemm(c, false, false, 1, d2, d1, 1.0, k.mu, D, k.G12, d2, 1.0, bias, d2);
+    gemm_mixed(c, dtype, n, d2, d2, inv, z2, ld2, k.G22s, d2, 0.0, g2, ldg2, bias);
+    gemm_mixed(c, dtype, n, d2, d1, inv, z1, ld1, k.G12, d2, 1.0, g2, ldg2, nullptr);
+  }
+  sync(c);
+}
+
+// Row-sharded batches: the moments have been summed over all ranks (ccz_moments + one all-reduce); this gives
+// the loss and ONE (d1 + d2)^2 matrix Gamma with  [dz1 | dz2] = ([z1 | z2] - 1 mean') Gamma  for any subset of
+// the rows (each rank applies it to its own shard with ccz_transform).
+static void cca_loss_moments_impl(ccz_ctx* c, const double* mom, int64_t n, int64_t d1, int64_t d2, double eps,
+                                  double* loss_host, double* gamma_dev, double* mean_dev) {
+  if (!mom || !loss_host) fail(CCZ_EINVAL, "cca_loss_moments: null argument");
+  if (n < 2 || d1 < 1 || d2 < 1) fail(CCZ_EINVAL, "cca_loss_moments: bad shape");
+  const int64_t D = d1 + d2;
+  const bool want = gamma_dev != nullptr;
+  if (want && !mean_dev) fail(CCZ_EINVAL, "cca_loss_moments: mean_dev is required with gamma_dev");
+  LossCore k = cca_loss_core(c, mom, mom + D * D, n, d1, d2, eps, want, want);
+  *loss_host = k.loss;
+  if (want) {
+    const double inv = 1.0 / double(n - 1);
+    copy2d(c, d1, d1, k.G11s, d1, gamma_dev, D);
+    copy2d(c, d1, d2, k.G12, d2, gamma_dev + d1, D);
+    copy2d(c, d2, d1, k.G12t, d1, gamma_dev + d1 * D, D);
+    copy2d(c, d2, d2, k.G22s, d2, gamma_dev + d1 * D + d1, D);
+    axpby2d(c, D, D, inv, gamma_dev, D, 0.0, nullptr, 0);
+    d2d(c, mean_dev, k.mu, size_t(D) * 8);
   }
   sync(c);
 }
@@ -286,6 +330,11 @@ int ccz_cca_loss(ccz_handle h, int dtype, const void* z1_dev, const void* z2_dev
   CCZ_GUARD(h, {
     cca_loss_impl(h, dtype, z1_dev, z2_dev, n, d1, d2, ld1, ld2, eps, loss_dev, g1_dev, g2_dev, ldg1, ldg2);
   })
+}
+
+int ccz_cca_loss_moments(ccz_handle h, const double* moments_dev, int64_t n_rows, int64_t d1, int64_t d2, double eps,
+                         double* loss_host, double* gamma_dev, double* mean_dev) {
+  CCZ_GUARD(h, ccz::cca_loss_moments_impl(h, moments_dev, n_rows, d1, d2, eps, loss_host, gamma_dev, mean_dev));
 }
 
 int ccz_transform(ccz_handle h, int dtype, const void* X_dev, int64_t n, int64_t d, int64_t ld, const double* mean_dev,

@@ -35,6 +35,56 @@ def _require_cuda(t: torch.Tensor, what: str) -> None:
         raise TypeError(f"{what}: dtype must be float32 or float64, got {t.dtype}")
 
 
+class _ShardedCCALossFn(torch.autograd.Function):
+    """CCALoss of a batch whose rows are spread over the ranks of ``row_sharded()``: K1 on the local rows, ONE
+    all-reduce of the packed (d1+d2)^2 moments, the d x d solve replicated on every rank
+    (``ccz_cca_loss_moments``) and the gradient of the GLOBAL loss with respect to the LOCAL rows as one
+    ``ccz_transform`` GEMM -- no all-gather of the embeddings."""
+
+    @staticmethod
+    def forward(ctx, z1: torch.Tensor, z2: torch.Tensor, eps: float) -> torch.Tensor:
+        from cca_zoo_amd import _dist
+
+        _require_cuda(z1, "CCALoss")
+        _require_cuda(z2, "CCALoss")
+        if z1.dim() != 2 or z2.dim() != 2 or z1.shape[0] != z2.shape[0]:
+            raise ValueError("CCALoss expects two (batch, d_i) tensors with equal batch size")
+        dt = z1.dtype
+        zcat = torch.cat([z1, z2.to(dt)], dim=1).contiguous()
+        n_local, D = int(zcat.shape[0]), int(zcat.shape[1])
+        d1, d2 = int(z1.shape[1]), int(z2.shape[1])
+        dev = zcat.device
+        h = _backend.default_handle(dev.index or 0)
+        mom = torch.empty(D * D + D, dtype=torch.float64, device=dev)
+        torch.cuda.current_stream(dev).synchronize()
+        h.moments([(zcat.data_ptr(), D, D)], n_local, _backend.F32 if dt == torch.float32 else _backend.F64, True, mom.data_ptr())
+        packed = torch.empty(D * (D + 1) // 2 + D, dtype=torch.float64, device=dev)
+        h.moments_pack(mom.data_ptr(), D, packed.data_ptr())
+        h.sync()
+        n_total = _dist.allreduce_moments(packed, n_local, _dist.active_group())
+        torch.cuda.current_stream(dev).synchronize()
+        h.moments_unpack(packed.data_ptr(), D, mom.data_ptr())
+        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        loss_h = C.c_double(0.0)
+        gamma = torch.empty((D, D), dtype=torch.float64, device=dev) if need else None
+        mean = torch.empty(D, dtype=torch.float64, device=dev) if need else None
+        h.check(h.lib.ccz_cca_loss_moments(h.raw, C.c_void_p(mom.data_ptr()), int(n_total), d1, d2, float(eps),
+                                           C.byref(loss_h), C.c_void_p(gamma.data_ptr()) if need else None,
+                                           C.c_void_p(mean.data_ptr()) if need else None))
+        if need:
+            g = _project(zcat, mean, gamma)
+            ctx.save_for_backward(g)
+            ctx.split = (d1, d2)
+            ctx.dtypes = (z1.dtype, z2.dtype)
+        return torch.tensor(loss_h.value, dtype=dt, device=dev)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (g,) = ctx.saved_tensors
+        g1, g2 = torch.split(g, ctx.split, dim=1)
+        return (grad_out * g1).to(ctx.dtypes[0]), (grad_out * g2).to(ctx.dtypes[1]), None
+
+
 class _CCALossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z1: torch.Tensor, z2: torch.Tensor, eps: float) -> torch.Tensor:
@@ -100,6 +150,10 @@ class CCALoss(nn.Module):
                 f"got {len(representations)}."
             )
         z1, z2 = representations
+        from cca_zoo_amd import _dist
+
+        if _dist.is_sharded():
+            return _ShardedCCALossFn.apply(z1, z2, self.eps)
         return _CCALossFn.apply(z1, z2, self.eps)
 
 

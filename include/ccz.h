@@ -179,6 +179,14 @@ CCZ_API int ccz_gemm_f64(ccz_handle h, int transA, int transB, int64_t M, int64_
 CCZ_API int ccz_cca_loss(ccz_handle h, int dtype, const void* z1_dev, const void* z2_dev, int64_t n,
                  int64_t d1, int64_t d2, int64_t ld1, int64_t ld2, double eps, void* loss_dev,
                  void* g1_dev, void* g2_dev, int64_t ldg1, int64_t ldg2);
+/* The same loss for a batch that is row-sharded over ranks: `moments_dev` holds the batch moments of
+ * [z1 | z2] summed over all shards (ccz_moments per rank + one all-reduce), n_rows the total batch size.
+ * Returns the loss (host) and, if gamma_dev != NULL, the (d1+d2) x (d1+d2) matrix Gamma and the batch mean
+ * (d1+d2) such that  [dz1 | dz2] = ([z1 | z2] - 1 mean') Gamma  for ANY subset of the rows: each rank
+ * applies it to its own shard with ccz_transform.  (Reference: the single-process CCALoss.forward,
+ * cca_zoo/deep/objectives.py:61-102; a DDP batch would otherwise need an all-gather of the embeddings.) */
+CCZ_API int ccz_cca_loss_moments(ccz_handle h, const double* moments_dev, int64_t n_rows, int64_t d1, int64_t d2,
+                                 double eps, double* loss_host, double* gamma_dev, double* mean_dev);
 
 /* ---- transform / score -------------------------------
  * out (n x k, dtype) = (X - mean) W ; X,out device; mean (d), W (d x k) device float64.

@@ -104,3 +104,73 @@ def test_loss_drives_training_step():
         opt.step()
         first = loss.item() if first is None else first
     assert loss.item() < first - 0.1
+
+
+@pytest.fixture(scope="module")
+def H():
+    from cca_zoo_amd import _backend
+
+    return _backend.default_handle(0)
+
+
+TAG64 = "cca/n256_d32_f64_eps0.0001"
+
+
+def test_sharded_loss_math_two_shards_one_gpu(H):
+    """ccz_cca_loss_moments: moments accumulated over two row shards give the full-batch loss, and Gamma applied to
+    each shard gives that shard's rows of the full-batch gradient (goldens of the reference)."""
+    import ctypes as C
+
+    from cca_zoo_amd import _backend
+
+    g = load_golden("losses")
+    z1, z2, eps = g[TAG64 + "/z1"], g[TAG64 + "/z2"], 1e-4
+    n, d1, d2 = z1.shape[0], z1.shape[1], z2.shape[1]
+    D = d1 + d2
+    zcat = np.ascontiguousarray(np.hstack([z1, z2]))
+    cut = n // 3
+    mom = H.alloc((D * D + D) * 8)
+    H.moments([(zcat[:cut], D, D)], cut, _backend.F64, False, mom.ptr)
+    H.moments([(zcat[cut:], D, D)], n - cut, _backend.F64, False, mom.ptr, accumulate=True)
+    loss = C.c_double()
+    gam, mean = H.alloc(D * D * 8), H.alloc(D * 8)
+    H.check(H.lib.ccz_cca_loss_moments(H.raw, C.c_void_p(mom.ptr), n, d1, d2, eps, C.byref(loss),
+                                       C.c_void_p(gam.ptr), C.c_void_p(mean.ptr)))
+    assert loss.value == pytest.approx(float(g[TAG64 + "/loss"]), rel=1e-9)
+    Gamma, mu = H.to_host(gam, (D, D)), H.to_host(mean, (D,))
+    np.testing.assert_allclose(mu, zcat.mean(axis=0), rtol=1e-12, atol=1e-14)
+    for rows in (slice(0, cut), slice(cut, n)):
+        grad = (zcat[rows] - mu) @ Gamma
+        np.testing.assert_allclose(grad[:, :d1], g[TAG64 + "/g1"][rows], rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(grad[:, d1:], g[TAG64 + "/g2"][rows], rtol=1e-6, atol=1e-9)
+    only = C.c_double()
+    H.check(H.lib.ccz_cca_loss_moments(H.raw, C.c_void_p(mom.ptr), n, d1, d2, eps, C.byref(only), None, None))
+    assert only.value == pytest.approx(loss.value, rel=1e-12)
+
+
+def test_sharded_loss_module_world_size_one():
+    """CCALoss inside row_sharded() (RCCL, world size 1 here): same value and gradients as the fused single-GPU path."""
+    import torch
+    import torch.distributed as dist
+
+    from cca_zoo_amd import row_sharded
+    from cca_zoo_amd.deep import CCALoss
+
+    started = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29653", rank=0, world_size=1)
+        started = True
+    try:
+        g = load_golden("losses")
+        for dtype, tol in ((torch.float64, 1e-6), (torch.float32, 1e-3)):
+            a = torch.tensor(g[TAG64 + "/z1"], dtype=dtype, device="cuda", requires_grad=True)
+            b = torch.tensor(g[TAG64 + "/z2"], dtype=dtype, device="cuda", requires_grad=True)
+            with row_sharded():
+                loss = CCALoss(eps=1e-4)([a, b])
+            loss.backward()
+            assert float(loss.detach()) == pytest.approx(float(g[TAG64 + "/loss"]), rel=tol)
+            for t, ref in ((a, g[TAG64 + "/g1"]), (b, g[TAG64 + "/g2"])):
+                assert np.abs(t.grad.double().cpu().numpy() - ref).max() < tol * np.abs(ref).max()
+    finally:
+        if started:
+            dist.destroy_process_group()
