@@ -170,8 +170,11 @@ def main():
             sys.exit("launch with torch.distributed.run for --gpus > 1")
     torch.cuda.set_device(local)
     os.environ["CCZ_DEVICE"] = str(local)
-    if world > 1:
+    # CCZ_BENCH_FORCE_SHARDED=1 runs the N > 1 code path (process group, row_sharded fits, sharded loss) with one rank
+    distributed = world > 1 or bool(os.environ.get("CCZ_BENCH_FORCE_SHARDED"))
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     from cca_zoo_amd import _backend, row_sharded, shard_bounds
@@ -190,7 +193,7 @@ def main():
     model = CCA(latent_dimensions=a.k)
 
     def step():
-        if world > 1:
+        if distributed:
             with row_sharded():
                 model.fit(views)
         else:
@@ -200,7 +203,7 @@ def main():
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -211,18 +214,18 @@ def main():
         gram_ms.append(h.moments_last_ms()[0])
         step_ms.append((time.perf_counter() - ts) * 1e3)
     torch.cuda.synchronize()
-    if world > 1:
+    if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / a.steps * 1e3
 
     sharded_loss_s = None
-    if world > 1 and not a.no_dcca and 8.0 * n_local * a.d * 4 < 150e9:
+    if distributed and not a.no_dcca and 8.0 * n_local * a.d * 4 < 150e9:
         del views
         torch.cuda.empty_cache()
         views = None
@@ -268,16 +271,28 @@ def main():
                 "value": 1.0 / sharded_loss_s, "ms": sharded_loss_s * 1e3}}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.n, a.d, a.k, a.cpu_sample_rows)
-        if world == 1 and not a.no_dcca:
+        if world == 1 and not a.no_dcca and views is not None:
             out["extra"] = {"dcca_loss": dcca_extra(), "grid_search": grid_extra(views, a.k, ms_per_step)}
             if a.n * a.d * 4 * 4 < 200e9:   # z1, z2 and their gradients must fit in HBM next to the views
                 del views
                 torch.cuda.empty_cache()
                 out["extra"]["dcca_loss_metric_shape"] = dcca_extra(steps=2, warmup=1, batch=a.n, d=a.d, label="metric shape")
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        line = json.dumps(out)
+    else:
+        line = None
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    # RCCL writes its version banner to the C stdout buffer, which would otherwise be flushed at exit AFTER the
+    # result: flush C stdio first so that the JSON is the last line on stdout
+    try:
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if line is not None:
+        print(line, flush=True)
 
 
 if __name__ == "__main__":
