@@ -10,6 +10,7 @@
 // image; consecutive lanes hit consecutive addresses, no bank conflicts).  B (K x N, row-major) is
 // already k-major and is staged exactly like a K1 panel.
 #include <algorithm>
+#include <cstdlib>
 
 #include "hip_common.h"
 
@@ -127,6 +128,145 @@ __global__ __launch_bounds__(256, 1) void k_gemm_f32_nn_big(int64_t M, int64_t N
       float* cp = C + m * ldc + nbase;
       v4f32 v = {acc[ti][0][r], acc[ti][1][r], acc[ti][2][r], acc[ti][3][r]};
       v = (v - b4) * alpha;
+      if (beta != 0.f) v += beta * *reinterpret_cast<const v4f32*>(cp);
+      *reinterpret_cast<v4f32*>(cp) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The same product on the wave-private LDS-DMA FIFO of K1 (gram.hip: k_gram_f32_fifo): no barriers, no
+// register staging, no LDS transpose.  What makes it possible for a SAMPLE-major A: the k order inside a
+// k-block is free, so lane l takes A[m = 32 ti + (l & 31)][k0 + 4 (l >> 5) .. + 3] as ONE 16-byte load and
+// uses its four floats as the A operand of k-steps t = 0..3 of tile ti (k-step t then multiplies
+// k = k0 + t on lanes 0-31 and k = k0 + 4 + t on lanes 32-63); the B fragment of step t is rows
+// k0 + t / k0 + 4 + t of B, four consecutive columns feeding the four column tiles as in K1.
+// Per 8-deep k-block a wave issues 4 A + 4 B buffer_load...lds (8 KiB slot, ring of 4), reads back its own
+// bytes with ds_read_b128 and orders everything with counted s_waitcnt vmcnt -- the K1 pipeline verbatim.
+// Block -> tile mapping keeps the 32 workgroups an XCD runs on two A stripes (shared through its L2).
+// ---------------------------------------------------------------------------------------------------
+constexpr int GFB = 8;                       // k per FIFO block
+constexpr int GFR = 4;                       // ring slots per wave
+constexpr int GFSLAB = 4 * 1024;             // bytes of the A (or B) part of a slot
+constexpr int GFSLOT = 2 * GFSLAB;
+
+__global__ __launch_bounds__(256, 1) void k_gemm_f32_nn_fifo(int64_t M, int64_t N, int64_t K, float alpha,
+                                                             const float* __restrict__ A, int64_t lda,
+                                                             const float* __restrict__ B, int64_t ldb, float beta,
+                                                             float* __restrict__ C, int64_t ldc,
+                                                             const float* __restrict__ bias) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int64_t tn = N / BT, tm = (M + BT - 1) / BT;
+  const int64_t q = int64_t(blockIdx.x) >> 3;
+  const int64_t mt = (q / tn) * 8 + (blockIdx.x & 7), nt = q % tn;
+  if (mt >= tm) return;
+  const int64_t m0 = mt * BT, n0 = nt * BT;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  char* ring = smem + wave * (GFR * GFSLOT);
+  const char* rd = ring + lane * 16;
+
+  const int64_t mw = m0 + wr * 128;                               // first sample row of this wave's slab
+  const int64_t rows_valid = min<int64_t>(128, M - mw);           // <= 0: slab entirely past M (nothing stored)
+  const __amdgpu_buffer_rsrc_t srcA = make_rsrc(A + (rows_valid > 0 ? mw : 0) * lda,
+                                                rows_valid > 0 ? ((rows_valid - 1) * lda + K) * 4 : 0);
+  const __amdgpu_buffer_rsrc_t srcB = make_rsrc(B + n0 + wc * 128, ((K - 1) * ldb + 128) * 4);
+  int voffA[4];
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti) voffA[ti] = int(((32 * ti + (lane & 31)) * lda + 4 * (lane >> 5)) * 4);
+  const int voffB = int(((4 * (lane >> 5)) * ldb + 4 * (lane & 31)) * 4);
+  const int rowB = __builtin_amdgcn_readfirstlane(int(ldb * 4));   // bytes per k row of B
+  int soffA = 0, soffB = 0;
+
+  v16f32 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // prologue: blocks 0, 1, 2 -> slots 0, 1, 2
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srcA, (lds_ptr)(ring + s * GFSLOT + u * 1024), 16, voffA[u], soffA, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srcB, (lds_ptr)(ring + s * GFSLOT + GFSLAB + u * 1024), 16, voffB, soffB, 0, 0);
+      soffB += rowB;
+    }
+    soffA += GFB * 4;
+    soffB += 4 * rowB;
+  }
+  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                  // block 0 landed
+  v4f32 ab[2][4], bf[2];
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti) ab[0][ti] = *reinterpret_cast<const v4f32*>(rd + ti * 1024);
+  bf[0] = *reinterpret_cast<const v4f32*>(rd + GFSLAB);
+
+  const int64_t nblk = K / GFB;
+  for (int64_t b0 = 0; b0 < nblk; b0 += GFR) {      // one trip = the whole ring period: slots are static
+#pragma unroll
+    for (int bb = 0; bb < GFR; ++bb) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int cur = (bb * 4 + u) & 1, nxt = cur ^ 1;
+        const int nslot = (u + 1 < 4) ? bb : (bb + 1) % GFR;
+        const int nu = (u + 1 < 4) ? u + 1 : 0;
+        const int wsl = (bb + 3) % GFR;               // slot being refilled: block b0 + bb + 3
+        const v4f32 b4 = bf[cur];
+        // -- gap 0: fragment reads for the next k-step (and, at the end of a block, the next block's A)
+        if (u == 3) {
+          asm volatile("s_waitcnt vmcnt(14)" ::: "memory");         // block b+1 landed (b+2: 8, three steps of b+3: 6)
+#pragma unroll
+          for (int ti = 0; ti < 4; ++ti)
+            ab[(bb + 1) & 1][ti] = *reinterpret_cast<const v4f32*>(rd + nslot * GFSLOT + ti * 1024);
+        }
+        bf[nxt] = *reinterpret_cast<const v4f32*>(rd + nslot * GFSLOT + GFSLAB + nu * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+          acc[0][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[bb & 1][0][u], b4[tj], acc[0][tj], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // -- gap 1: DMA of A tile u of block b+3
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srcA, (lds_ptr)(ring + wsl * GFSLOT + u * 1024), 16, voffA[u], soffA, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+          acc[1][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[bb & 1][1][u], b4[tj], acc[1][tj], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // -- gap 2: DMA of B rows of k-step u of block b+3
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srcB, (lds_ptr)(ring + wsl * GFSLOT + GFSLAB + u * 1024), 16, voffB, soffB, 0, 0);
+        soffB += rowB;
+        if (u == 3) { soffA += GFB * 4; soffB += 4 * rowB; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+          acc[2][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[bb & 1][2][u], b4[tj], acc[2][tj], 0, 0, 0);
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+          acc[3][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[bb & 1][3][u], b4[tj], acc[3][tj], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // epilogue: tile ti owns rows 32 ti + trow (plain), column tiles are strided (n = 4 (lane & 31) + tj)
+  const int64_t nbase = n0 + wc * 128 + 4 * (lane & 31);
+  v4f32 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (bias) bias4 = *reinterpret_cast<const v4f32*>(bias + nbase);
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int trow = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int64_t m = mw + 32 * ti + trow;
+      if (m >= M) continue;
+      float* cp = C + m * ldc + nbase;
+      v4f32 v = {acc[ti][0][r], acc[ti][1][r], acc[ti][2][r], acc[ti][3][r]};
+      v = (v - bias4) * alpha;
       if (beta != 0.f) v += beta * *reinterpret_cast<const v4f32*>(cp);
       *reinterpret_cast<v4f32*>(cp) = v;
     }
@@ -310,11 +450,22 @@ void gemm_f32_big(ccz_ctx* c, int64_t M, int64_t N, int64_t K, double alpha, con
     if (bias_row)
       hipLaunchKernelGGL(k_f64_to_f32, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, N, N, bias_row, N, bias32, N);
   }
-  const size_t lds_bytes = size_t(2) * 2 * BKK * BT * 4;
-  CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_f32_nn_big), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
-  const int64_t nblocks = (M + BT - 1) / BT * (N / BT);
-  hipLaunchKernelGGL(k_gemm_f32_nn_big, dim3((unsigned)nblocks), dim3(256), lds_bytes, st, M, N, K, float(alpha), A, lda, B32,
-                     N, float(beta), C, ldc, bias32);
+  static const int nn_impl = [] { const char* e = getenv("CCZ_GEMM_NN_IMPL"); return e ? atoi(e) : 1; }();   // 1: LDS-DMA FIFO, 0: staged tile
+  const int64_t tmb = (M + BT - 1) / BT, tnb = N / BT;
+  const bool fifo_ok = nn_impl != 0 && K % 32 == 0 && int64_t(128) * lda * 4 < (int64_t(1) << 31) &&
+                       (tmb + 7) / 8 * 8 * tnb < (int64_t(1) << 31);
+  if (fifo_ok) {
+    const size_t fifo_bytes = size_t(4) * GFR * GFSLOT;   // 128 KiB: four wave-private rings
+    CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_f32_nn_fifo), hipFuncAttributeMaxDynamicSharedMemorySize, int(fifo_bytes)));
+    hipLaunchKernelGGL(k_gemm_f32_nn_fifo, dim3((unsigned)((tmb + 7) / 8 * 8 * tnb)), dim3(256), fifo_bytes, st, M, N, K,
+                       float(alpha), A, lda, B32, N, float(beta), C, ldc, bias32);
+  } else {
+    const size_t lds_bytes = size_t(2) * 2 * BKK * BT * 4;
+    CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_f32_nn_big), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
+    const int64_t nblocks = tmb * tnb;
+    hipLaunchKernelGGL(k_gemm_f32_nn_big, dim3((unsigned)nblocks), dim3(256), lds_bytes, st, M, N, K, float(alpha), A, lda, B32,
+                       N, float(beta), C, ldc, bias32);
+  }
   CCZ_LAUNCH_CHECK();
   CCZ_HIP(hipStreamSynchronize(st));   // B32 is pooled scratch
   dev_free(c, B32);

@@ -229,3 +229,26 @@ def test_transform_f32_projection_kernel(H, n, d, k, ld_extra, ldo_extra):
     assert np.abs(got[:, :k] - ref).max() < 2e-5 * scale * np.sqrt(d)
     if ldo_extra:
         assert np.all(got[:, k:] == 7.0)                  # padding columns untouched
+
+
+@pytest.mark.parametrize("n,d,k,impl", [(65536, 288, 256, "1"), (65600, 512, 512, "1"), (65536, 256, 256, "0")])
+def test_transform_f32_wide_output_kernels(H, n, d, k, impl, monkeypatch):
+    """(X - mean) W with k a multiple of 256 and >= 256 output tiles: the 256 x 256-tile kernels (wave-private
+    LDS-DMA FIFO by default, register-staged tile with CCZ_GEMM_NN_IMPL=0; the choice is read once per process, so
+    the second variant is only exercised when this test runs first in a fresh process)."""
+    from cca_zoo_amd import _backend
+
+    monkeypatch.setenv("CCZ_GEMM_NN_IMPL", impl)
+    rng = np.random.default_rng(n + d + k)
+    Xp = (rng.standard_normal((n, d)) + 0.3).astype(np.float32)
+    mean = rng.standard_normal(d)
+    W = rng.standard_normal((d, k))
+    Xd, md, Wd = H.to_device(Xp), H.to_device(mean), H.to_device(W)
+    od = H.alloc(n * k * 4)
+    call(H, "ccz_transform", _backend.F32, vp(Xd), n, d, d, vp(md), vp(Wd), k, vp(od), k)
+    got = H.to_host(od, (n, k), dtype=np.float32)
+    rows = np.r_[0:300, n // 2:n // 2 + 300, n - 300:n]               # first / middle / ragged last tile
+    ref = (Xp[rows].astype(np.float64) - mean) @ W
+    scale = np.abs(ref).max()
+    assert np.abs(got[rows] - ref).max() < 2e-5 * scale * np.sqrt(d)
+    assert np.isfinite(got).all()
