@@ -14,7 +14,7 @@ jd = JointData(n_views=2, n_samples=n, latent_dimensions=k, n_features=[d, d], r
                latent_scales=list(np.linspace(2.0, 0.5, k)))
 views = jd.sample_device(device="cuda:0", dtype=torch.float32, n_samples=n, seed=1)
 torch.cuda.synchronize()
-for it in range(4):
+for it in range(int(os.environ.get('PHASE_ITERS', '4'))):
     t0 = time.perf_counter()
     mom, keep, nt, dims, kind = compute_moments(views, h)
     h.sync()
@@ -23,6 +23,7 @@ for it in range(4):
     t2 = time.perf_counter()
     print(f"it {it}: moments {1e3*(t1-t0):.1f} ms (gram kernel {h.moments_last_ms()[0]:.1f}, colsum {h.moments_last_ms()[1]:.1f}), solve {1e3*(t2-t1):.1f} ms, top corr {vals[:3]}", flush=True)
 
+if os.environ.get('PHASE_ONLY'): sys.exit(0)
 from cca_zoo_amd.linear import CCA
 import cProfile, pstats
 m = CCA(latent_dimensions=k)
