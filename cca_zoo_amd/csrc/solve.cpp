@@ -12,6 +12,8 @@
 // oracle/gram_form.py.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -267,10 +269,16 @@ void topk_symmetric(ccz_ctx* c, const SymOp& op, int k, std::vector<double>& the
     const double x = (st.theta[k - 1] - c0) / e;
     int degree = 30;
     if (x > 1.0 + 1e-12) {
-      const double need = std::max(worst / (tol * scale), 2.0) * 10.0;
+      // x1000 margin: the cosh estimate is optimistic by ~10x in practice, and landing a hair above the tolerance
+      // costs a whole extra filter + orthonormalise + Rayleigh-Ritz cycle (one more degree costs two GEMMs)
+      const double need = std::max(worst / (tol * scale), 2.0) * 1e3;
       degree = int(std::ceil(std::acosh(need) / std::acosh(x)));
     }
     degree = std::min(40, std::max(2, degree) + boost);
+    static const bool trace = getenv("CCZ_TRACE_SOLVER") != nullptr;
+    if (trace)
+      fprintf(stderr, "[ccz] topk p=%lld k=%d b=%lld cycle %d: worst/scale %.3e  x %.6f  degree %d\n", (long long)p, k,
+              (long long)b, cycle, worst / scale, x, degree);
     chebyshev_filter(c, op, b, degree, a, cut, aL, X, Y, Z);
     orthonormalize(c, p, b, X, b);
     rayleigh_ritz(c, op, b, X, Y, Z, st);

@@ -10,9 +10,9 @@ from cca_zoo_amd.linear import CCA
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 d, k = 4096, 64
 h = _backend.default_handle(0)
-jd = JointData(n_views=2, n_samples=n, latent_dimensions=k, n_features=[d, d], random_state=0,
+jd = JointData(n_views=2, n_samples=n, latent_dimensions=k, n_features=[d, d], signal_to_noise=1.0, random_state=0,
                latent_scales=list(np.linspace(2.0, 0.5, k)))
-views = jd.sample_device(device="cuda:0", dtype=torch.float32, n_samples=n, seed=1)
+views = jd.sample_device(device="cuda:0", dtype=torch.float32, n_samples=n, seed=1000)
 torch.cuda.synchronize()
 orig_cm, orig_solve = _moments.compute_moments, h.rcca_solve
 marks = {}
