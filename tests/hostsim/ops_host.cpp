@@ -231,4 +231,80 @@ int ccz_create(ccz_handle* out, int device) {
 }
 int ccz_destroy(ccz_handle h) { delete h; return CCZ_OK; }
 const char* ccz_last_error(ccz_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+// ---- test doubles of the HIP-side entry points (api.hip / gram.hip): "device" memory is host memory, K1 is a
+// plain double loop.  They exist so that the package's HOST LOGIC (estimators, grid search, partial / group CCA)
+// can run end to end in the CPU test suite; the package itself never loads this library.
+int ccz_set_stream(ccz_handle, void*) { return CCZ_OK; }
+int ccz_sync(ccz_handle) { return CCZ_OK; }
+int ccz_dev_alloc(ccz_handle h, void** out, size_t bytes) {
+  if (!h || !out) return CCZ_EINVAL;
+  *out = std::malloc(bytes ? bytes : 8);
+  return *out ? CCZ_OK : CCZ_ENOMEM;
+}
+int ccz_dev_free(ccz_handle, void* p) { std::free(p); return CCZ_OK; }
+int ccz_memcpy_h2d(ccz_handle, void* dst, const void* src, size_t bytes) { std::memcpy(dst, src, bytes); return CCZ_OK; }
+int ccz_memcpy_d2h(ccz_handle, void* dst, const void* src, size_t bytes) { std::memcpy(dst, src, bytes); return CCZ_OK; }
+int ccz_memset0(ccz_handle, void* dst, size_t bytes) { std::memset(dst, 0, bytes); return CCZ_OK; }
+int ccz_moments_last_ms(ccz_handle, double* g, double* s) { if (g) *g = 0.0; if (s) *s = 0.0; return CCZ_OK; }
+
+int ccz_moments(ccz_handle h, int dtype, const ccz_view* views, int n_views, int64_t n_rows, int /*on_device*/,
+                double* mom, int accumulate) {
+  if (!h || !views || !mom || n_views < 1 || n_rows < 0) return CCZ_EINVAL;
+  if (dtype != CCZ_F32 && dtype != CCZ_F64) { h->err = "dtype must be CCZ_F32 or CCZ_F64"; return CCZ_EUNSUP; }
+  int64_t D = 0;
+  for (int v = 0; v < n_views; ++v) D += views[v].cols;
+  if (!accumulate) std::fill(mom, mom + D * D + D, 0.0);
+  std::vector<double> row(static_cast<size_t>(D));
+  for (int64_t r = 0; r < n_rows; ++r) {
+    int64_t o = 0;
+    for (int v = 0; v < n_views; ++v) {
+      for (int64_t j = 0; j < views[v].cols; ++j)
+        row[o + j] = dtype == CCZ_F32 ? double(static_cast<const float*>(views[v].data)[r * views[v].ld + j])
+                                      : static_cast<const double*>(views[v].data)[r * views[v].ld + j];
+      o += views[v].cols;
+    }
+    for (int64_t i = 0; i < D; ++i) {
+      const double a = row[i];
+      double* g = mom + i * D;
+      for (int64_t j = i; j < D; ++j) g[j] += a * row[j];      // upper triangle only, as the device kernel
+      mom[D * D + i] += a;
+    }
+  }
+  return CCZ_OK;
+}
+int ccz_moments_symmetrize(ccz_handle, double* mom, int64_t D) {
+  for (int64_t i = 0; i < D; ++i)
+    for (int64_t j = 0; j < i; ++j) mom[i * D + j] = mom[j * D + i];
+  return CCZ_OK;
+}
+int ccz_moments_pack(ccz_handle, const double* mom, int64_t D, double* packed) {
+  int64_t o = 0;
+  for (int64_t i = 0; i < D; ++i)
+    for (int64_t j = i; j < D; ++j) packed[o++] = mom[i * D + j];
+  std::memcpy(packed + o, mom + D * D, size_t(D) * 8);
+  return CCZ_OK;
+}
+int ccz_moments_unpack(ccz_handle, const double* packed, int64_t D, double* mom) {
+  int64_t o = 0;
+  for (int64_t i = 0; i < D; ++i)
+    for (int64_t j = i; j < D; ++j) mom[i * D + j] = packed[o++];
+  std::memcpy(mom + D * D, packed + o, size_t(D) * 8);
+  return CCZ_OK;
+}
+int ccz_transform(ccz_handle h, int dtype, const void* X, int64_t n, int64_t d, int64_t ld, const double* mean,
+                  const double* W, int64_t k, void* out, int64_t ldo) {
+  if (!h || !X || !W || !out) return CCZ_EINVAL;
+  for (int64_t r = 0; r < n; ++r)
+    for (int64_t j = 0; j < k; ++j) {
+      double acc = 0.0;
+      for (int64_t i = 0; i < d; ++i) {
+        const double x = dtype == CCZ_F32 ? double(static_cast<const float*>(X)[r * ld + i]) : static_cast<const double*>(X)[r * ld + i];
+        acc += (x - (mean ? mean[i] : 0.0)) * W[i * k + j];
+      }
+      if (dtype == CCZ_F32) static_cast<float*>(out)[r * ldo + j] = float(acc);
+      else static_cast<double*>(out)[r * ldo + j] = acc;
+    }
+  return CCZ_OK;
+}
 }
