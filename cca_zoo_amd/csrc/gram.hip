@@ -270,43 +270,15 @@ constexpr int FR = 4;        // ring slots per wave
 constexpr int FSLAB = FB * 128 * 4;       // bytes of one slab (A or B) in a slot
 constexpr int FSLOT = 2 * FSLAB;          // bytes per slot: A slab + B slab
 
-__global__ __launch_bounds__(256, 1) void k_gram_f32_fifo(const GramTile* __restrict__ tiles, int ntiles, int per_xcd,
-                                                          int64_t ksplit, int64_t n, int64_t rows_per_wg,
-                                                          double* __restrict__ G, int64_t ldg) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const WorkItem wi = locate_work(blockIdx.x, ntiles, per_xcd, ksplit);
-  if (!wi.valid) return;
-  const GramTile t = tiles[wi.tile];
-  const int64_t k_begin = wi.chunk * rows_per_wg;
-  const int64_t k_end = min(n, k_begin + rows_per_wg);
-  if (k_begin >= k_end) return;
-  const int64_t nrows = k_end - k_begin;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
+// One wave's whole pipeline for a 128 x 128 quadrant: rows [0, nrows) of the two 128-column slabs behind srcA / srcB
+// -> acc.  SYM (quadrant on the diagonal of G: A slab == B slab) skips the MFMA tiles with ti > tj: with the strided
+// tile ownership tile (tj, ti) is the transpose of tile (ti, tj), so 10 of the 16 tiles carry all the information.
+template <bool SYM>
+__device__ __forceinline__ void gram_fifo_quadrant(v16f32 (&acc)[4][4], char* ring, const char* rd,
+                                                   __amdgpu_buffer_rsrc_t srcA, __amdgpu_buffer_rsrc_t srcB, int voffA,
+                                                   int voffB, int stepA, int stepB, int64_t nrows) {
   typedef __attribute__((address_space(3))) void* lds_ptr;
-  char* ring = smem + wave * (FR * FSLOT);       // wave-uniform base of this wave's ring
-  const char* rd = ring + lane * 16;             // per-lane read base: every read is rd + immediate
-
-  const __amdgpu_buffer_rsrc_t srcA =
-      panel_rsrc(static_cast<const float*>(t.a) + k_begin * t.lda + wr * 128, ((nrows - 1) * t.lda + 128) * 4);
-  const __amdgpu_buffer_rsrc_t srcB =
-      panel_rsrc(static_cast<const float*>(t.b) + k_begin * t.ldb + wc * 128, ((nrows - 1) * t.ldb + 128) * 4);
-  const int voffA = int(((lane >> 5) * t.lda + 4 * (lane & 31)) * 4);
-  const int voffB = int(((lane >> 5) * t.ldb + 4 * (lane & 31)) * 4);
-  const int stepA = __builtin_amdgcn_readfirstlane(int(2 * t.lda * 4));   // bytes per k-step (2 rows)
-  const int stepB = __builtin_amdgcn_readfirstlane(int(2 * t.ldb * 4));
   int soffA = 0, soffB = 0;          // byte offset of the next k-step to DMA (rows past the extent arrive as 0)
-
-  v16f32 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
   // prologue: blocks 0, 1, 2 -> slots 0, 1, 2 (12 k-steps = 24 DMA instructions)
 #pragma unroll
   for (int s = 0; s < 3; ++s)
@@ -351,35 +323,109 @@ __global__ __launch_bounds__(256, 1) void k_gram_f32_fifo(const GramTile* __rest
         soffA += stepA;
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int tj = 0; tj < 4; ++tj) acc[1][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[1], b4[tj], acc[1][tj], 0, 0, 0);
+        for (int tj = SYM ? 1 : 0; tj < 4; ++tj) acc[1][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[1], b4[tj], acc[1][tj], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         // -- gap 2: DMA of the B slab rows
         __builtin_amdgcn_raw_ptr_buffer_load_lds(srcB, (lds_ptr)(ring + wsl * FSLOT + FSLAB + u * 1024), 16, voffB, soffB, 0, 0);
         soffB += stepB;
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int tj = 0; tj < 4; ++tj) acc[2][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[2], b4[tj], acc[2][tj], 0, 0, 0);
+        for (int tj = SYM ? 2 : 0; tj < 4; ++tj) acc[2][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[2], b4[tj], acc[2][tj], 0, 0, 0);
 #pragma unroll
-        for (int tj = 0; tj < 4; ++tj) acc[3][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[3], b4[tj], acc[3][tj], 0, 0, 0);
+        for (int tj = SYM ? 3 : 0; tj < 4; ++tj) acc[3][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[3], b4[tj], acc[3][tj], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 
+__global__ __launch_bounds__(256, 1) void k_gram_f32_fifo(const GramTile* __restrict__ tiles, int ntiles, int per_xcd,
+                                                          int64_t ksplit, int64_t n, int64_t rows_per_wg,
+                                                          double* __restrict__ G, int64_t ldg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const WorkItem wi = locate_work(blockIdx.x, ntiles, per_xcd, ksplit);
+  if (!wi.valid) return;
+  const GramTile t = tiles[wi.tile];
+  const int64_t k_begin = wi.chunk * rows_per_wg;
+  const int64_t k_end = min(n, k_begin + rows_per_wg);
+  if (k_begin >= k_end) return;
+  const int64_t nrows_wg = k_end - k_begin;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int wr = wave >> 1, wc = wave & 1;
+  // Diagonal tiles (panel a == panel b) hold three distinct 128 x 128 quadrants: Q00 and Q11 are symmetric
+  // (SYM path: 10 of 16 MFMA tiles) and Q10 = Q01'.  The wave that would compute Q10 instead takes the second
+  // half of Q01's rows, so the tile finishes in 62.5% of the time of an off-diagonal tile.  (No barriers in this
+  // kernel: the four waves are independent pipelines.)
+  const bool diag = t.diag != 0;
+  const bool sym = diag && wr == wc;
+  int64_t row0 = 0, nrows = nrows_wg;
+  if (diag && wr != wc) {
+    const int64_t half = ((nrows_wg + 1) / 2 + FB - 1) / FB * FB;
+    if (wr == 0) nrows = min(half, nrows_wg);          // wave (0,1): rows [0, half)
+    else { row0 = min(half, nrows_wg); nrows = nrows_wg - row0; wr = 0; wc = 1; }   // wave (1,0): the rest of Q01
+    if (nrows <= 0) return;
+  }
+  char* ring = smem + wave * (FR * FSLOT);       // wave-uniform base of this wave's ring
+  const char* rd = ring + lane * 16;             // per-lane read base: every read is rd + immediate
+
+  const __amdgpu_buffer_rsrc_t srcA =
+      panel_rsrc(static_cast<const float*>(t.a) + (k_begin + row0) * t.lda + wr * 128, ((nrows - 1) * t.lda + 128) * 4);
+  const __amdgpu_buffer_rsrc_t srcB =
+      panel_rsrc(static_cast<const float*>(t.b) + (k_begin + row0) * t.ldb + wc * 128, ((nrows - 1) * t.ldb + 128) * 4);
+  const int voffA = int(((lane >> 5) * t.lda + 4 * (lane & 31)) * 4);
+  const int voffB = int(((lane >> 5) * t.ldb + 4 * (lane & 31)) * 4);
+  const int stepA = __builtin_amdgcn_readfirstlane(int(2 * t.lda * 4));   // bytes per k-step (2 rows)
+  const int stepB = __builtin_amdgcn_readfirstlane(int(2 * t.ldb * 4));
+
+  v16f32 acc[4][4];
 #pragma unroll
-  for (int ti = 0; ti < 4; ++ti)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int trow = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      const int i = wr * 128 + 4 * trow + ti;
-      double* grow = G + (t.out_row + i) * ldg + t.out_col;
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int tj = 0; tj < 4; ++tj) {
-        const int j = wc * 128 + 4 * (lane & 31) + tj;
-        unsafeAtomicAdd(grow + j, double(acc[ti][tj][r]));
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (sym) gram_fifo_quadrant<true>(acc, ring, rd, srcA, srcB, voffA, voffB, stepA, stepB, nrows);
+  else gram_fifo_quadrant<false>(acc, ring, rd, srcA, srcB, voffA, voffB, stepA, stepB, nrows);
+
+  // epilogue: fp32 chunk sums -> fp64 G (atomics: other row chunks / the other half of Q01 add into the same tile).
+  // Tile (ti, tj) owns rows 4 trow + ti and columns 4 (lane & 31) + tj of the quadrant.
+  if (!sym) {
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int trow = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int i = wr * 128 + 4 * trow + ti;
+        double* grow = G + (t.out_row + i) * ldg + t.out_col;
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) {
+          const int j = wc * 128 + 4 * (lane & 31) + tj;
+          unsafeAtomicAdd(grow + j, double(acc[ti][tj][r]));
+        }
       }
-    }
+  } else {
+    // symmetric quadrant: an element below the diagonal (i > j) of a computed tile ti < tj is the mirror of an
+    // element of the skipped tile (tj, ti): it is added at (j, i).  Tiles ti == tj keep their upper half only.
+    double* Q = G + (t.out_row + wr * 128) * ldg + t.out_col + wc * 128;
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int trow = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int i = 4 * trow + ti;
+#pragma unroll
+        for (int tj = ti; tj < 4; ++tj) {
+          const int j = 4 * (lane & 31) + tj;
+          const double v = double(acc[ti][tj][r]);
+          if (i <= j) unsafeAtomicAdd(Q + int64_t(i) * ldg + j, v);
+          else if (tj != ti) unsafeAtomicAdd(Q + int64_t(j) * ldg + i, v);
+        }
+      }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -595,6 +641,25 @@ void launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
       t.pad_ = 0;
       tiles.push_back(t);
     }
+  }
+  // Per-XCD slices (locate_work): slice x = entries [x * per, (x+1) * per) of the table.  Diagonal tiles cost ~65%
+  // of an off-diagonal one (k_gram_f32_fifo skips their redundant quadrant work), so they are dealt round-robin
+  // to the slices and the off-diagonal tiles fill each slice up to `per` in supertile order (the last slice takes
+  // what is left).  The table stays dense: the plain order of small grids uses the same list.
+  {
+    std::vector<GramTile> dg, off, balanced;
+    for (const GramTile& tl : tiles) (tl.diag ? dg : off).push_back(tl);
+    const size_t per = (tiles.size() + 7) / 8;
+    size_t id = 0, io = 0;
+    for (int x = 0; x < 8; ++x) {
+      size_t cnt = 0;
+      const size_t want_d = dg.size() / 8 + (size_t(x) < dg.size() % 8 ? 1 : 0);
+      for (size_t q = 0; q < want_d && id < dg.size() && cnt < per; ++q, ++cnt) balanced.push_back(dg[id++]);
+      for (; cnt < per && io < off.size(); ++cnt) balanced.push_back(off[io++]);
+      for (; cnt < per && id < dg.size(); ++cnt) balanced.push_back(dg[id++]);
+    }
+    if (balanced.size() != tiles.size()) fail(CCZ_EHIP, "gram: tile slicing lost tiles (internal error)");
+    tiles.swap(balanced);
   }
   const int ntiles = int(tiles.size());
   // the tile table depends only on the views (pointers, widths, strides): pipelined callers keep it on
