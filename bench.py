@@ -30,7 +30,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", dest="n", type=int, default=1_000_000)
     ap.add_argument("--d", type=int, default=4096)
     ap.add_argument("--k", type=int, default=64)
@@ -245,10 +245,10 @@ def main():
         achieved = flop / (g_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[a.dtype]
         # HBM/fabric bytes per launch from the committed PMC pass (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
-        # profiles/r01_c_gram_pmc.md), measured at n=262144 on the same kernel/shape and linear in the rows
+        # profiles/r01_e_gram_pmc.md), measured at n=262144 on the same kernel/shape and linear in the rows
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_c_gram_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r01_e_gram_traffic.json")) as f:
                 tj = json.load(f)
             if a.dtype == "f32" and tj.get("D") == D:
                 traffic = tj["bytes_per_row"] * n_local
@@ -266,7 +266,7 @@ def main():
                        "device": info["name"], "arch": info["arch"], "compute_units": info["compute_units"]},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
-                         "traffic_source": "profiles/r01_c_gram_pmc.md (PMC pass at n=262144, scaled by rows)" if traffic else None,
+                         "traffic_source": "profiles/r01_e_gram_pmc.md (PMC pass at n=262144, scaled by rows)" if traffic else None,
                          "kernel": "k_gram_f32_fifo" if a.dtype == "f32" else "k_gram_f64",
                          "kernel_ms": g_ms, "flop_per_launch": flop,
                          "bytes_per_launch": float(n_local) * D * (4 if a.dtype == "f32" else 8),
