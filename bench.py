@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dcca", action="store_true")
+    ap.add_argument("--with-sharded-dcca", action="store_true",
+                    help="N > 1 only: also time CCALoss fwd+bwd on the batch sharded over the ranks (extra collectives "
+                         "after the timed fits; off by default so that nothing can delay the headline result)")
     ap.add_argument("--cpu-sample-rows", type=int, default=2048)
     return ap.parse_args()
 
@@ -232,7 +235,7 @@ def main():
     ms_per_step = elapsed / a.steps * 1e3
 
     sharded_loss_s = None
-    if distributed and not a.no_dcca and 8.0 * n_local * a.d * 4 < 150e9:
+    if distributed and (a.with_sharded_dcca or os.environ.get("CCZ_BENCH_FORCE_SHARDED")) and 8.0 * n_local * a.d * 4 < 150e9:
         del views
         torch.cuda.empty_cache()
         views = None
