@@ -55,14 +55,11 @@ def validate_views(views, min_views: int = 2, check_finite: bool = True) -> list
 
 
 def perview_parameter(name: str, value, default, n_views: int) -> list:
-    """Broadcast a scalar / per-view list / ``None`` to a list of length ``n_views``."""
-    if value is None:
-        return [default] * n_views
-    if isinstance(value, list):
-        if len(value) != n_views:
-            raise ValueError(
-                f"Parameter '{name}' must be a scalar or a list of length "
-                f"{n_views}, got length {len(value)}."
-            )
+    """One value per view: a list is taken as is (its length must be ``n_views``), a scalar is repeated and
+    ``None`` stands for ``default`` (semantics and message of cca_zoo/_utils/_validation.py:45-75)."""
+    if not isinstance(value, list):
+        fill = default if value is None else value
+        return [fill for _ in range(n_views)]
+    if len(value) == n_views:
         return value
-    return [value] * n_views
+    raise ValueError(f"Parameter '{name}' must be a scalar or a list of length {n_views}, got length {len(value)}.")
