@@ -192,6 +192,9 @@ class GridSearchCV:
                 fit_t[ci, f], score_t[ci, f] = t1 - t0, t2 - t1
                 if self.verbose:
                     print(f"[fold {f + 1}/{n_folds}] {params} score={scores[ci, f]:.6f} fit={t1 - t0:.3f}s")
+        if np.all(np.isnan(scores)):
+            raise ValueError(f"All the {scores.size} fits failed. It is very likely that your model is misconfigured "
+                             "(see the warnings above for the individual failures).")
         self._finish(candidates, scores, fit_t, score_t)
         if self.refit:
             t0 = time.perf_counter()

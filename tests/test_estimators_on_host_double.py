@@ -138,3 +138,35 @@ def test_nan_input_is_reported_from_the_column_sums(host_double):
     x[7, 1] = np.inf
     with pytest.raises(ValueError, match="NaN or infinity"):
         rCCA().fit([x, y])
+
+
+def test_grid_search_and_partial_edge_cases_on_host_double(host_double):
+    from sklearn.model_selection import KFold
+
+    from cca_zoo_amd.linear import CCA, GRCCA, MCCA, PartialCCA, rCCA
+    from cca_zoo_amd.model_selection import GridSearchCV
+
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((60, 5))
+    Y = X @ rng.standard_normal((5, 4)) + 0.5 * rng.standard_normal((60, 4))
+    z = rng.standard_normal(60)                                    # 1-D confound
+    m = PartialCCA(latent_dimensions=2).fit([X, Y], partials=z)
+    assert [b.shape for b in m.confound_betas_] == [(1, 5), (1, 4)]
+    assert m.transform([X, Y], partials=z)[0].shape == (60, 2)
+    m32 = PartialCCA().fit([X.astype(np.float32), Y.astype(np.float32)], partials=z)
+    assert m32.weights_[0].dtype == np.float64                     # MCCA family promotes (np.cov)
+    labels = [np.array(list("aabbc")), np.array([1, 1, 2, 2])]     # any hashable group labels
+    assert GRCCA(latent_dimensions=1, c=0.5, mu=0.1).fit([X, Y], feature_groups=labels).weights_[1].shape == (4, 1)
+
+    gs = GridSearchCV(rCCA(), {"c": [0.1, 0.5]}, cv=3, refit=False).fit([X, Y])
+    assert not hasattr(gs, "best_estimator_") and gs.best_params_["c"] in (0.1, 0.5)
+    with pytest.raises(AttributeError):
+        gs.score([X, Y])
+    gs = GridSearchCV(rCCA(), [{"c": [0.1]}, {"latent_dimensions": [1, 2]}], cv=2).fit([X, Y])
+    assert len(gs.cv_results_["params"]) == 3 and gs.cv_results_["param_c"].mask.tolist() == [False, True, True]
+    gs = GridSearchCV(MCCA(), {"c": [0.2]}, cv=KFold(4)).fit([X, Y])
+    assert gs.route_ == "shared-moments" and gs.n_splits_ == 4
+    gs = GridSearchCV(CCA(), {"latent_dimensions": [1, 9]}, cv=2).fit([X, Y])          # k clamps to the view width
+    assert gs.best_estimator_.weights_[0].shape[1] <= 5
+    with pytest.warns(RuntimeWarning, match="fit failed"), pytest.raises(ValueError, match="All the 2 fits failed"):
+        GridSearchCV(rCCA(), {"c": [2.0]}, cv=2).fit([X, Y])
