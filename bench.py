@@ -279,14 +279,15 @@ def main():
             out["extra"] = {"dcca_loss_metric_shape_sharded": {
                 "metric": f"DCCA CCALoss fwd+bwd/sec (batch {a.n} sharded over {world} GPUs, 2x{a.d}, fp32)",
                 "value": 1.0 / sharded_loss_s, "ms": sharded_loss_s * 1e3}}
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.n, a.d, a.k, a.cpu_sample_rows)
         if world == 1 and not a.no_dcca and views is not None:
             out["extra"] = {"dcca_loss": dcca_extra(), "grid_search": grid_extra(views, a.k, ms_per_step)}
             if a.n * a.d * 4 * 4 < 200e9:   # z1, z2 and their gradients must fit in HBM next to the views
                 del views
                 torch.cuda.empty_cache()
                 out["extra"]["dcca_loss_metric_shape"] = dcca_extra(steps=2, warmup=1, batch=a.n, d=a.d, label="metric shape")
+        # last: its 64 OpenBLAS threads keep spinning for a while and would slow the launch chains of the GPU extras
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.n, a.d, a.k, a.cpu_sample_rows)
         line = json.dumps(out)
     else:
         line = None
