@@ -566,6 +566,136 @@ __global__ __launch_bounds__(256, 1) void k_gram_f64(const GramTile* __restrict_
 }
 
 // ---------------------------------------------------------------------------
+// fp64 Gram on the same wave-private LDS-DMA FIFO as k_gram_f32_fifo: 128 x 128 tile per workgroup, each wave a
+// 64 x 64 quadrant = 4 x 4 v_mfma_f64_16x16x4_f64 tiles.  A k-step is 4 rows; lane l takes row k0 + (l >> 4),
+// columns 4 (l & 15) .. + 3 of its 64-column slab as two 16-byte DMAs (the four doubles feed the four column
+// tiles: strided ownership as in fp32).  A FIFO block is 8 rows = 2 k-steps = 8 DMA instructions, the slot
+// layout is [A: k-step][half][lane] | [B: ...], ring of 4 slots (32 KiB per wave), counted vmcnt.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void k_gram_f64_fifo(const GramTile* __restrict__ tiles, int ntiles, int per_xcd,
+                                                          int64_t ksplit, int64_t n, int64_t rows_per_wg,
+                                                          double* __restrict__ G, int64_t ldg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const WorkItem wi = locate_work(blockIdx.x, ntiles, per_xcd, ksplit);
+  if (!wi.valid) return;
+  const GramTile t = tiles[wi.tile];
+  const int64_t k_begin = wi.chunk * rows_per_wg;
+  const int64_t k_end = min(n, k_begin + rows_per_wg);
+  if (k_begin >= k_end) return;
+  const int64_t nrows = k_end - k_begin;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  char* ring = smem + wave * (FR * FSLOT);
+  const char* rd = ring + lane * 16;
+
+  const __amdgpu_buffer_rsrc_t srcA =
+      panel_rsrc(static_cast<const double*>(t.a) + k_begin * t.lda + wr * 64, ((nrows - 1) * t.lda + 64) * 8);
+  const __amdgpu_buffer_rsrc_t srcB =
+      panel_rsrc(static_cast<const double*>(t.b) + k_begin * t.ldb + wc * 64, ((nrows - 1) * t.ldb + 64) * 8);
+  const int voffA = int(((lane >> 4) * t.lda + 4 * (lane & 15)) * 8);
+  const int voffB = int(((lane >> 4) * t.ldb + 4 * (lane & 15)) * 8);
+  const int voffA2 = voffA + 16, voffB2 = voffB + 16;   // second pair of doubles (no instruction offset: it would also move the LDS address)
+  const int stepA = __builtin_amdgcn_readfirstlane(int(4 * t.lda * 8));   // bytes per k-step (4 rows)
+  const int stepB = __builtin_amdgcn_readfirstlane(int(4 * t.ldb * 8));
+  int soffA = 0, soffB = 0;
+
+  v4f64 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
+
+  // slot: A part [k-step u (2)][half (2)][lane (64)][16 B] = 4 KiB, B part the same at + FSLAB
+  // prologue: blocks 0, 1, 2 -> slots 0, 1, 2 (6 k-steps = 24 DMA instructions)
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srcA, (lds_ptr)(ring + s * FSLOT + u * 2048), 16, voffA, soffA, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srcA, (lds_ptr)(ring + s * FSLOT + u * 2048 + 1024), 16, voffA2, soffA, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srcB, (lds_ptr)(ring + s * FSLOT + FSLAB + u * 2048), 16, voffB, soffB, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srcB, (lds_ptr)(ring + s * FSLOT + FSLAB + u * 2048 + 1024), 16, voffB2, soffB, 0, 0);
+      soffA += stepA;
+      soffB += stepB;
+    }
+  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                  // block 0 landed
+  v2f64 af[2][2], bf[2][2];
+  af[0][0] = *reinterpret_cast<const v2f64*>(rd);
+  af[0][1] = *reinterpret_cast<const v2f64*>(rd + 1024);
+  bf[0][0] = *reinterpret_cast<const v2f64*>(rd + FSLAB);
+  bf[0][1] = *reinterpret_cast<const v2f64*>(rd + FSLAB + 1024);
+
+  const int64_t nblk = (nrows + FB - 1) / FB;
+  for (int64_t b0 = 0; b0 < nblk; b0 += FR) {
+#pragma unroll
+    for (int bb = 0; bb < FR; ++bb) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int cur = (bb * 2 + u) & 1, nxt = cur ^ 1;
+        const int nslot = (u == 0) ? bb : (bb + 1) % FR;
+        const int nu = (u == 0) ? 1 : 0;
+        const int wsl = (bb + 3) % FR;               // slot being refilled: block b0 + bb + 3
+        const double a4[4] = {af[cur][0][0], af[cur][0][1], af[cur][1][0], af[cur][1][1]};
+        const double b4[4] = {bf[cur][0][0], bf[cur][0][1], bf[cur][1][0], bf[cur][1][1]};
+        // -- gap 0: fragment reads for the next k-step
+        if (u == 1) {
+          // the next k-step opens block b+1: newer than it are block b+2 (8) and the first k-step of b+3 (4)
+          asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        }
+        af[nxt][0] = *reinterpret_cast<const v2f64*>(rd + nslot * FSLOT + nu * 2048);
+        af[nxt][1] = *reinterpret_cast<const v2f64*>(rd + nslot * FSLOT + nu * 2048 + 1024);
+        bf[nxt][0] = *reinterpret_cast<const v2f64*>(rd + nslot * FSLOT + FSLAB + nu * 2048);
+        bf[nxt][1] = *reinterpret_cast<const v2f64*>(rd + nslot * FSLOT + FSLAB + nu * 2048 + 1024);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) acc[0][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[0], b4[tj], acc[0][tj], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srcA, (lds_ptr)(ring + wsl * FSLOT + u * 2048), 16, voffA, soffA, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) acc[1][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[1], b4[tj], acc[1][tj], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srcA, (lds_ptr)(ring + wsl * FSLOT + u * 2048 + 1024), 16, voffA2, soffA, 0, 0);
+        soffA += stepA;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) acc[2][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[2], b4[tj], acc[2][tj], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srcB, (lds_ptr)(ring + wsl * FSLOT + FSLAB + u * 2048), 16, voffB, soffB, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) acc[3][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[3], b4[tj], acc[3][tj], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srcB, (lds_ptr)(ring + wsl * FSLOT + FSLAB + u * 2048 + 1024), 16, voffB2, soffB, 0, 0);
+        soffB += stepB;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // f64 16x16 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int trow = (lane >> 4) + 4 * r;
+      const int i = wr * 64 + 4 * trow + ti;
+      double* grow = G + (t.out_row + i) * ldg + t.out_col;
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj) {
+        const int j = wc * 64 + 4 * (lane & 15) + tj;
+        unsafeAtomicAdd(grow + j, acc[ti][tj][r]);
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // column sums: HBM-bound single pass, fp64 accumulation
 // ---------------------------------------------------------------------------
 template <typename T>
@@ -727,7 +857,12 @@ void launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
       hipLaunchKernelGGL(k_gram_f32<false>, dim3((unsigned)nblocks), dim3(256), lds_bytes, st, d_tiles, ntiles, per_xcd, ksplit, n, rows_per_wg, G, D);
     }
   } else {
-    if (fast) {
+    static const int impl64 = [] { const char* e = getenv("CCZ_GRAM64_IMPL"); return e ? atoi(e) : 1; }();   // 1: FIFO, 0: staged
+    if (fast && impl64 != 0) {
+      const size_t fifo_bytes = size_t(4) * FR * FSLOT;
+      CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_f64_fifo), hipFuncAttributeMaxDynamicSharedMemorySize, int(fifo_bytes)));
+      hipLaunchKernelGGL(k_gram_f64_fifo, dim3((unsigned)nblocks), dim3(256), fifo_bytes, st, d_tiles, ntiles, per_xcd, ksplit, n, rows_per_wg, G, D);
+    } else if (fast) {
       CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_f64<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
       hipLaunchKernelGGL(k_gram_f64<true>, dim3((unsigned)nblocks), dim3(256), lds_bytes, st, d_tiles, ntiles, per_xcd, ksplit, n, rows_per_wg, G, D);
     } else {
