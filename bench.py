@@ -270,7 +270,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
                          "traffic_source": "profiles/r01_e_gram_pmc.md (PMC pass at n=262144, scaled by rows)" if traffic else None,
-                         "kernel": "k_gram_f32_fifo" if a.dtype == "f32" else "k_gram_f64",
+                         "kernel": "k_gram_f32_fifo" if a.dtype == "f32" else "k_gram_f64_fifo",
                          "kernel_ms": g_ms, "flop_per_launch": flop,
                          "bytes_per_launch": float(n_local) * D * (4 if a.dtype == "f32" else 8),
                          "gram_share_of_step": g_ms / ms_per_step},
