@@ -40,7 +40,8 @@ def compute_moments(views, handle=None):
     if on_device or sharded:
         import torch
 
-        dev = views[0].device if on_device else torch.device("cuda", h.device)
+        # (a test double of the library keeps "device" memory on the host and says so: gloo tests on CPU)
+        dev = views[0].device if on_device else (getattr(h, "torch_device", None) or torch.device("cuda", h.device))
         mom_t = torch.empty(D * D + D, dtype=torch.float64, device=dev)
         mom_ptr = mom_t.data_ptr()
         keep.append(mom_t)
@@ -76,7 +77,8 @@ def compute_moments(views, handle=None):
         h.moments_pack(mom_ptr, D, packed.data_ptr())
         h.sync()
         n_total = _dist.allreduce_moments(packed, n, _dist.active_group())
-        torch.cuda.current_stream(mom_t.device).synchronize()
+        if mom_t.is_cuda:
+            torch.cuda.current_stream(mom_t.device).synchronize()
         h.moments_unpack(packed.data_ptr(), D, mom_ptr)
         keep.append(packed)
     # non-finite inputs (NaN / inf anywhere in a column) surface in that column's sum: the reference's

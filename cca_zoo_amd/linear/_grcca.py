@@ -77,6 +77,7 @@ class GRCCA(MCCA):
         self.feature_groups_ = feature_groups
         h = _backend.default_handle()
         mom, keep, n, dims, kind = compute_moments(views_, h)
+        self.n_samples_ = int(n)
         D = int(sum(dims))
         maps = [_augment_map(np.asarray(g), ci, mi) for g, ci, mi in zip(feature_groups, c_, mu_)]
         dims_aug = [int(T.shape[1]) for T in maps]

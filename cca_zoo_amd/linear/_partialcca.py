@@ -60,6 +60,7 @@ class PartialCCA(MCCA):
         h = _backend.default_handle()
         # K1 over [Z | X_1 .. X_m]: the confound rows of G are the first dz rows (all inside the upper triangle)
         mom, keep, n, dims_all, kind = compute_moments([Z, *views_], h)
+        self.n_samples_ = int(n)
         dims = dims_all[1:]
         D, Da = int(sum(dims)), int(sum(dims_all))
         top = h.to_host(mom, (dz, Da))                                   # [Z'Z | Z'X]

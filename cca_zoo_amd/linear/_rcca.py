@@ -56,6 +56,7 @@ class rCCA(BaseModel):
         self._check_n_views()
         h = _backend.default_handle()
         mom, keep, n_total, dims, kind = compute_moments(views_, h)
+        self.n_samples_ = int(n_total)            # inside row_sharded(): the global row count
         self._fit_moments(h, mom, n_total, dims, kind)
         del keep
         return self

@@ -25,8 +25,12 @@ def build_hostsim():
 def hostsim_handle():
     from cca_zoo_amd import _backend
 
+    import torch
+
     lib = _backend.bind(ctypes.CDLL(build_hostsim()), strict=False)
-    return _backend.Handle(0, lib=lib)
+    h = _backend.Handle(0, lib=lib)
+    h.torch_device = torch.device("cpu")          # the double's "device" memory is host memory
+    return h
 
 
 def pack_moments(G, s):

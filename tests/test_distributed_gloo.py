@@ -98,3 +98,70 @@ def test_two_rank_allreduce_then_solve():
             assert col_rel_err(w, r) < 1e-9
         for m, r in zip(means, means_ref):
             np.testing.assert_allclose(m, r, atol=1e-12)
+
+
+def _estimator_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cca_zoo_amd import _backend, row_sharded, shard_bounds
+        from cca_zoo_amd.linear import GCCA, MCCA, rCCA
+        from hostsim_util import hostsim_handle
+        from oracle import reference_form as rf
+
+        h = hostsim_handle()
+        _backend.default_handle = lambda device=None: h
+        views = rf.joint_data(3, 257, 3, [10, 8, 6], 2.0, 9)       # same data on every rank
+        lo, hi = shard_bounds(257, rank, world)
+        local = [v[lo:hi] for v in views]
+        out = {}
+        with row_sharded():
+            m = rCCA(latent_dimensions=2, c=0.1).fit(local[:2])
+            out["rcca"] = ([w.copy() for w in m.weights_], [x.copy() for x in m.means_], m.n_samples_,
+                           m.score(local[:2]).copy())
+            mm = MCCA(latent_dimensions=2, c=0.2).fit(local)
+            out["mcca"] = [w.copy() for w in mm.weights_]
+            gg = GCCA(latent_dimensions=2, c=0.2).fit(local)
+            out["gcca"] = [w.copy() for w in gg.weights_]
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharded_estimators_match_single_process():
+    """The estimators themselves inside row_sharded() (K1 on the local rows through the host double, packed
+    all-reduce over gloo, replicated solve): every rank reproduces the fit on the full data, and score() inside
+    the context is the global-sample score."""
+    from conftest import col_rel_err
+    from oracle import reference_form as rf
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_estimator_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    views = rf.joint_data(3, 257, 3, [10, 8, 6], 2.0, 9)
+    Wr, mr = rf.rcca_weights(views[:2], 2, c=0.1)
+    Wm, _ = rf.mcca_weights(views, 2, c=0.2)
+    Wg, _ = rf.gcca_weights(views, 2, c=0.2)
+    score_ref = rf.mean_offdiag_corr(views[:2], Wr, mr)
+    for rank, out in results:
+        W, means, n_seen, score = out["rcca"]
+        assert n_seen == 257
+        for w, r in zip(W, Wr):
+            assert col_rel_err(w, r) < 1e-8
+        for a, b in zip(means, mr):
+            np.testing.assert_allclose(a, b, atol=1e-12)
+        np.testing.assert_allclose(score, score_ref, rtol=1e-8, atol=1e-10)
+        for w, r in zip(out["mcca"], Wm):
+            assert col_rel_err(w, r) < 1e-7
+        for w, r in zip(out["gcca"], Wg):
+            assert col_rel_err(w, r) < 1e-7
