@@ -29,7 +29,7 @@ import numpy as np
 from sklearn.base import BaseEstimator, clone
 from sklearn.model_selection import ParameterGrid, check_cv
 
-from cca_zoo_amd import _backend, _dist
+from cca_zoo_amd import _backend
 from cca_zoo_amd._moments import compute_moments
 from cca_zoo_amd._utils._validation import is_device_tensor, validate_views
 
@@ -124,7 +124,7 @@ class GridSearchCV:
 
     # -- public API --------------------------------------------------------------------------
     def fit(self, views, y=None, **fit_params):
-        if self.scoring is None and not fit_params and not _dist.is_sharded() and _gram_reusable(self.estimator):
+        if self.scoring is None and not fit_params and _gram_reusable(self.estimator):
             validated = validate_views(views, check_finite=False)
             n = int(validated[0].shape[0])
             splits = list(check_cv(self.cv).split(np.zeros((n, 1))))
@@ -150,8 +150,10 @@ class GridSearchCV:
 
     # -- one pass over the data ------------------------------------------------------------------
     def _fit_from_shared_moments(self, views, splits):
+        """Inside ``row_sharded()`` the views are this rank's rows: the folds are cut within every shard (global fold f
+        = union of the ranks' folds f), ``compute_moments`` all-reduces each fold's moments, and every rank then runs
+        the same solves on the same global moments (replicated, like a sharded ``fit``)."""
         h = _backend.default_handle()
-        n = int(views[0].shape[0])
         candidates = list(ParameterGrid(self.param_grid))
         n_folds = len(splits)
         t_pass = time.perf_counter()
@@ -161,6 +163,7 @@ class GridSearchCV:
             mom, keep, n_f, dims, kind = compute_moments([_rows(v, test) for v in views], h)
             folds.append((mom, keep, n_f))
         D = int(sum(dims))
+        n = int(sum(n_f for _, _, n_f in folds))                 # global row count (all-reduced under sharding)
         total = h.alloc((D * D + D) * 8)
         h.memset0(total.ptr, (D * D + D) * 8)
         for mom, _, _ in folds:

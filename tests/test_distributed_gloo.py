@@ -165,3 +165,74 @@ def test_two_rank_sharded_estimators_match_single_process():
             assert col_rel_err(w, r) < 1e-7
         for w, r in zip(out["gcca"], Wg):
             assert col_rel_err(w, r) < 1e-7
+
+
+def _grid_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cca_zoo_amd import _backend, row_sharded, shard_bounds
+        from cca_zoo_amd.linear import rCCA
+        from cca_zoo_amd.model_selection import GridSearchCV
+        from hostsim_util import hostsim_handle
+        from oracle import reference_form as rf
+
+        h = hostsim_handle()
+        _backend.default_handle = lambda device=None: h
+        views = rf.joint_data(2, 203, 3, [9, 7], 1.5, 4)
+        lo, hi = shard_bounds(203, rank, world)
+        with row_sharded():
+            gs = GridSearchCV(rCCA(latent_dimensions=2), {"c": [0.01, 0.2, 0.7]}, cv=3).fit([v[lo:hi] for v in views])
+        q.put((rank, gs.route_, np.stack([gs.cv_results_[f"split{f}_test_score"] for f in range(3)], axis=1),
+               gs.best_params_, [w.copy() for w in gs.best_estimator_.weights_], gs.best_estimator_.n_samples_))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharded_grid_search():
+    """GridSearchCV inside row_sharded(): folds are cut within every shard, each fold's moments are all-reduced, every
+    rank runs the same solves.  Equal to a single-process search whose splitter assigns the same global folds."""
+    from sklearn.model_selection import KFold, PredefinedSplit
+
+    from conftest import col_rel_err
+    from hostsim_util import hostsim_handle
+    from oracle import reference_form as rf
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grid_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+
+    from cca_zoo_amd import _backend, shard_bounds
+    from cca_zoo_amd.linear import rCCA
+    from cca_zoo_amd.model_selection import GridSearchCV
+
+    views = rf.joint_data(2, 203, 3, [9, 7], 1.5, 4)
+    fold_of_row = np.empty(203, dtype=int)
+    for r in range(2):
+        lo, hi = shard_bounds(203, r, 2)
+        for f, (_, te) in enumerate(KFold(3).split(np.zeros((hi - lo, 1)))):
+            fold_of_row[lo + te] = f
+    h = hostsim_handle()
+    saved = _backend.default_handle
+    _backend.default_handle = lambda device=None: h
+    try:
+        ref = GridSearchCV(rCCA(latent_dimensions=2), {"c": [0.01, 0.2, 0.7]}, cv=PredefinedSplit(fold_of_row)).fit(views)
+    finally:
+        _backend.default_handle = saved
+    ref_scores = np.stack([ref.cv_results_[f"split{f}_test_score"] for f in range(3)], axis=1)
+    for rank, route, scores, best, W, n_seen in results:
+        assert route == "shared-moments" and n_seen == 203
+        np.testing.assert_allclose(scores, ref_scores, rtol=1e-9, atol=1e-11)
+        assert best == ref.best_params_
+        for w, r in zip(W, ref.best_estimator_.weights_):
+            assert col_rel_err(w, r) < 1e-8
