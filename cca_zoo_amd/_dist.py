@@ -72,3 +72,24 @@ def allreduce_moments(moments, n_local: int, group=None):
     dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     moments.copy_(buf[:-1])
     return int(round(float(buf[-1].item())))
+
+
+def rank_and_world(group=None):
+    """(rank, world size) of the enclosing ``row_sharded`` block; (0, 1) outside one."""
+    import torch.distributed as dist
+
+    if not is_sharded():
+        return 0, 1
+    return dist.get_rank(group), dist.get_world_size(group)
+
+
+def allreduce_small(values, device, group=None):
+    """SUM-reduce a small float64 NumPy array over the ranks (host bookkeeping such as per-setting scores); the
+    tensor lives on ``device`` (CUDA for nccl, CPU for gloo)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    t = torch.as_tensor(np.ascontiguousarray(values, dtype=np.float64), device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t.cpu().numpy()

@@ -29,7 +29,7 @@ import numpy as np
 from sklearn.base import BaseEstimator, clone
 from sklearn.model_selection import ParameterGrid, check_cv
 
-from cca_zoo_amd import _backend
+from cca_zoo_amd import _backend, _dist
 from cca_zoo_amd._moments import compute_moments
 from cca_zoo_amd._utils._validation import is_device_tensor, validate_views
 
@@ -171,17 +171,25 @@ class GridSearchCV:
         h.sync()
         self.moments_pass_time_ = time.perf_counter() - t_pass
 
-        scores = np.full((len(candidates), n_folds), np.nan)
+        # (setting, fold) work items: replicated moments, so inside row_sharded() every rank takes a share of the
+        # solves and the score tables are summed over the ranks afterwards
+        rank, world = _dist.rank_and_world(_dist.active_group())
+        scores = np.zeros((len(candidates), n_folds))
+        failed = np.zeros_like(scores)
         fit_t = np.zeros_like(scores)
         score_t = np.zeros_like(scores)
         train = h.alloc((D * D + D) * 8)
         for f, (mom, _, n_f) in enumerate(folds):
+            mine = [ci for ci in range(len(candidates)) if (f * len(candidates) + ci) % world == rank]
+            if not mine:
+                continue
             h.memset0(train.ptr, (D * D + D) * 8)
             h.moments_axpby(D, 1.0, total.ptr, 1.0, train.ptr)
             h.moments_axpby(D, -1.0, mom, 1.0, train.ptr)                 # moments of the rows outside fold f
             colsum = h.to_host(mom, (D,), offset_bytes=D * D * 8)
             h.moments_symmetrize(mom, D)                                  # scoring GEMMs read full rows of G
-            for ci, params in enumerate(candidates):
+            for ci in mine:
+                params = candidates[ci]
                 est = clone(self.estimator).set_params(**params)
                 t0 = time.perf_counter()
                 try:
@@ -191,10 +199,16 @@ class GridSearchCV:
                     t2 = time.perf_counter()
                 except (ValueError, np.linalg.LinAlgError, RuntimeError) as err:     # sklearn's error_score=nan
                     t1 = t2 = time.perf_counter()
+                    failed[ci, f] = 1.0
                     warnings.warn(f"fit failed for {params} on fold {f}: {err}; score set to nan", RuntimeWarning)
                 fit_t[ci, f], score_t[ci, f] = t1 - t0, t2 - t1
                 if self.verbose:
                     print(f"[fold {f + 1}/{n_folds}] {params} score={scores[ci, f]:.6f} fit={t1 - t0:.3f}s")
+        if world > 1:
+            dev = getattr(h, "torch_device", None) or f"cuda:{h.device}"
+            packed = _dist.allreduce_small(np.stack([scores, failed, fit_t, score_t]), dev, _dist.active_group())
+            scores, failed, fit_t, score_t = packed
+        scores = np.where(failed > 0, np.nan, scores)
         if np.all(np.isnan(scores)):
             raise ValueError(f"All the {scores.size} fits failed. It is very likely that your model is misconfigured "
                              "(see the warnings above for the individual failures).")
