@@ -126,6 +126,14 @@ def _estimator_worker(rank, world, port, q):
             out["mcca"] = [w.copy() for w in mm.weights_]
             gg = GCCA(latent_dimensions=2, c=0.2).fit(local)
             out["gcca"] = [w.copy() for w in gg.weights_]
+            from cca_zoo_amd.linear import GRCCA, PartialCCA
+
+            conf = np.random.default_rng(3).standard_normal((257, 2)) + 0.4        # same confounds on every rank
+            pc = PartialCCA(latent_dimensions=2, c=0.1).fit(local[:2], partials=conf[lo:hi])
+            out["pcca"] = ([w.copy() for w in pc.weights_], [b.copy() for b in pc.confound_betas_])
+            groups = [np.arange(10) // 3, np.arange(8) // 4]
+            gr = GRCCA(latent_dimensions=2, c=[0.5, 0.3], mu=[0.2, 0.0]).fit(local[:2], feature_groups=groups)
+            out["grcca"] = [w.copy() for w in gr.weights_]
         q.put((rank, out))
     finally:
         dist.destroy_process_group()
@@ -153,6 +161,11 @@ def test_two_rank_sharded_estimators_match_single_process():
     Wm, _ = rf.mcca_weights(views, 2, c=0.2)
     Wg, _ = rf.gcca_weights(views, 2, c=0.2)
     score_ref = rf.mean_offdiag_corr(views[:2], Wr, mr)
+    from oracle import partial_group as pg
+
+    conf = np.random.default_rng(3).standard_normal((257, 2)) + 0.4
+    Wp, _, Bp = pg.partialcca_reference_form(views[:2], conf, 2, c=0.1)
+    Wgr, _ = pg.grcca_reference_form(views[:2], [np.arange(10) // 3, np.arange(8) // 4], 2, c=[0.5, 0.3], mu=[0.2, 0.0])
     for rank, out in results:
         W, means, n_seen, score = out["rcca"]
         assert n_seen == 257
@@ -164,6 +177,12 @@ def test_two_rank_sharded_estimators_match_single_process():
         for w, r in zip(out["mcca"], Wm):
             assert col_rel_err(w, r) < 1e-7
         for w, r in zip(out["gcca"], Wg):
+            assert col_rel_err(w, r) < 1e-7
+        for w, r in zip(out["pcca"][0], Wp):
+            assert col_rel_err(w, r) < 1e-7
+        for b, r in zip(out["pcca"][1], Bp):
+            np.testing.assert_allclose(b, r, rtol=1e-8, atol=1e-10)
+        for w, r in zip(out["grcca"], Wgr):
             assert col_rel_err(w, r) < 1e-7
 
 
