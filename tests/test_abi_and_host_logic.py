@@ -118,3 +118,16 @@ def test_joint_data_matches_reference_stream():
     np.testing.assert_array_equal(b[1], g["draw1_v1"])
     with pytest.raises(ValueError, match="n_features"):
         JointData(n_views=2, n_features=[3])
+
+
+def test_docs_quote_the_real_entry_point_count():
+    """DESIGN.md / INTEGRATION.md state how many entry points the ABI has: keep them honest."""
+    import os
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = len(re.findall(r"^CCZ_API ", open(os.path.join(root, "include", "ccz.h")).read(), flags=re.M))
+    design = open(os.path.join(root, "DESIGN.md")).read()
+    integ = open(os.path.join(root, "INTEGRATION.md")).read()
+    assert f"({n} `extern \"C\"` entry points" in design
+    assert f"argtypes for all {n} symbols" in integ
