@@ -15,7 +15,7 @@ import threading
 
 import numpy as np
 
-__all__ = ["CCZError", "Handle", "bind", "library", "library_path", "default_handle"]
+__all__ = ["CCZError", "Handle", "bind", "library", "library_path", "default_handle", "handle_for", "device_index"]
 
 F32, F64 = 0, 1
 _ERRORS = {
@@ -69,6 +69,7 @@ SIGNATURES = {
     "ccz_moments_pack": (_int, [_vp, _vp, _i64, _vp]),
     "ccz_moments_unpack": (_int, [_vp, _vp, _i64, _vp]),
     "ccz_moments_last_ms": (_int, [_vp, _pdbl, _pdbl]),
+    "ccz_moments_last_pilot": (_int, [_vp, _pint]),
     "ccz_rcca_solve": (_int, [_vp, _vp, _i64, _pi64, _pdbl, _int, _int, _vp, _vp, _vp, _pint]),
     "ccz_mcca_solve": (_int, [_vp, _vp, _i64, _pi64, _int, _pdbl, _dbl, _int, _int, _vp, _vp, _vp, _pint]),
     "ccz_gcca_solve": (_int, [_vp, _vp, _i64, _pi64, _int, _pdbl, _pdbl, _dbl, _int, _int, _vp, _vp, _vp, _pint]),
@@ -85,6 +86,11 @@ SIGNATURES = {
     "ccz_gemm_f64": (_int, [_vp, _int, _int, _i64, _i64, _i64, _dbl, _vp, _i64, _vp, _i64, _dbl, _vp, _i64]),
     "ccz_cca_loss": (_int, [_vp, _int, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _dbl, _vp, _vp, _vp, _i64, _i64]),
     "ccz_cca_loss_moments": (_int, [_vp, _vp, _i64, _i64, _i64, _dbl, C.POINTER(_dbl), _vp, _vp]),
+    "ccz_pair_loss_moments": (_int, [_vp, _vp, _i64, _pi64, _int, _dbl, C.POINTER(_dbl), _vp, _vp]),
+    "ccz_cholinv": (_int, [_vp, _int, C.POINTER(_vp), _pi64, C.POINTER(_vp), C.POINTER(_vp)]),
+    "ccz_randn_fill": (_int, [_vp, _int, _vp, _i64, _i64, _i64, C.c_uint64, _i64, _i64, _dbl, _int]),
+    "ccz_gcca_loss_moments": (_int, [_vp, _vp, _i64, _pi64, _int, _dbl, _int, C.POINTER(_dbl), _vp, _vp]),
+    "ccz_factor_loadings": (_int, [_vp, _vp, _i64, _i64, _vp, _i64, _vp]),
     "ccz_transform": (_int, [_vp, _int, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _i64]),
 }
 
@@ -266,6 +272,12 @@ class Handle:
         self.check(self.lib.ccz_moments_last_ms(self._h, C.byref(g), C.byref(s)))
         return g.value, s.value
 
+    def moments_last_pilot(self):
+        """True if the last K1 launch on this handle used the pilot-mean (shifted) fp32 Gram kernel."""
+        u = C.c_int(0)
+        self.check(self.lib.ccz_moments_last_pilot(self._h, C.byref(u)))
+        return bool(u.value)
+
     # -- fused solves ----------------------------------------------------------------------
     def _solve_out(self, dims, k):
         D = int(sum(dims))
@@ -344,3 +356,28 @@ def default_handle(device=None):
     if h is None:
         h = _default[device] = Handle(device)
     return h
+
+
+def device_index(tensor) -> int:
+    """Ordinal of the GPU a CUDA tensor lives on (``cuda`` without an index = torch's current device)."""
+    idx = tensor.device.index
+    if idx is None:
+        import torch
+
+        idx = torch.cuda.current_device()
+    return int(idx)
+
+
+def handle_for(arrays):
+    """The handle every libccz call on ``arrays`` must go through: bound to the GPU the CUDA tensors among them
+    live on (all on ONE device, else ``ValueError``), the process default for host arrays.  A handle launches
+    on its own device only -- a device-0 handle reading ``cuda:1`` pointers is a fault (or silent peer access)."""
+    devs = set()
+    for a in arrays:
+        if type(a).__module__.startswith("torch") and getattr(a, "is_cuda", False):
+            devs.add(device_index(a))
+    if len(devs) > 1:
+        raise ValueError(f"all CUDA views must live on the same device, got devices {sorted(devs)}")
+    if devs:
+        return default_handle(devs.pop())
+    return default_handle()

@@ -120,7 +120,7 @@ class BaseModel(BaseEstimator, ABC):
 
         zs = self.transform(views)
         m, k = len(zs), int(zs[0].shape[1])
-        h = _backend.default_handle()
+        h = _backend.handle_for(zs)
         mom, keep, n, _, _ = compute_moments(zs, h)
         D = m * k
         h.moments_symmetrize(mom, D)
@@ -150,19 +150,32 @@ class BaseModel(BaseEstimator, ABC):
         return self.weights_
 
     def get_factor_loadings(self, views) -> list:
-        """Pearson correlation of every input feature with every canonical variate."""
-        validated = validate_views(views)
-        zs = self.transform(views)
+        """Pearson correlation of every input feature with every canonical variate.
+
+        The reference forms the n x k variates and an n x d x k product per view on the host
+        (``_base.py:208-234``).  Both the covariance between features and variates and their variances are
+        functions of the view's second moments: ``cov(x, z) = C W``, ``var z = diag(W'CW)``, ``var x = diag(C)``
+        -- so each view takes ONE K1 pass (``ccz_moments``; host arrays are streamed, CUDA tensors stay in HBM)
+        and a d x d x k product on the device (``ccz_factor_loadings``).  Inside ``row_sharded()`` the moments are
+        all-reduced, i.e. the loadings are those of the global sample."""
+        import ctypes as C
+
+        from cca_zoo_amd import _backend
+        from cca_zoo_amd._moments import compute_moments
+
+        check_is_fitted(self)
+        validated = validate_views(views, check_finite=False)
         out = []
-        for v, t in zip(validated, zs):
-            if is_device_tensor(v):
-                v, t = v.double().cpu().numpy(), t.double().cpu().numpy()
-            vc = v - v.mean(axis=0)
-            tc = t - t.mean(axis=0)
-            cov = vc.T @ tc / (v.shape[0] - 1)
-            sv = np.maximum(vc.std(axis=0, ddof=1), 1e-12)
-            st = np.maximum(tc.std(axis=0, ddof=1), 1e-12)
-            out.append(cov / np.outer(sv, st))
+        for v, w in zip(validated, self.weights_):
+            h = _backend.handle_for([v])
+            mom, keep, n, dims, _ = compute_moments([v], h)
+            d, k = int(dims[0]), int(w.shape[1])
+            wd = h.to_device(np.ascontiguousarray(w, dtype=np.float64))
+            od = h.alloc(d * k * 8)
+            h.check(h.lib.ccz_factor_loadings(h.raw, C.c_void_p(int(mom)), int(n), d, C.c_void_p(wd.ptr), k,
+                                              C.c_void_p(od.ptr)))
+            out.append(h.to_host(od, (d, k)))
+            del keep
         return out
 
     def __sklearn_tags__(self) -> Tags:
@@ -204,8 +217,8 @@ def _device_project(v, mean, w):
 
     from cca_zoo_amd import _backend
 
-    h = _backend.default_handle(v.device.index or 0)
-    if v.stride(1) != 1:
+    h = _backend.handle_for([v])
+    if v.stride(1) != 1 or v.stride(0) < v.shape[1]:      # expanded / overlapping rows: ld must be >= d
         v = v.contiguous()
     k = int(w.shape[1])
     out = torch.empty((v.shape[0], k), dtype=v.dtype, device=v.device)

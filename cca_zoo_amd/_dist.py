@@ -54,23 +54,20 @@ def row_sharded(group=None):
         _state.on, _state.group = prev
 
 
-def allreduce_moments(moments, n_local: int, group=None):
-    """SUM-reduce the packed moments tensor in place and return the global row count.
+def allreduce_moments(buf, group=None):
+    """SUM-reduce ``buf`` IN PLACE and return the global row count.
 
-    ``moments`` is a float64 torch tensor ``[G (D*D) | s (D)]`` (CUDA for nccl, CPU for
-    gloo).  The row count travels in the same collective as one extra element so the
-    path has exactly ONE exchange step.
+    ``buf`` is a flat float64 torch tensor ``[payload ... | n_local]`` (CUDA for nccl, CPU for gloo): the packed
+    moments with the local row count in the LAST slot, so the path has exactly ONE exchange step, no staging
+    copy and no extra allocation.  Reading the reduced count back is the one host synchronisation the solve needs
+    anyway (``n`` is a host argument of ``ccz_*_solve``); it also orders the collective before libccz's stream.
     """
     import torch
     import torch.distributed as dist
 
-    if moments.dtype != torch.float64 or moments.dim() != 1:
-        raise ValueError("moments must be a flat float64 tensor")
-    buf = torch.empty(moments.numel() + 1, dtype=torch.float64, device=moments.device)
-    buf[:-1].copy_(moments)
-    buf[-1] = float(n_local)
+    if buf.dtype != torch.float64 or buf.dim() != 1 or buf.numel() < 2:
+        raise ValueError("moments buffer must be a flat float64 tensor with the row count in its last slot")
     dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-    moments.copy_(buf[:-1])
     return int(round(float(buf[-1].item())))
 
 

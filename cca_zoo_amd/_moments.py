@@ -8,10 +8,16 @@ moments (upper-triangular tiles of G, column sums) and -- inside ``row_sharded()
 
 from __future__ import annotations
 
+import time
+
 import numpy as np
 
 from cca_zoo_amd import _backend, _dist
 from cca_zoo_amd._utils._validation import is_device_tensor
+
+
+#: wall-clock of the pieces of the last ``compute_moments`` call on this process (bench.py reports them)
+LAST = {"moments_ms": 0.0, "allreduce_ms": 0.0}
 
 
 def _common_float(views):
@@ -27,7 +33,7 @@ def _common_float(views):
 
 
 def compute_moments(views, handle=None):
-    h = handle or _backend.default_handle()
+    h = handle or _backend.handle_for(views)
     n = int(views[0].shape[0])
     dims = [int(v.shape[1]) for v in views]
     D = sum(dims)
@@ -67,18 +73,23 @@ def compute_moments(views, handle=None):
             a = np.ascontiguousarray(v, dtype=ndt)
             keep.append(a)
             descr.append((a, a.shape[1], a.shape[1]))
+    t_k1 = time.perf_counter()
     h.moments(descr, n, _backend.F32 if kind == "f32" else _backend.F64, on_device, mom_ptr, accumulate=False)
+    LAST["moments_ms"] = (time.perf_counter() - t_k1) * 1e3
+    LAST["allreduce_ms"] = 0.0
     n_total = n
     if sharded:
         # the one collective of the path: packed upper triangle + column sums + row count
         import torch
 
-        packed = torch.empty(D * (D + 1) // 2 + D, dtype=torch.float64, device=mom_t.device)
+        npk = D * (D + 1) // 2 + D
+        packed = torch.empty(npk + 1, dtype=torch.float64, device=mom_t.device)
         h.moments_pack(mom_ptr, D, packed.data_ptr())
         h.sync()
-        n_total = _dist.allreduce_moments(packed, n, _dist.active_group())
-        if mom_t.is_cuda:
-            torch.cuda.current_stream(mom_t.device).synchronize()
+        packed[npk:].fill_(float(n))                     # the row count rides in the tail slot of the same buffer
+        t_ar = time.perf_counter()
+        n_total = _dist.allreduce_moments(packed, _dist.active_group())     # in place; its .item() is the sync
+        LAST["allreduce_ms"] = (time.perf_counter() - t_ar) * 1e3
         h.moments_unpack(packed.data_ptr(), D, mom_ptr)
         keep.append(packed)
     # non-finite inputs (NaN / inf anywhere in a column) surface in that column's sum: the reference's

@@ -10,10 +10,22 @@
 
 using namespace ccz;
 
+namespace ccz {
+// loss.hip
+void cca_loss_impl(ccz_ctx* c, int dtype, const void* z1, const void* z2, int64_t n, int64_t d1, int64_t d2, int64_t ld1,
+                   int64_t ld2, double eps, void* loss_dev, void* g1, void* g2, int64_t ldg1, int64_t ldg2);
+void cca_loss_moments_impl(ccz_ctx* c, const double* mom, int64_t n, int64_t d1, int64_t d2, double eps, double* loss_host,
+                           double* gamma_dev, double* mean_dev);
+void pair_loss_moments_impl(ccz_ctx* c, const double* mom, int64_t n, const int64_t* dims, int m, double eps,
+                            double* loss_host, double* gamma_dev, double* mean_dev);
+void randn_fill_impl(ccz_ctx* c, int dtype, void* out, int64_t rows, int64_t cols, int64_t ld, uint64_t seed,
+                     int64_t row0, int64_t row_stride, double scale, bool accumulate);
+}  // namespace ccz
+
 #define CCZ_GUARD(h, ...)                   \
   if (!(h)) return CCZ_EINVAL;              \
   try {                                     \
-    ::ccz::activate(h);                     \
+    ::ccz::DeviceScope ccz_scope_(h);                   \
     __VA_ARGS__;                            \
     return CCZ_OK;                          \
   } catch (const ccz::Error& e) {           \
@@ -28,152 +40,6 @@ using namespace ccz;
   }
 
 namespace ccz {
-
-// ---------------------------------------------------------------------------
-// DCCA correlation loss: value + closed-form input gradients
-// reference: cca_zoo/deep/objectives.py:61-102 (forward) + autograd backward;
-// maths: oracle/losses.py::cca_loss_closed_form
-// ---------------------------------------------------------------------------
-// Everything between the batch moments and the sample-side GEMMs: loss value and the four d x d gradient
-// matrices (dz1 = ((z1 - mu1) G11s + (z2 - mu2) G12') / (n-1), dz2 = ((z1 - mu1) G12 + (z2 - mu2) G22s) / (n-1)).
-struct LossCore {
-  DBuf G11s, G22s, G12, G12t, mu;
-  double loss = 0.0;
-};
-
-static LossCore cca_loss_core(ccz_ctx* c, const double* G, const double* s, int64_t n, int64_t d1, int64_t d2, double eps,
-                              bool want1, bool want2) {
-  const int64_t D = d1 + d2;
-  const double inv = 1.0 / double(n - 1);
-  LossCore out;
-  DBuf L1(c, d1 * d1), L2(c, d2 * d2), S12(c, d1 * d2);
-  cov_block(c, G, D, s, n, true, inv, 0, d1, 0, d1, L1, d1);
-  add_diag(c, d1, L1, d1, eps);
-  cov_block(c, G, D, s, n, true, inv, d1, d2, d1, d2, L2, d2);
-  add_diag(c, d2, L2, d2, eps);
-  cov_block(c, G, D, s, n, true, inv, 0, d1, d1, d2, S12, d2);
-  {
-    double* Lp[2] = {L1.get(), L2.get()};
-    const int64_t dd[2] = {d1, d2};
-    int info[2] = {0, 0};
-    potrf_lower_batched(c, 2, Lp, dd, dd, info);
-    if (info[0] != 0) fail(CCZ_ENOTSPD, "cca_loss: S11 + eps I is not positive definite");
-    if (info[1] != 0) fail(CCZ_ENOTSPD, "cca_loss: S22 + eps I is not positive definite");
-  }
-
-  // Explicit triangular inverses Li = L^-1 (one blocked TRSM on the identity per factor): every
-  // S^-1 product below is then two MFMA GEMMs instead of two blocked triangular solves -- the loss is
-  // launch-latency bound at DCCA batch shapes (d ~ 512), and S + eps I keeps this well conditioned in fp64.
-  auto tri_inverse = [&](const double* L, int64_t d) {
-    DBuf Li(c, d * d);
-    fill2d(c, d, d, Li, d, 0.0);
-    add_diag(c, d, Li, d, 1.0);
-    trsm_right_lower(c, false, d, d, L, d, Li, d);            // I L^-1
-    return Li;
-  };
-  DBuf Li1 = tri_inverse(L1, d1), Li2 = tri_inverse(L2, d2);
-  // left  solve: S^-1 M = Li' (Li M)      right solve: M S^-1 = (M Li') Li
-  auto solve_left = [&](const double* Li, int64_t d, bool transM, const double* M, int64_t ldm, int64_t r, double alpha, double* o) {
-    DBuf t(c, d * r);
-    gemm(c, false, transM, d, r, d, 1.0, Li, d, M, ldm, 0.0, t, r);
-    gemm(c, true, false, d, r, d, alpha, Li, d, t, r, 0.0, o, r);
-  };
-  auto solve_right = [&](const double* Li, int64_t d, const double* M, int64_t ldm, int64_t r, double alpha, double* o) {
-    DBuf t(c, r * d);
-    gemm(c, false, true, r, d, d, 1.0, M, ldm, Li, d, 0.0, t, d);
-    gemm(c, false, false, r, d, d, alpha, t, d, Li, d, 0.0, o, d);
-  };
-
-  DBuf A(c, d1 * d2), Bmt(c, d1 * d2);
-  solve_left(Li1, d1, false, S12, d2, d2, 1.0, A);            // A   = S11^-1 S12           (d1 x d2)
-  solve_right(Li2, d2, S12, d2, d1, 1.0, Bmt);                // Bm' = S12 S22^-1           (d1 x d2)
-  DBuf rd(c, d1);
-  row_dots(c, d1, d2, A, d2, Bmt, d2, rd);                    // tr(A Bm) = sum A o Bm'
-  std::vector<double> rh(d1);
-  d2h(c, rh.data(), rd, size_t(d1) * 8);
-  for (double v : rh) out.loss -= v;
-  if (!want1 && !want2) return out;
-
-  // G12 = -2 S11^-1 S12 S22^-1 = -2 A S22^-1 (d1 x d2) and its transpose
-  out.G12 = DBuf(c, d1 * d2);
-  out.G12t = DBuf(c, d2 * d1);
-  solve_right(Li2, d2, A, d2, d1, -2.0, out.G12);
-  transpose(c, d1, d2, out.G12, d2, out.G12t, d1);
-  out.mu = DBuf(c, D);
-  d2d(c, out.mu, s, size_t(D) * 8);
-  axpby2d(c, 1, D, 1.0 / double(n), out.mu, D, 0.0, nullptr, 0);
-  if (want1) {
-    // G11 = A Bm S11^-1 = S11^-1 (S12 S22^-1 S21) S11^-1 is symmetric, so G11 + G11' = 2 G11
-    DBuf P(c, d1 * d1);
-    out.G11s = DBuf(c, d1 * d1);
-    gemm(c, false, true, d1, d1, d2, 1.0, A, d2, Bmt, d2, 0.0, P, d1);          // A Bm
-    solve_right(Li1, d1, P, d1, d1, 2.0, out.G11s);
-  }
-  if (want2) {
-    DBuf P(c, d2 * d2);
-    out.G22s = DBuf(c, d2 * d2);
-    gemm(c, true, false, d2, d2, d1, 1.0, Bmt, d2, A, d2, 0.0, P, d2);          // Bm A
-    solve_right(Li2, d2, P, d2, d2, 2.0, out.G22s);
-  }
-  return out;
-}
-
-static void cca_loss_impl(ccz_ctx* c, int dtype, const void* z1, const void* z2, int64_t n, int64_t d1, int64_t d2,
-                          int64_t ld1, int64_t ld2, double eps, void* loss_dev, void* g1, void* g2, int64_t ldg1,
-                          int64_t ldg2) {
-  if (dtype != CCZ_F32 && dtype != CCZ_F64) fail(CCZ_EUNSUP, "cca_loss: dtype must be CCZ_F32 or CCZ_F64");
-  if (!z1 || !z2 || !loss_dev) fail(CCZ_EINVAL, "cca_loss: null argument");
-  if (n < 2 || d1 < 1 || d2 < 1 || ld1 < d1 || ld2 < d2) fail(CCZ_EINVAL, "cca_loss: bad shape");
-  if ((g1 && ldg1 < d1) || (g2 && ldg2 < d2)) fail(CCZ_EINVAL, "cca_loss: bad gradient stride");
-  const int64_t D = d1 + d2;
-  DBuf mom(c, D * D + D);
-  ccz_view views[2] = {{z1, d1, ld1}, {z2, d2, ld2}};
-  moments_impl(c, dtype, views, 2, n, true, mom, false);
-  const double inv = 1.0 / double(n - 1);
-  LossCore k = cca_loss_core(c, mom, mom.get() + D * D, n, d1, d2, eps, g1 != nullptr, g2 != nullptr);
-  if (dtype == CCZ_F32) { const float lf = float(k.loss); h2d(c, loss_dev, &lf, 4); }
-  else h2d(c, loss_dev, &k.loss, 8);
-  if (!g1 && !g2) return;
-  if (g1) {
-    DBuf bias(c, d1);
-    gemm(c, false, false, 1, d1, d1, 1.0, k.mu, D, k.G11s, d1, 0.0, bias, d1);
-    gemm(c, false, false, 1, d1, d2, 1.0, k.mu.get() + d1, D, k.G12t, d1, 1.0, bias, d1);
-    gemm_mixed(c, dtype, n, d1, d1, inv, z1, ld1, k.G11s, d1, 0.0, g1, ldg1, bias);
-    gemm_mixed(c, dtype, n, d1, d2, inv, z2, ld2, k.G12t, d1, 1.0, g1, ldg1, nullptr);
-  }
-  if (g2) {
-    DBuf bias(c, d2);
-    gemm(c, false, false, 1, d2, d2, 1.0, k.mu.get() + d1, D, k.G22s, d2, 0.0, bias, d2);
-    gemm(c, false, false, 1, d2, d1, 1.0, k.mu, D, k.G12, d2, 1.0, bias, d2);
-    gemm_mixed(c, dtype, n, d2, d2, inv, z2, ld2, k.G22s, d2, 0.0, g2, ldg2, bias);
-    gemm_mixed(c, dtype, n, d2, d1, inv, z1, ld1, k.G12, d2, 1.0, g2, ldg2, nullptr);
-  }
-  sync(c);
-}
-
-// Row-sharded batches: the moments have been summed over all ranks (ccz_moments + one all-reduce); this gives
-// the loss and ONE (d1 + d2)^2 matrix Gamma with  [dz1 | dz2] = ([z1 | z2] - 1 mean') Gamma  for any subset of
-// the rows (each rank applies it to its own shard with ccz_transform).
-static void cca_loss_moments_impl(ccz_ctx* c, const double* mom, int64_t n, int64_t d1, int64_t d2, double eps,
-                                  double* loss_host, double* gamma_dev, double* mean_dev) {
-  if (!mom || !loss_host) fail(CCZ_EINVAL, "cca_loss_moments: null argument");
-  if (n < 2 || d1 < 1 || d2 < 1) fail(CCZ_EINVAL, "cca_loss_moments: bad shape");
-  const int64_t D = d1 + d2;
-  const bool want = gamma_dev != nullptr;
-  if (want && !mean_dev) fail(CCZ_EINVAL, "cca_loss_moments: mean_dev is required with gamma_dev");
-  LossCore k = cca_loss_core(c, mom, mom + D * D, n, d1, d2, eps, want, want);
-  *loss_host = k.loss;
-  if (want) {
-    const double inv = 1.0 / double(n - 1);
-    copy2d(c, d1, d1, k.G11s, d1, gamma_dev, D);
-    copy2d(c, d1, d2, k.G12, d2, gamma_dev + d1, D);
-    copy2d(c, d2, d1, k.G12t, d1, gamma_dev + d1 * D, D);
-    copy2d(c, d2, d2, k.G22s, d2, gamma_dev + d1 * D + d1, D);
-    axpby2d(c, D, D, inv, gamma_dev, D, 0.0, nullptr, 0);
-    d2d(c, mean_dev, k.mu, size_t(D) * 8);
-  }
-  sync(c);
-}
 
 // out = (X - mean) W     reference: cca_zoo/_base.py:108-123
 static void transform_impl(ccz_ctx* c, int dtype, const void* X, int64_t n, int64_t d, int64_t ld, const double* mean,
@@ -230,6 +96,10 @@ int ccz_destroy(ccz_handle h) {
     for (int i = 0; i < 4; ++i) (void)hipEventDestroy(im->ev[i]);
     for (int i = 0; i < 4; ++i) if (im->pipe_ev[i]) (void)hipEventDestroy(im->pipe_ev[i]);
     for (int i = 0; i < 2; ++i) if (im->pin_buf[i]) (void)hipHostFree(im->pin_buf[i]);
+    for (int i = 0; i < Impl::kSmallSlots; ++i) {
+      if (im->small_ev[i]) (void)hipEventDestroy(im->small_ev[i]);
+      if (im->small_pin[i]) (void)hipHostFree(im->small_pin[i]);
+    }
     if (im->copy_stream) (void)hipStreamDestroy(im->copy_stream);
     (void)hipFree(im->d_flag);
     (void)hipFree(im->d_small);
@@ -324,6 +194,12 @@ int ccz_moments_last_ms(ccz_handle h, double* gram_ms, double* colsum_ms) {
   })
 }
 
+int ccz_moments_last_pilot(ccz_handle h, int* used) {
+  CCZ_GUARD(h, {
+    if (used) *used = h->last_pilot;
+  })
+}
+
 int ccz_cca_loss(ccz_handle h, int dtype, const void* z1_dev, const void* z2_dev, int64_t n, int64_t d1, int64_t d2,
                  int64_t ld1, int64_t ld2, double eps, void* loss_dev, void* g1_dev, void* g2_dev, int64_t ldg1,
                  int64_t ldg2) {
@@ -335,6 +211,41 @@ int ccz_cca_loss(ccz_handle h, int dtype, const void* z1_dev, const void* z2_dev
 int ccz_cca_loss_moments(ccz_handle h, const double* moments_dev, int64_t n_rows, int64_t d1, int64_t d2, double eps,
                          double* loss_host, double* gamma_dev, double* mean_dev) {
   CCZ_GUARD(h, ccz::cca_loss_moments_impl(h, moments_dev, n_rows, d1, d2, eps, loss_host, gamma_dev, mean_dev));
+}
+
+int ccz_pair_loss_moments(ccz_handle h, const double* moments_dev, int64_t n_rows, const int64_t* dims, int n_views, double eps,
+                          double* loss_host, double* gamma_dev, double* mean_dev) {
+  CCZ_GUARD(h, ccz::pair_loss_moments_impl(h, moments_dev, n_rows, dims, n_views, eps, loss_host, gamma_dev, mean_dev));
+}
+
+int ccz_randn_fill(ccz_handle h, int dtype, void* out_dev, int64_t rows, int64_t cols, int64_t ld, uint64_t seed, int64_t row0,
+                   int64_t row_stride, double scale, int accumulate) {
+  CCZ_GUARD(h, ccz::randn_fill_impl(h, dtype, out_dev, rows, cols, ld, seed, row0, row_stride, scale, accumulate != 0));
+}
+
+int ccz_cholinv(ccz_handle h, int count, double* const* A_dev, const int64_t* d, double* const* L_dev, double* const* X_dev) {
+  CCZ_GUARD(h, {
+    if (count < 1 || count > 8 || !A_dev || !d || !L_dev) fail(CCZ_EINVAL, "cholinv: 1..8 matrices, non-null arrays");
+    std::vector<DBuf> T(count);
+    std::vector<double*> Tp(count);
+    for (int b = 0; b < count; ++b) {
+      if (d[b] < 1 || !A_dev[b] || !L_dev[b] || (X_dev && !X_dev[b])) fail(CCZ_EINVAL, "cholinv: bad matrix %d", b);
+      T[b] = DBuf(h, (d[b] + 63) / 64 * 4096);
+      Tp[b] = T[b].get();
+    }
+    int* info_dev = static_cast<int*>(dev_alloc(h, 8 * sizeof(int)));
+    int got[8];
+    try {
+      cholinv_batched(h, count, A_dev, d, d, L_dev, d, X_dev, d, Tp.data(), info_dev);
+      d2h(h, got, info_dev, size_t(count) * sizeof(int));
+    } catch (...) {
+      dev_free(h, info_dev);
+      throw;
+    }
+    dev_free(h, info_dev);
+    for (int b = 0; b < count; ++b)
+      if (got[b] != 0x7fffffff) fail(CCZ_ENOTSPD, "cholinv: matrix %d is not positive definite (pivot %d)", b, got[b] - 1);
+  })
 }
 
 int ccz_transform(ccz_handle h, int dtype, const void* X_dev, int64_t n, int64_t d, int64_t ld, const double* mean_dev,

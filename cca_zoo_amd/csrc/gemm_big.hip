@@ -153,7 +153,9 @@ __global__ __launch_bounds__(256, 1) void k_gemm_f32_nn_fifo(int64_t M, int64_t 
                                                              const float* __restrict__ A, int64_t lda,
                                                              const float* __restrict__ B, int64_t ldb, float beta,
                                                              float* __restrict__ C, int64_t ldc,
-                                                             const float* __restrict__ bias) {
+                                                             const float* __restrict__ bias,
+                                                             float* __restrict__ C2, int64_t ldc2, int64_t nsplit) {
+  // C2 != null: output columns [nsplit, N) go to C2 (columns renumbered from 0), nsplit a multiple of 256
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int64_t tn = N / BT, tm = (M + BT - 1) / BT;
   const int64_t q = int64_t(blockIdx.x) >> 3;
@@ -257,6 +259,9 @@ __global__ __launch_bounds__(256, 1) void k_gemm_f32_nn_fifo(int64_t M, int64_t 
   const int64_t nbase = n0 + wc * 128 + 4 * (lane & 31);
   v4f32 bias4 = {0.f, 0.f, 0.f, 0.f};
   if (bias) bias4 = *reinterpret_cast<const v4f32*>(bias + nbase);
+  float* Cout = C;
+  int64_t ldo = ldc, ncol = nbase;
+  if (C2 && n0 >= nsplit) { Cout = C2; ldo = ldc2; ncol = nbase - nsplit; }
 #pragma unroll
   for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
@@ -264,7 +269,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_f32_nn_fifo(int64_t M, int64_t 
       const int trow = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
       const int64_t m = mw + 32 * ti + trow;
       if (m >= M) continue;
-      float* cp = C + m * ldc + nbase;
+      float* cp = Cout + m * ldo + ncol;
       v4f32 v = {acc[ti][0][r], acc[ti][1][r], acc[ti][2][r], acc[ti][3][r]};
       v = (v - bias4) * alpha;
       if (beta != 0.f) v += beta * *reinterpret_cast<const v4f32*>(cp);
@@ -458,7 +463,7 @@ void gemm_f32_big(ccz_ctx* c, int64_t M, int64_t N, int64_t K, double alpha, con
     const size_t fifo_bytes = size_t(4) * GFR * GFSLOT;   // 128 KiB: four wave-private rings
     CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_f32_nn_fifo), hipFuncAttributeMaxDynamicSharedMemorySize, int(fifo_bytes)));
     hipLaunchKernelGGL(k_gemm_f32_nn_fifo, dim3((unsigned)((tmb + 7) / 8 * 8 * tnb)), dim3(256), fifo_bytes, st, M, N, K,
-                       float(alpha), A, lda, B32, N, float(beta), C, ldc, bias32);
+                       float(alpha), A, lda, B32, N, float(beta), C, ldc, bias32, static_cast<float*>(nullptr), int64_t(0), N);
   } else {
     const size_t lds_bytes = size_t(2) * 2 * BKK * BT * 4;
     CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_f32_nn_big), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
@@ -469,6 +474,31 @@ void gemm_f32_big(ccz_ctx* c, int64_t M, int64_t N, int64_t K, double alpha, con
   CCZ_LAUNCH_CHECK();
   CCZ_HIP(hipStreamSynchronize(st));   // B32 is pooled scratch
   dev_free(c, B32);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// FIFO product with prepared fp32 operands and a column-split destination (DCCA loss: [dz1 | dz2] = (Z - mean) Gamma
+// in ONE launch, the two column ranges landing in the two gradient tensors).  No conversion, no allocation, no
+// synchronisation: everything the caller hands in stays alive until its own synchronisation point.
+// ---------------------------------------------------------------------------------------------------
+bool gemm_f32_fifo_split_eligible(int64_t M, int64_t N, int64_t K, int64_t nsplit, const void* C1, int64_t ldc1, const void* C2,
+                                  int64_t ldc2) {
+  if (N % BT != 0 || nsplit % BT != 0 || nsplit <= 0 || nsplit >= N || K % 32 != 0 || K < 32 || M < 1) return false;
+  if (ldc1 % 4 != 0 || ldc2 % 4 != 0) return false;
+  if (reinterpret_cast<uintptr_t>(C1) % 16 != 0 || reinterpret_cast<uintptr_t>(C2) % 16 != 0) return false;
+  if (int64_t(128) * K * 4 >= (int64_t(1) << 31) || K * N * 4 >= (int64_t(1) << 31)) return false;
+  const int64_t tmb = (M + BT - 1) / BT, tnb = N / BT;
+  return (tmb + 7) / 8 * 8 * tnb < (int64_t(1) << 31);
+}
+
+void gemm_f32_fifo_split(ccz_ctx* c, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda, const float* B32,
+                         const float* bias32, float* C1, int64_t ldc1, float* C2, int64_t ldc2, int64_t nsplit) {
+  const int64_t tmb = (M + BT - 1) / BT, tnb = N / BT;
+  const size_t fifo_bytes = size_t(4) * GFR * GFSLOT;
+  CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_f32_nn_fifo), hipFuncAttributeMaxDynamicSharedMemorySize, int(fifo_bytes)));
+  hipLaunchKernelGGL(k_gemm_f32_nn_fifo, dim3((unsigned)((tmb + 7) / 8 * 8 * tnb)), dim3(256), fifo_bytes, stream(c), M, N, K, alpha, A, lda,
+                     B32, N, 0.0f, C1, ldc1, bias32, C2, ldc2, nsplit);
+  CCZ_LAUNCH_CHECK();
 }
 
 }  // namespace ccz

@@ -120,10 +120,16 @@ __device__ __forceinline__ v4f32 load4_f32(gptr_f32 base, int64_t row, int64_t l
   return v;
 }
 
+// PILOT (fp32 robustness, reference semantics cca_zoo/_base.py:97-99 "centre before any product"): `pilot` holds one
+// float per stacked column (the column mean of this launch's rows, rounded to fp32) and is subtracted while the rows
+// are staged into LDS, so the MFMA accumulates (x - p)(x - p)' -- numbers of the size of the covariance instead of
+// mean^2 + covariance.  Every thread stages the same four columns of every row, so the pilot costs eight registers
+// and 32 VALU subtractions per 128 MFMAs.  The shift is undone on the d x d side in fp64 (k_pilot_fixup).
 template <bool FAST>
 __global__ __launch_bounds__(256, 1) void k_gram_f32(const GramTile* __restrict__ tiles, int ntiles, int per_xcd,
                                                      int64_t ksplit, int64_t n, int64_t rows_per_wg,
-                                                     double* __restrict__ G, int64_t ldg) {
+                                                     double* __restrict__ G, int64_t ldg,
+                                                     const float* __restrict__ pilot) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* lds = reinterpret_cast<float*>(smem);  // [2 buffers][A | B][BK][256]
   const WorkItem wi = locate_work(blockIdx.x, ntiles, per_xcd, ksplit);
@@ -180,15 +186,27 @@ __global__ __launch_bounds__(256, 1) void k_gram_f32(const GramTile* __restrict_
       }
     }
   };
+  // pilot values of this thread's four A-panel and four B-panel columns (0 past the panel width: those lanes
+  // staged zeros and must keep them)
+  v4f32 pa = {0.f, 0.f, 0.f, 0.f}, pb = {0.f, 0.f, 0.f, 0.f};
+  if (pilot) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (4 * cg + e < t.wa) pa[e] = pilot[t.out_row + 4 * cg + e];
+      if (4 * cg + e < t.wb) pb[e] = pilot[t.out_col + 4 * cg + e];
+    }
+  }
   auto lstore = [&](int buf, int64_t k0) {
     float* as = lds + buf * (2 * BK * T32);
     float* bs = as + BK * T32;
     const v4f32 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const bool ok = FAST || k0 + r4 + 4 * i <= last_row;   // fast path: the descriptor already zero-fills
-      *reinterpret_cast<v4f32*>(as + (r4 + 4 * i) * T32 + 4 * cg) = ok ? ra[i] : z;
-      *reinterpret_cast<v4f32*>(bs + (r4 + 4 * i) * T32 + 4 * cg) = ok ? rb[i] : z;
+      // fast path without a pilot: the descriptor already zero-fills; with a pilot the rows past the end must
+      // stay exactly zero (0 - p would count p p' for every padded row)
+      const bool ok = (FAST && !pilot) || k0 + r4 + 4 * i <= last_row;
+      *reinterpret_cast<v4f32*>(as + (r4 + 4 * i) * T32 + 4 * cg) = ok ? ra[i] - pa : z;
+      *reinterpret_cast<v4f32*>(bs + (r4 + 4 * i) * T32 + 4 * cg) = ok ? rb[i] - pb : z;
     }
   };
 
@@ -698,23 +716,53 @@ __global__ __launch_bounds__(256, 1) void k_gram_f64_fifo(const GramTile* __rest
 // ---------------------------------------------------------------------------
 // column sums: HBM-bound single pass, fp64 accumulation
 // ---------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool SQ>
 __global__ __launch_bounds__(256) void k_colsum(const T* __restrict__ X, int64_t n, int64_t cols, int64_t ld,
-                                                double* __restrict__ out, int64_t rows_per_block) {
+                                                double* __restrict__ out, double* __restrict__ out_sq,
+                                                int64_t rows_per_block) {
   const int64_t col = int64_t(blockIdx.x) * 256 + threadIdx.x;
   if (col >= cols) return;
   const int64_t r0 = int64_t(blockIdx.y) * rows_per_block;
   const int64_t r1 = min(n, r0 + rows_per_block);
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  double q0 = 0.0, q1 = 0.0;
   int64_t r = r0;
   for (; r + 3 < r1; r += 4) {
-    a0 += double(X[(r + 0) * ld + col]);
-    a1 += double(X[(r + 1) * ld + col]);
-    a2 += double(X[(r + 2) * ld + col]);
-    a3 += double(X[(r + 3) * ld + col]);
+    const double x0 = double(X[(r + 0) * ld + col]), x1 = double(X[(r + 1) * ld + col]);
+    const double x2 = double(X[(r + 2) * ld + col]), x3 = double(X[(r + 3) * ld + col]);
+    a0 += x0; a1 += x1; a2 += x2; a3 += x3;
+    if (SQ) { q0 += x0 * x0 + x2 * x2; q1 += x1 * x1 + x3 * x3; }
   }
-  for (; r < r1; ++r) a0 += double(X[r * ld + col]);
+  for (; r < r1; ++r) {
+    const double x = double(X[r * ld + col]);
+    a0 += x;
+    if (SQ) q0 += x * x;
+  }
   unsafeAtomicAdd(out + col, (a0 + a1) + (a2 + a3));
+  if (SQ) unsafeAtomicAdd(out_sq + col, q0 + q1);
+}
+
+// pilot[j] = fl32(colsum[j] / n): the fp32 value closest to the mean of this launch's rows
+__global__ void k_pilot_from_sums(const double* __restrict__ s, int64_t D, double inv_n, float* __restrict__ pilot) {
+  const int64_t j = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (j < D) pilot[j] = float(s[j] * inv_n);
+}
+
+// Undo the pilot shift on the d x d side, in fp64, and fold the launch's column sums into the running ones:
+//   sum x_i x_j = sum (x_i - p_i)(x_j - p_j) + p_i s_j + p_j s_i - n p_i p_j      (s = column sums of these rows)
+// Only elements on or above the diagonal are authoritative (every consumer reads G through its upper triangle).
+__global__ void k_pilot_fixup(double* __restrict__ G, int64_t D, const double* __restrict__ s_launch, double n,
+                              const float* __restrict__ pilot) {
+  const int64_t i = blockIdx.y;
+  const int64_t j = i + int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (j >= D) return;
+  const double pi = double(pilot[i]), pj = double(pilot[j]);
+  G[i * D + j] += pi * s_launch[j] + pj * s_launch[i] - n * pi * pj;
+}
+
+__global__ void k_vec_add(double* __restrict__ dst, const double* __restrict__ src, int64_t n) {
+  const int64_t j = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (j < n) dst[j] += src[j];
 }
 
 // ---------------------------------------------------------------------------
@@ -727,9 +775,11 @@ struct Panel {
   int64_t col0, width, gcol0;
 };
 
+// pilot_mode (fp32 only): 0 = never, 1 = automatic (column sums and sums of squares are inspected on the host: one small
+// read-back), 2 = always (device-side only, no host synchronisation).  Returns whether the pilot path ran.
 template <typename T>
-void launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, double* G, double* s, int64_t D,
-                    bool time_it, void** tile_cache = nullptr) {
+bool launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, double* G, double* s, int64_t D,
+                    bool time_it, void** tile_cache = nullptr, int pilot_mode = 0) {
   Impl* im = impl(c);
   hipStream_t st = stream(c);
   constexpr bool is32 = sizeof(T) == 4;
@@ -799,11 +849,8 @@ void launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
     d_tiles = static_cast<GramTile*>(*tile_cache);
   } else {
     d_tiles = static_cast<GramTile*>(dev_alloc(c, tiles.size() * sizeof(GramTile)));
-    h2d(c, d_tiles, tiles.data(), tiles.size() * sizeof(GramTile));
-    if (tile_cache) {
-      CCZ_HIP(hipStreamSynchronize(st));   // `tiles` is a pageable temporary
-      *tile_cache = d_tiles;
-    }
+    h2d_small(c, d_tiles, tiles.data(), tiles.size() * sizeof(GramTile));   // through a pinned slot: no stream sync
+    if (tile_cache) *tile_cache = d_tiles;
   }
 
   const int ncu = std::max(1, im->props.multiProcessorCount);
@@ -842,19 +889,71 @@ void launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
   if (nblocks > 0x7fffffffLL) fail(CCZ_EUNSUP, "gram: grid too large");
   const size_t lds_bytes = size_t(2) * 2 * BK * tile * sizeof(T);  // 64 KiB either way
 
+  // ---- column sums first: they are the means, and for fp32 views they decide (and define) the pilot shift ----
+  static const int pilot_env = [] { const char* e = getenv("CCZ_GRAM_PILOT"); return e ? atoi(e) : -1; }();   // -1: caller's mode
+  if (pilot_env == 0 || pilot_env == 1) pilot_mode = pilot_env == 1 ? 2 : 0;
+  if (!is32) pilot_mode = 0;                                  // fp64 views accumulate in fp64: nothing to protect
+  static const double pilot_thr = [] { const char* e = getenv("CCZ_GRAM_PILOT_RATIO"); return e ? atof(e) : 2.0; }();
+  double* s_launch = s;            // column sums of THIS launch's rows (separate from the running sums in pilot modes)
+  double* sq = nullptr;
+  if (pilot_mode != 0) {
+    s_launch = static_cast<double*>(dev_alloc(c, size_t(D) * 8 * (pilot_mode == 1 ? 2 : 1)));
+    zero(c, s_launch, size_t(D) * 8 * (pilot_mode == 1 ? 2 : 1));
+    if (pilot_mode == 1) sq = s_launch + D;
+  }
+  if (time_it) CCZ_HIP(hipEventRecord(im->ev[2], st));
+  int64_t off = 0;
+  for (int v = 0; v < n_views; ++v) {
+    // enough row blocks to cover the chip even for narrow / short views
+    const int64_t colblocks = (views[v].cols + 255) / 256;
+    int64_t rpb = 2048;
+    while (rpb > 64 && colblocks * ((n + rpb - 1) / rpb) < 4 * int64_t(ncu)) rpb /= 2;
+    dim3 grid((unsigned)colblocks, (unsigned)((n + rpb - 1) / rpb));
+    if (sq)
+      hipLaunchKernelGGL((k_colsum<T, true>), grid, dim3(256), 0, st, static_cast<const T*>(views[v].data), n, views[v].cols,
+                         views[v].ld, s_launch + off, sq + off, rpb);
+    else
+      hipLaunchKernelGGL((k_colsum<T, false>), grid, dim3(256), 0, st, static_cast<const T*>(views[v].data), n, views[v].cols,
+                         views[v].ld, s_launch + off, static_cast<double*>(nullptr), rpb);
+    off += views[v].cols;
+  }
+  CCZ_LAUNCH_CHECK();
+  if (time_it) CCZ_HIP(hipEventRecord(im->ev[3], st));
+  bool use_pilot = pilot_mode == 2;
+  if (pilot_mode == 1) {
+    // largest |mean| / std over the columns: fp32 accumulation of raw products loses ~ eps32 sqrt(rows) (mean/std)^2 of
+    // a covariance entry (6e-4 at ratio 10, garbage at 1000); the FIFO kernel is kept for ratio <= 2
+    std::vector<double> hs(size_t(2) * D);
+    d2h(c, hs.data(), s_launch, size_t(2) * D * 8);
+    double worst = 0.0;
+    for (int64_t j = 0; j < D; ++j) {
+      const double mu = hs[j] / double(n), var = hs[D + j] / double(n) - mu * mu;
+      if (!std::isfinite(mu) || !std::isfinite(var)) continue;          // NaN / inf inputs are reported by the caller
+      const double sd = var > 0.0 ? std::sqrt(var) : 0.0;
+      const double ratio = std::fabs(mu) <= pilot_thr * sd ? 0.0 : (sd > 0.0 ? std::fabs(mu) / sd : 1e300);
+      if (ratio > worst) worst = ratio;
+    }
+    use_pilot = worst > pilot_thr;
+  }
+  float* pilot = nullptr;
+  if (use_pilot) {
+    pilot = static_cast<float*>(dev_alloc(c, size_t(D) * 4));
+    hipLaunchKernelGGL(k_pilot_from_sums, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, st, s_launch, D, 1.0 / double(n), pilot);
+  }
+
   if (time_it) CCZ_HIP(hipEventRecord(im->ev[0], st));
   static const int impl_sel = [] { const char* e = getenv("CCZ_GRAM_IMPL"); return e ? atoi(e) : 1; }();   // 1: wave-private FIFO (default), 0: register-staged shared tile
   if (is32) {
-    if (fast && impl_sel != 0) {
+    if (fast && impl_sel != 0 && !use_pilot) {
       const size_t fifo_bytes = size_t(4) * FR * FSLOT;   // 128 KiB: four wave-private rings
       CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_f32_fifo), hipFuncAttributeMaxDynamicSharedMemorySize, int(fifo_bytes)));
       hipLaunchKernelGGL(k_gram_f32_fifo, dim3((unsigned)nblocks), dim3(256), fifo_bytes, st, d_tiles, ntiles, per_xcd, ksplit, n, rows_per_wg, G, D);
     } else if (fast) {
       CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_f32<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
-      hipLaunchKernelGGL(k_gram_f32<true>, dim3((unsigned)nblocks), dim3(256), lds_bytes, st, d_tiles, ntiles, per_xcd, ksplit, n, rows_per_wg, G, D);
+      hipLaunchKernelGGL(k_gram_f32<true>, dim3((unsigned)nblocks), dim3(256), lds_bytes, st, d_tiles, ntiles, per_xcd, ksplit, n, rows_per_wg, G, D, pilot);
     } else {
       CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_f32<false>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
-      hipLaunchKernelGGL(k_gram_f32<false>, dim3((unsigned)nblocks), dim3(256), lds_bytes, st, d_tiles, ntiles, per_xcd, ksplit, n, rows_per_wg, G, D);
+      hipLaunchKernelGGL(k_gram_f32<false>, dim3((unsigned)nblocks), dim3(256), lds_bytes, st, d_tiles, ntiles, per_xcd, ksplit, n, rows_per_wg, G, D, pilot);
     }
   } else {
     static const int impl64 = [] { const char* e = getenv("CCZ_GRAM64_IMPL"); return e ? atoi(e) : 1; }();   // 1: FIFO, 0: staged
@@ -871,36 +970,28 @@ void launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
     }
   }
   CCZ_LAUNCH_CHECK();
-  if (time_it) {
-    CCZ_HIP(hipEventRecord(im->ev[1], st));
-    CCZ_HIP(hipEventRecord(im->ev[2], st));
+  if (time_it) CCZ_HIP(hipEventRecord(im->ev[1], st));
+  if (use_pilot) {
+    if (D > 65535) fail(CCZ_EUNSUP, "gram: pilot fix-up supports D <= 65535");
+    hipLaunchKernelGGL(k_pilot_fixup, dim3((unsigned)((D + 255) / 256), (unsigned)D), dim3(256), 0, st, G, D, s_launch, double(n), pilot);
   }
-  int64_t off = 0;
-  for (int v = 0; v < n_views; ++v) {
-    // enough row blocks to cover the chip even for narrow / short views
-    const int64_t colblocks = (views[v].cols + 255) / 256;
-    int64_t rpb = 2048;
-    while (rpb > 64 && colblocks * ((n + rpb - 1) / rpb) < 4 * int64_t(ncu)) rpb /= 2;
-    dim3 grid((unsigned)colblocks, (unsigned)((n + rpb - 1) / rpb));
-    hipLaunchKernelGGL(k_colsum<T>, grid, dim3(256), 0, st, static_cast<const T*>(views[v].data), n, views[v].cols,
-                       views[v].ld, s + off, rpb);
-    off += views[v].cols;
-  }
+  if (s_launch != s) hipLaunchKernelGGL(k_vec_add, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, st, s, s_launch, D);
   CCZ_LAUNCH_CHECK();
   if (time_it) {
-    CCZ_HIP(hipEventRecord(im->ev[3], st));
-    CCZ_HIP(hipEventSynchronize(im->ev[3]));
+    CCZ_HIP(hipEventSynchronize(im->ev[1]));
     float g = 0.f, cs = 0.f;
     CCZ_HIP(hipEventElapsedTime(&g, im->ev[0], im->ev[1]));
     CCZ_HIP(hipEventElapsedTime(&cs, im->ev[2], im->ev[3]));
     c->last_gram_ms += g;
     c->last_colsum_ms += cs;
   }
-  // the tile table must outlive the kernel: stream-ordered, so synchronise before recycling it
-  // (pipelined callers own the table and free it after their final synchronise)
-  if (tile_cache) return;
-  CCZ_HIP(hipStreamSynchronize(st));
-  dev_free(c, d_tiles);
+  c->last_pilot = use_pilot ? 1 : 0;
+  // scratch goes back to the handle's pool right away: the pool is stream-ordered (one stream per handle), so a later
+  // allocation that reuses a block can only touch it after the kernels enqueued above
+  if (pilot) dev_free(c, pilot);
+  if (s_launch != s) dev_free(c, s_launch);
+  if (!tile_cache) dev_free(c, d_tiles);
+  return use_pilot;
 }
 
 // pinned bounce buffers + copy stream of the host-input pipeline; false if pinned memory is unavailable
@@ -955,7 +1046,7 @@ void pack_rows(char* dst, const ccz_view* views, int n_views, size_t es, int64_t
 }  // namespace
 
 void moments_impl(ccz_ctx* c, int dtype, const ccz_view* views, int n_views, int64_t n_rows, bool on_device,
-                  double* moments, bool accumulate) {
+                  double* moments, bool accumulate, int pilot_mode, bool time_it) {
   if (!views || n_views < 1 || !moments) fail(CCZ_EINVAL, "moments: null argument");
   if (dtype != CCZ_F32 && dtype != CCZ_F64) fail(CCZ_EUNSUP, "moments: dtype must be CCZ_F32 or CCZ_F64");
   if (n_rows < 0) fail(CCZ_EINVAL, "moments: negative row count");
@@ -973,8 +1064,8 @@ void moments_impl(ccz_ctx* c, int dtype, const ccz_view* views, int n_views, int
   if (n_rows == 0) return;
   const size_t es = dtype == CCZ_F32 ? 4 : 8;
   if (on_device) {
-    if (dtype == CCZ_F32) launch_moments<float>(c, views, n_views, n_rows, G, s, D, true);
-    else launch_moments<double>(c, views, n_views, n_rows, G, s, D, true);
+    if (dtype == CCZ_F32) launch_moments<float>(c, views, n_views, n_rows, G, s, D, time_it, nullptr, pilot_mode);
+    else launch_moments<double>(c, views, n_views, n_rows, G, s, D, time_it, nullptr, 0);
     return;
   }
   // Host-resident (pageable) views: a three-stage pipeline over ~512 MiB row chunks,
@@ -1009,7 +1100,14 @@ void moments_impl(ccz_ctx* c, int dtype, const ccz_view* views, int n_views, int
         stage[sl * n_views + v] = dev_alloc(c, size_t(chunk) * views[v].cols * es);
         dv[sl * n_views + v] = ccz_view{stage[sl * n_views + v], views[v].cols, views[v].cols};
       }
+    if (piped) {
+      // pooled scratch is recycled in stream order on the handle's stream: make the copy stream a part of that order
+      // before it writes into freshly pooled staging blocks
+      CCZ_HIP(hipEventRecord(im->pipe_ev[2], stream(c)));
+      CCZ_HIP(hipStreamWaitEvent(im->copy_stream, im->pipe_ev[2], 0));
+    }
     int64_t ci = 0;
+    int chunk_mode = pilot_mode;
     for (int64_t r0 = 0; r0 < n_rows; r0 += chunk, ++ci) {
       const int64_t rows = std::min(chunk, n_rows - r0);
       const int sl = piped ? int(ci & 1) : 0;
@@ -1033,8 +1131,14 @@ void moments_impl(ccz_ctx* c, int dtype, const ccz_view* views, int n_views, int
         }
         CCZ_HIP(hipStreamSynchronize(stream(c)));
       }
-      if (dtype == CCZ_F32) launch_moments<float>(c, &dv[sl * n_views], n_views, rows, G, s, D, false, &tile_tab[sl]);
-      else launch_moments<double>(c, &dv[sl * n_views], n_views, rows, G, s, D, false, &tile_tab[sl]);
+      // streamed chunks: the first chunk decides (its read-back happens while the pipeline is still filling); the
+      // later chunks follow it without touching the host, each with the pilot of its own rows
+      if (dtype == CCZ_F32) {
+        const bool used = launch_moments<float>(c, &dv[sl * n_views], n_views, rows, G, s, D, false, &tile_tab[sl], chunk_mode);
+        if (chunk_mode == 1) chunk_mode = used ? 2 : 0;
+      } else {
+        launch_moments<double>(c, &dv[sl * n_views], n_views, rows, G, s, D, false, &tile_tab[sl], 0);
+      }
       if (piped) CCZ_HIP(hipEventRecord(im->pipe_ev[2 + sl], stream(c)));
     }
   } catch (...) {

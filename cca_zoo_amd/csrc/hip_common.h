@@ -40,6 +40,12 @@ struct Impl {
   size_t pin_cap = 0;
   hipStream_t copy_stream = nullptr;
   hipEvent_t pipe_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // h2d done [2], compute done [2]
+  // ring of pinned slots for small asynchronous host -> device copies (tile tables, descriptors)
+  static constexpr int kSmallSlots = 8;
+  static constexpr size_t kSmallBytes = size_t(64) << 10;
+  void* small_pin[kSmallSlots] = {};
+  hipEvent_t small_ev[kSmallSlots] = {};
+  int small_next = 0;
 };
 
 inline Impl* impl(ccz_ctx* c) { return static_cast<Impl*>(c->impl); }
@@ -56,8 +62,13 @@ inline hipStream_t stream(ccz_ctx* c) { return static_cast<hipStream_t>(c->strea
 #define CCZ_LAUNCH_CHECK() CCZ_HIP(hipGetLastError())
 
 // gram.hip
+// pilot_mode: 0 never / 1 automatic (one small host read-back) / 2 always (no host sync) -- fp32 views only;
+// time_it: record HIP events around the Gram and column-sum kernels (costs a host wait at the end)
 void moments_impl(ccz_ctx* c, int dtype, const ccz_view* views, int n_views, int64_t n_rows,
-                  bool on_device, double* moments, bool accumulate);
+                  bool on_device, double* moments, bool accumulate, int pilot_mode = 1, bool time_it = true);
+// small host -> device copy through a ring of pinned slots: asynchronous on the handle's stream (the pageable source
+// may be reused as soon as this returns); larger than a slot falls back to the synchronous copy
+void h2d_small(ccz_ctx* c, void* dst, const void* src, size_t bytes);
 // typed GEMM used by the loss backward / transform: C (M x N) = alpha A (M x K) B (K x N) + beta C
 // A, C of type T (float or double); B is float64 on the device and converted on load.
 void gemm_mixed(ccz_ctx* c, int dtype, int64_t M, int64_t N, int64_t K, double alpha, const void* A,
@@ -70,6 +81,12 @@ bool gemm_f32_big_eligible(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t
 void gemm_f32_big(ccz_ctx* c, int64_t M, int64_t N, int64_t K, double alpha, const float* A, int64_t lda,
                   const double* B, int64_t ldb, double beta, float* C, int64_t ldc, const double* bias_row);
 
+// the FIFO kernel on prepared fp32 operands with a column-split destination: C1 <- columns [0, nsplit), C2 <- the rest
+bool gemm_f32_fifo_split_eligible(int64_t M, int64_t N, int64_t K, int64_t nsplit, const void* C1, int64_t ldc1, const void* C2,
+                                  int64_t ldc2);
+void gemm_f32_fifo_split(ccz_ctx* c, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda, const float* B32,
+                         const float* bias32, float* C1, int64_t ldc1, float* C2, int64_t ldc2, int64_t nsplit);
+
 // gemm64_big.hip: 128x128-tile fp64 GEMM (solver stage)
 bool gemm_f64_big_eligible(bool tA, bool tB, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
                            const double* B, int64_t ldb, const double* C, int64_t ldc);
@@ -81,5 +98,20 @@ bool gemm_f64_skinny_eligible(bool tA, bool tB, int64_t M, int64_t N, int64_t K,
                               const double* B, int64_t ldb);
 void gemm_f64_skinny(ccz_ctx* c, bool tA, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda,
                      const double* B, int64_t ldb, double beta, double* C, int64_t ldc);
+
+// cholinv.hip: batched (<= 8 matrices) Cholesky factor + triangular inverse in d / 64 + 1 launches, no host sync;
+// A destroyed, L lower factor, X = L^-1 lower (blocks strictly above the diagonal are NOT written: zero X first if a
+// consumer reads them), T scratch of ceil(d / 64) * 4096 doubles per matrix, info_dev[b] = 0x7fffffff or 1 + bad pivot
+void cholinv_batched(ccz_ctx* c, int count, double* const* A, const int64_t* lda, const int64_t* d, double* const* L,
+                     const int64_t* ldl, double* const* X, const int64_t* ldx, double* const* T, int* info_dev);
+// up to 8 independent fp64 products per launch: C = alpha op(A) op(B) + beta C, optional transposed copy Ct = C'
+struct MultiGemmArgs {
+  const double* A; const double* B; double* C; double* Ct;
+  int64_t lda, ldb, ldc, ldct;
+  int64_t M, N, K;
+  bool tA, tB, lower_only;
+  double alpha, beta;
+};
+void gemm_f64_multi(ccz_ctx* c, int count, const MultiGemmArgs* problems);
 
 }  // namespace ccz

@@ -25,6 +25,7 @@ struct ccz_ctx {
   std::string err;
   double last_gram_ms = 0.0;
   double last_colsum_ms = 0.0;
+  int last_pilot = 0;      // 1 if the last ccz_moments launch used the pilot-mean (shifted) Gram kernel
   void* impl = nullptr;    // backend-private (memory pool, events, device props)
 };
 
@@ -45,6 +46,19 @@ void d2d(ccz_ctx* c, void* dst, const void* src, size_t bytes);
 void zero(ccz_ctx* c, void* dst, size_t bytes);
 void sync(ccz_ctx* c);
 void activate(ccz_ctx* c);  // make the handle's device current on the calling thread (every ABI entry)
+int device_current();       // the calling thread's current device (-1 when there is none)
+void device_set(int dev);
+
+// Every ABI entry runs inside one of these: the handle's device is made current for the call and the
+// caller's device is restored afterwards, so a handle on cuda:1 never leaks "current device = 1" into the
+// caller's runtime state (PyTorch keeps its own notion of the current device per thread).
+struct DeviceScope {
+  int prev, mine;
+  explicit DeviceScope(ccz_ctx* c) : prev(device_current()), mine(c->device) { activate(c); }
+  ~DeviceScope() { if (prev >= 0 && prev != mine) device_set(prev); }
+  DeviceScope(const DeviceScope&) = delete;
+  DeviceScope& operator=(const DeviceScope&) = delete;
+};
 
 // RAII device buffer of doubles
 class DBuf {

@@ -65,6 +65,27 @@ void h2d(ccz_ctx* c, void* dst, const void* src, size_t bytes) {
   CCZ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream(c)));
   CCZ_HIP(hipStreamSynchronize(stream(c)));  // src is pageable host memory owned by the caller
 }
+void h2d_small(ccz_ctx* c, void* dst, const void* src, size_t bytes) {
+  if (!bytes) return;
+  Impl* im = impl(c);
+  if (bytes > Impl::kSmallBytes) { h2d(c, dst, src, bytes); return; }
+  const int i = im->small_next;
+  if (!im->small_pin[i]) {
+    if (hipHostMalloc(&im->small_pin[i], Impl::kSmallBytes, hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&im->small_ev[i], hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      if (im->small_pin[i]) { (void)hipHostFree(im->small_pin[i]); im->small_pin[i] = nullptr; }
+      h2d(c, dst, src, bytes);
+      return;
+    }
+  } else {
+    CCZ_HIP(hipEventSynchronize(im->small_ev[i]));      // the copy that last used this slot has drained it
+  }
+  im->small_next = (i + 1) % Impl::kSmallSlots;
+  std::memcpy(im->small_pin[i], src, bytes);
+  CCZ_HIP(hipMemcpyAsync(dst, im->small_pin[i], bytes, hipMemcpyHostToDevice, stream(c)));
+  CCZ_HIP(hipEventRecord(im->small_ev[i], stream(c)));
+}
 void d2h(ccz_ctx* c, void* dst, const void* src, size_t bytes) {
   if (!bytes) return;
   CCZ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream(c)));
@@ -84,6 +105,12 @@ void activate(ccz_ctx* c) {
   CCZ_HIP(hipSetDevice(c->device));
   wave_kernels_init();
 }
+int device_current() {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return -1; }
+  return dev;
+}
+void device_set(int dev) { (void)hipSetDevice(dev); }
 
 // ===========================================================================
 // GEMM on the matrix pipe: 64x64 block tile, 4 waves (2x2), each wave 2x2 MFMA 16x16x4

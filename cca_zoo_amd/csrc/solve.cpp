@@ -765,6 +765,103 @@ static void gcca_solve_impl(ccz_ctx* c, const double* mom, int64_t n, const int6
   if (k_out) *k_out = kk;
 }
 
+// ===========================================================================
+// top-k generalised eigenpairs  A v = lam B v  (B SPD or null), rows-form output Vt (kk x p), v'Bv = 1
+// reference: gevp, cca_zoo/_utils/_linalg.py:44-73
+// ===========================================================================
+void gevp_topk_rows(ccz_ctx* c, const double* A, const double* B, int64_t p, int kk, std::vector<double>& lam, double* Vt) {
+  if (!B) {
+    eig_topk_dense(c, A, p, kk, lam, Vt, p);
+    return;
+  }
+  DBuf L(c, p * p), Y(c, p * p), St(c, p * p);
+  d2d(c, L, B, size_t(p) * p * 8);
+  if (potrf_lower(c, L, p, p) != 0) fail(CCZ_ENOTSPD, "B is not positive definite");
+  d2d(c, Y, A, size_t(p) * p * 8);
+  trsm_right_lower(c, true, p, p, L, p, Y, p);          // A L^-T
+  transpose(c, p, p, Y, p, St, p);
+  trsm_right_lower(c, true, p, p, L, p, St, p);         // (L^-1 A L^-T)'
+  transpose(c, p, p, St, p, Y, p);
+  axpby2d(c, p, p, 0.5, Y, p, 0.5, St, p);             // symmetrise
+  eig_topk_dense(c, Y, p, kk, lam, Vt, p);
+  trsm_right_lower(c, false, kk, p, L, p, Vt, p);       // rows y' L^-1 = (L^-T y)'
+}
+
+// ===========================================================================
+// GCCALoss from the batch moments      reference: cca_zoo/deep/objectives.py:155-220
+//   loss  = -(n-1) sum_{j<k} lam_j,   C u = lam B u,  B = blockdiag(C_ii) + eps I,  u'Bu = 1
+//   Gamma = -2 sum_j (u_j u_j' - lam_j blockdiag(u_ji u_ji'))    with   dL/dZ = (Z - 1 mean') Gamma
+// (maths: oracle/losses.py::gcca_loss_closed_form).  Everything stays on the device; only the k eigenvalues
+// come to the host.
+// ===========================================================================
+static void gcca_loss_moments_impl(ccz_ctx* c, const double* mom, int64_t n, const int64_t* dims, int m, double eps,
+                                   int k, double* loss_host, double* gamma_dev, double* mean_dev) {
+  if (!mom || !dims || !loss_host) fail(CCZ_EINVAL, "gcca_loss_moments: null argument");
+  if (m < 1 || n < 2 || k < 1) fail(CCZ_EINVAL, "gcca_loss_moments: bad shape");
+  if (gamma_dev && !mean_dev) fail(CCZ_EINVAL, "gcca_loss_moments: mean_dev is required with gamma_dev");
+  for (int i = 0; i < m; ++i)
+    if (dims[i] < 1) fail(CCZ_EINVAL, "gcca_loss_moments: view %d has no features", i);
+  auto off = offsets(dims, m);
+  const int64_t D = off[m];
+  const double* G = mom;
+  const double* s = mom + D * D;
+  const double inv = 1.0 / double(n - 1);
+  const int kk = int(std::min<int64_t>(k, D));
+  DBuf Cm(c, D * D), Bm(c, D * D);
+  cov_block(c, G, D, s, n, true, inv, 0, D, 0, D, Cm, D);
+  fill2d(c, D, D, Bm, D, 0.0);
+  for (int i = 0; i < m; ++i)
+    copy2d(c, dims[i], dims[i], Cm.get() + off[i] * D + off[i], D, Bm.get() + off[i] * D + off[i], D);
+  add_diag(c, D, Bm, D, eps);
+  std::vector<double> lam;
+  DBuf Vt(c, int64_t(kk) * D);
+  gevp_topk_rows(c, Cm, Bm, D, kk, lam, Vt);
+  double total = 0.0;
+  for (double v : lam) total += v;
+  *loss_host = -double(n - 1) * total;
+  if (!gamma_dev) return;
+  // Gamma = -2 Vt'Vt  +  2 blockdiag_i( (Lam Vt_i)' Vt_i )
+  gemm(c, true, false, D, D, kk, -2.0, Vt, D, Vt, D, 0.0, gamma_dev, D);
+  std::vector<int64_t> perm(kk);
+  std::iota(perm.begin(), perm.end(), 0);
+  DBuf VtL(c, int64_t(kk) * D);
+  gather_rows(c, kk, D, Vt, D, perm.data(), lam.data(), VtL, D);
+  for (int i = 0; i < m; ++i)
+    gemm(c, true, false, dims[i], dims[i], kk, 2.0, VtL.get() + off[i], D, Vt.get() + off[i], D, 1.0,
+         gamma_dev + off[i] * D + off[i], D);
+  d2d(c, mean_dev, s, size_t(D) * 8);
+  axpby2d(c, 1, D, 1.0 / double(n), mean_dev, D, 0.0, nullptr, 0);
+}
+
+// ===========================================================================
+// factor loadings of ONE view from its second moments      reference: cca_zoo/_base.py:208-234
+//   out[j][t] = corr(x_j, z_t),  z = (x - mean) W:   cov(x, z) = C W,  var z = diag(W'CW),  var x = diag(C)
+// with the reference's guards std = max(std, 1e-12).
+// ===========================================================================
+static void factor_loadings_impl(ccz_ctx* c, const double* mom, int64_t n, int64_t d, const double* W, int64_t k,
+                                 double* out) {
+  if (!mom || !W || !out || n < 2 || d < 1 || k < 1) fail(CCZ_EINVAL, "factor_loadings: bad argument");
+  DBuf Cm(c, d * d), CW(c, d * k), ones(c, d), vx(c, d), vt(c, k), Wt(c, k * d), CWt(c, k * d);
+  cov_block(c, mom, d, mom + d * d, n, true, 1.0 / double(n - 1), 0, d, 0, d, Cm, d);
+  gemm(c, false, false, d, k, d, 1.0, Cm, d, W, k, 0.0, CW, k);
+  fill2d(c, 1, d, ones, d, 1.0);
+  row_dots(c, d, 1, Cm, d + 1, ones, 1, vx);                 // diag(C)
+  transpose(c, d, k, W, k, Wt, d);
+  transpose(c, d, k, CW, k, CWt, d);
+  row_dots(c, k, d, Wt, d, CWt, d, vt);                      // diag(W' C W)
+  std::vector<double> hx(d), ht(k);
+  d2h(c, hx.data(), vx, size_t(d) * 8);
+  d2h(c, ht.data(), vt, size_t(k) * 8);
+  std::vector<int64_t> perm(d);
+  std::iota(perm.begin(), perm.end(), 0);
+  for (auto& v : hx) v = 1.0 / std::max(std::sqrt(std::max(v, 0.0)), 1e-12);
+  for (auto& v : ht) v = std::max(std::sqrt(std::max(v, 0.0)), 1e-12);
+  DBuf td(c, k);
+  h2d(c, td, ht.data(), size_t(k) * 8);
+  gather_rows(c, d, k, CW, k, perm.data(), hx.data(), out, k);   // rows / std_x
+  scale_cols(c, d, k, out, k, td, 1);                             // columns / std_z
+}
+
 }  // namespace ccz
 
 // ===========================================================================
@@ -773,7 +870,7 @@ static void gcca_solve_impl(ccz_ctx* c, const double* mom, int64_t n, const int6
 #define CCZ_GUARD(h, ...)                                              \
   if (!(h)) return CCZ_EINVAL;                                         \
   try {                                                                \
-    ::ccz::activate(h);                                                \
+    ::ccz::DeviceScope ccz_scope_(h);                                              \
     __VA_ARGS__;                                                       \
     return CCZ_OK;                                                     \
   } catch (const ccz::Error& e) {                                      \
@@ -848,21 +945,7 @@ int ccz_gevp_topk(ccz_handle h, const double* A_dev, const double* B_dev, int64_
     const int kk = int(std::min<int64_t>(k, p));
     std::vector<double> lam;
     ccz::DBuf Vt(h, int64_t(kk) * p);
-    if (!B_dev) {
-      ccz::eig_topk_dense(h, A_dev, p, kk, lam, Vt, p);
-    } else {
-      ccz::DBuf L(h, p * p), Y(h, p * p), St(h, p * p);
-      ccz::d2d(h, L, B_dev, size_t(p) * p * 8);
-      if (ccz::potrf_lower(h, L, p, p) != 0) ccz::fail(CCZ_ENOTSPD, "B is not positive definite");
-      ccz::d2d(h, Y, A_dev, size_t(p) * p * 8);
-      ccz::trsm_right_lower(h, true, p, p, L, p, Y, p);          // A L^-T
-      ccz::transpose(h, p, p, Y, p, St, p);
-      ccz::trsm_right_lower(h, true, p, p, L, p, St, p);         // (L^-1 A L^-T)'
-      ccz::transpose(h, p, p, St, p, Y, p);
-      ccz::axpby2d(h, p, p, 0.5, Y, p, 0.5, St, p);             // symmetrise
-      ccz::eig_topk_dense(h, Y, p, kk, lam, Vt, p);
-      ccz::trsm_right_lower(h, false, kk, p, L, p, Vt, p);       // rows y' L^-1 = (L^-T y)'
-    }
+    ccz::gevp_topk_rows(h, A_dev, B_dev, p, kk, lam, Vt);
     ccz::transpose(h, kk, p, Vt, p, V_dev, kk);
     ccz::h2d(h, w_dev, lam.data(), size_t(kk) * 8);
   })
@@ -967,6 +1050,16 @@ int ccz_gemm_f64(ccz_handle h, int transA, int transB, int64_t M, int64_t N, int
     if (!A_dev || !B_dev || !C_dev || M < 1 || N < 1 || K < 1) ccz::fail(CCZ_EINVAL, "bad argument");
     ccz::gemm(h, transA != 0, transB != 0, M, N, K, alpha, A_dev, lda, B_dev, ldb, beta, C_dev, ldc);
   })
+}
+
+int ccz_gcca_loss_moments(ccz_handle h, const double* moments_dev, int64_t n_rows, const int64_t* dims, int n_views,
+                          double eps, int k, double* loss_host, double* gamma_dev, double* mean_dev) {
+  CCZ_GUARD(h, ccz::gcca_loss_moments_impl(h, moments_dev, n_rows, dims, n_views, eps, k, loss_host, gamma_dev, mean_dev));
+}
+
+int ccz_factor_loadings(ccz_handle h, const double* moments_dev, int64_t n_rows, int64_t d, const double* W_dev,
+                        int64_t k, double* out_dev) {
+  CCZ_GUARD(h, ccz::factor_loadings_impl(h, moments_dev, n_rows, d, W_dev, k, out_dev));
 }
 
 }  // extern "C"

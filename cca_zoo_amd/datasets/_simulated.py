@@ -3,9 +3,10 @@
 Host generator: bit-identical to the reference's ``JointData`` for a given seed
 (cca_zoo/datasets/_simulated.py:49-130 -- one ``default_rng``; loadings drawn at
 construction in view order; every ``sample()`` draws ``z`` then one noise block per
-view).  ``sample_device`` draws the same *model* straight into HBM with torch's
-Philox generator for the at-scale measurement inputs (32.8 GB at the north-star
-shape cannot be generated on the host); its streams are torch's, not NumPy's.
+view).  ``sample_device`` draws the same *model* straight into HBM with libccz's
+counter-based generator for the at-scale measurement inputs (32.8 GB at the
+north-star shape cannot be generated on the host); ``oracle/rng.py`` restates it
+in NumPy, so any row range can be regenerated on the host.
 """
 
 from __future__ import annotations
@@ -63,27 +64,50 @@ class JointData:
     def __call__(self) -> list[np.ndarray]:
         return self.sample()
 
-    def sample_device(self, device="cuda", dtype=None, n_samples=None, seed=None, row_chunk=65536):
-        """Draw the views directly into HBM (torch CUDA tensors), chunked over rows."""
+    def sample_device(self, device="cuda", dtype=None, n_samples=None, seed=None, row0=0, row_chunk=131072):
+        """Draw rows ``[row0, row0 + n_samples)`` of the views directly into HBM (torch CUDA tensors).
+
+        Every element is a pure function of ``(seed, global row, column)`` (``ccz_randn_fill``: SplitMix64 +
+        Box-Muller, ``csrc/rng_hash.h``), the signal ``z (W diag(scales))'`` is a device GEMM (``ccz_transform``):
+        ``x_v[r, :] = fl(z[r, :]) Wt_v + N_v[r, :] / sqrt(snr_v)``.  The same rows come out whatever the chunking,
+        the shard (``row0``) or the number of GPUs, and ``oracle.rng.joint_data_rows`` regenerates any of them on
+        the host."""
+        import ctypes as C
+
         import torch
 
+        from cca_zoo_amd import _backend
+
         dtype = dtype or torch.float32
+        if dtype not in (torch.float32, torch.float64):
+            raise TypeError("sample_device: dtype must be torch.float32 or torch.float64")
         n = int(n_samples if n_samples is not None else self.n_samples)
-        gen = torch.Generator(device=device)
-        gen.manual_seed(int(self.random_state or 0) if seed is None else int(seed))
-        Ws = [torch.as_tensor(w, dtype=torch.float32, device=device) for w in self._weights]
-        scales = None
-        if self.latent_scales is not None:
-            scales = torch.as_tensor(np.asarray(self.latent_scales), dtype=torch.float32, device=device)
-        outs = [torch.empty((n, p), dtype=dtype, device=device) for p in self._features_per_view]
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("sample_device draws into HBM: a CUDA (ROCm) device is required")
+        seed = int(self.random_state or 0) if seed is None else int(seed)
+        base = (seed * 1000003) & 0xFFFFFFFFFFFFFFFF
+        zseed = (base + 1) & 0xFFFFFFFFFFFFFFFF
+        k = int(self.latent_dimensions)
+        code = _backend.F32 if dtype == torch.float32 else _backend.F64
+        outs = [torch.empty((n, p), dtype=dtype, device=dev) for p in self._features_per_view]
+        h = _backend.handle_for(outs)
+        scales = np.ones(k) if self.latent_scales is None else np.asarray(self.latent_scales, dtype=np.float64)
+        wts = [torch.as_tensor(np.ascontiguousarray((w * scales[None, :]).T), dtype=torch.float64, device=dev)
+               for w in self._weights]                                    # k x d_v
+        zbuf = torch.empty((min(n, row_chunk), k), dtype=dtype, device=dev)
+        torch.cuda.current_stream(dev).synchronize()
         for r0 in range(0, n, row_chunk):
-            r1 = min(n, r0 + row_chunk)
-            z = torch.randn((r1 - r0, self.latent_dimensions), generator=gen, device=device, dtype=torch.float32)
-            if scales is not None:
-                z = z * scales
-            for out, w, snr in zip(outs, Ws, self._snr_per_view):
+            rows = min(n, r0 + row_chunk) - r0
+            h.check(h.lib.ccz_randn_fill(h.raw, code, C.c_void_p(zbuf.data_ptr()), rows, k, k, zseed, int(row0) + r0,
+                                         k + (k & 1), 1.0, 0))
+            for v, (out, wt, snr) in enumerate(zip(outs, wts, self._snr_per_view)):
+                d = int(out.shape[1])
                 sd = 1.0 / float(np.sqrt(snr)) if snr > 0 else 1.0
-                blk = torch.randn((r1 - r0, w.shape[0]), generator=gen, device=device, dtype=torch.float32)
-                blk.mul_(sd).addmm_(z, w.T)
-                out[r0:r1].copy_(blk)
+                blk = out[r0:r0 + rows]
+                h.check(h.lib.ccz_transform(h.raw, code, C.c_void_p(zbuf.data_ptr()), rows, k, k, None,
+                                            C.c_void_p(wt.data_ptr()), d, C.c_void_p(blk.data_ptr()), d))
+                h.check(h.lib.ccz_randn_fill(h.raw, code, C.c_void_p(blk.data_ptr()), rows, d, d,
+                                             (base + 2 + v) & 0xFFFFFFFFFFFFFFFF, int(row0) + r0, d + (d & 1), sd, 1))
+        h.sync()
         return outs

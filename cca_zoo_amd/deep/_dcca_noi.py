@@ -54,7 +54,7 @@ class _BatchWhiten(nn.Module):
         n, d = int(x.shape[0]), int(x.shape[1])
         a = x.detach()
         a = a if a.stride(1) == 1 else a.contiguous()
-        h = _backend.default_handle(x.device.index or 0)
+        h = _backend.handle_for([x])
         mom = torch.empty(d * d + d, dtype=torch.float64, device=x.device)
         torch.cuda.current_stream(x.device).synchronize()
         h.moments([(a.data_ptr(), d, a.stride(0))], n, _backend.F32 if a.dtype == torch.float32 else _backend.F64,

@@ -54,15 +54,16 @@ class _ShardedCCALossFn(torch.autograd.Function):
         n_local, D = int(zcat.shape[0]), int(zcat.shape[1])
         d1, d2 = int(z1.shape[1]), int(z2.shape[1])
         dev = zcat.device
-        h = _backend.default_handle(dev.index or 0)
+        h = _backend.handle_for([zcat])
         mom = torch.empty(D * D + D, dtype=torch.float64, device=dev)
         torch.cuda.current_stream(dev).synchronize()
         h.moments([(zcat.data_ptr(), D, D)], n_local, _backend.F32 if dt == torch.float32 else _backend.F64, True, mom.data_ptr())
-        packed = torch.empty(D * (D + 1) // 2 + D, dtype=torch.float64, device=dev)
+        npk = D * (D + 1) // 2 + D
+        packed = torch.empty(npk + 1, dtype=torch.float64, device=dev)
         h.moments_pack(mom.data_ptr(), D, packed.data_ptr())
         h.sync()
-        n_total = _dist.allreduce_moments(packed, n_local, _dist.active_group())
-        torch.cuda.current_stream(dev).synchronize()
+        packed[npk:].fill_(float(n_local))
+        n_total = _dist.allreduce_moments(packed, _dist.active_group())
         h.moments_unpack(packed.data_ptr(), D, mom.data_ptr())
         need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         loss_h = C.c_double(0.0)
@@ -94,13 +95,13 @@ class _CCALossFn(torch.autograd.Function):
             z2 = z2.to(z1.dtype)
         if z1.dim() != 2 or z2.dim() != 2 or z1.shape[0] != z2.shape[0]:
             raise ValueError("CCALoss expects two (batch, d_i) tensors with equal batch size")
-        a = z1 if z1.stride(1) == 1 else z1.contiguous()
-        b = z2 if z2.stride(1) == 1 else z2.contiguous()
+        a = z1 if (z1.stride(1) == 1 and z1.stride(0) >= z1.shape[1]) else z1.contiguous()
+        b = z2 if (z2.stride(1) == 1 and z2.stride(0) >= z2.shape[1]) else z2.contiguous()
         need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         loss = torch.empty((), dtype=a.dtype, device=a.device)
         g1 = torch.empty_like(a, memory_format=torch.contiguous_format) if need else None
         g2 = torch.empty_like(b, memory_format=torch.contiguous_format) if need else None
-        h = _backend.default_handle(a.device.index or 0)
+        h = _backend.handle_for([a])
         torch.cuda.current_stream(a.device).synchronize()
         h.check(h.lib.ccz_cca_loss(
             h.raw, _backend.F32 if a.dtype == torch.float32 else _backend.F64,
@@ -122,7 +123,7 @@ class _CCALossFn(torch.autograd.Function):
 def _inv_sqrtm(A: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
     """``A^-1/2`` with eigenvalues clamped at ``eps`` (device Jacobi EVD, forward only)."""
     _require_cuda(A, "_inv_sqrtm")
-    h = _backend.default_handle(A.device.index or 0)
+    h = _backend.handle_for([A])
     a64 = A.detach().to(torch.float64).contiguous()
     out = torch.empty_like(a64)
     torch.cuda.current_stream(A.device).synchronize()
@@ -157,6 +158,64 @@ class CCALoss(nn.Module):
         return _CCALossFn.apply(z1, z2, self.eps)
 
 
+class _PairLossFn(torch.autograd.Function):
+    """Sum over all view pairs of the CCA loss from ONE pass over the stacked batch: K1 on ``[z_1 .. z_m]``, (inside
+    ``row_sharded()``) one all-reduce of the packed moments, ``ccz_pair_loss_moments`` -- one Cholesky + inverse per
+    VIEW, where the reference re-centres every view and recomputes its ``S_aa^-1/2`` once per PAIR
+    (cca_zoo/deep/objectives.py:138-153) -- and the gradient of every view as one ``ccz_transform`` GEMM
+    ``(Z - mean) Gamma``."""
+
+    @staticmethod
+    def forward(ctx, eps: float, *zs: torch.Tensor) -> torch.Tensor:
+        from cca_zoo_amd import _dist
+
+        for z in zs:
+            _require_cuda(z, "MCCALoss")
+            if z.dim() != 2 or z.shape[0] != zs[0].shape[0]:
+                raise ValueError("MCCALoss expects (batch, d_i) tensors with equal batch size")
+        dt = zs[0].dtype
+        zcat = torch.cat([z.to(dt) for z in zs], dim=1).contiguous()
+        n_local, D = int(zcat.shape[0]), int(zcat.shape[1])
+        dims = [int(z.shape[1]) for z in zs]
+        dev = zcat.device
+        h = _backend.handle_for([zcat])
+        mom = torch.empty(D * D + D, dtype=torch.float64, device=dev)
+        torch.cuda.current_stream(dev).synchronize()
+        h.moments([(zcat.data_ptr(), D, D)], n_local, _backend.F32 if dt == torch.float32 else _backend.F64, True, mom.data_ptr())
+        n_total = n_local
+        if _dist.is_sharded():
+            npk = D * (D + 1) // 2 + D
+            packed = torch.empty(npk + 1, dtype=torch.float64, device=dev)
+            h.moments_pack(mom.data_ptr(), D, packed.data_ptr())
+            h.sync()
+            packed[npk:].fill_(float(n_local))
+            n_total = _dist.allreduce_moments(packed, _dist.active_group())
+            h.moments_unpack(packed.data_ptr(), D, mom.data_ptr())
+        need = any(ctx.needs_input_grad[1:])
+        loss_h = C.c_double(0.0)
+        gam = torch.empty((D, D), dtype=torch.float64, device=dev) if need else None
+        mean = torch.empty(D, dtype=torch.float64, device=dev) if need else None
+        dims_a = (C.c_int64 * len(dims))(*dims)
+        h.check(h.lib.ccz_pair_loss_moments(h.raw, C.c_void_p(mom.data_ptr()), int(n_total), dims_a, len(dims), float(eps),
+                                            C.byref(loss_h), C.c_void_p(gam.data_ptr()) if need else None,
+                                            C.c_void_p(mean.data_ptr()) if need else None))
+        if need:
+            ctx.save_for_backward(_project(zcat, mean, gam))
+            ctx.dims = dims
+            ctx.dtypes = [z.dtype for z in zs]
+        return torch.tensor(loss_h.value, dtype=dt, device=dev)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (gcat,) = ctx.saved_tensors
+        grads = torch.split(gcat, ctx.dims, dim=1)
+        return (None, *[(grad_out * g).to(t) for g, t in zip(grads, ctx.dtypes)])
+
+
+#: widest view the one-pass pairwise core serves (wider views: pair by pair through ``CCALoss``)
+_PAIR_CORE_MAX_WIDTH = 2048
+
+
 class MCCALoss(nn.Module):
     r"""Sum of pairwise :class:`CCALoss` over all view pairs ``i < j``.
 
@@ -171,7 +230,9 @@ class MCCALoss(nn.Module):
 
     def forward(self, representations: list[torch.Tensor]) -> torch.Tensor:
         n_views = len(representations)
-        total = torch.tensor(0.0, device=representations[0].device)
+        total = torch.tensor(0.0, device=representations[0].device)      # fp32 accumulator, as the reference (:149)
+        if 2 <= n_views <= 8 and max(int(z.shape[1]) for z in representations) <= _PAIR_CORE_MAX_WIDTH:
+            return total + _PairLossFn.apply(self.eps, *representations)
         for i in range(n_views):
             for j in range(i + 1, n_views):
                 total = total + self._cca_loss([representations[i], representations[j]])
@@ -180,8 +241,8 @@ class MCCALoss(nn.Module):
 
 def _project(x: torch.Tensor, mean64: torch.Tensor, w64: torch.Tensor) -> torch.Tensor:
     """``(x - mean) @ w`` through ``ccz_transform`` (x: n x d CUDA tensor, mean: d, w: d x k float64 CUDA)."""
-    h = _backend.default_handle(x.device.index or 0)
-    a = x if x.stride(1) == 1 else x.contiguous()
+    h = _backend.handle_for([x])
+    a = x if (x.stride(1) == 1 and x.stride(0) >= x.shape[1]) else x.contiguous()   # e.g. an expanded gradient
     out = torch.empty((a.shape[0], w64.shape[1]), dtype=a.dtype, device=a.device)
     torch.cuda.current_stream(a.device).synchronize()
     h.check(h.lib.ccz_transform(h.raw, _backend.F32 if a.dtype == torch.float32 else _backend.F64,
@@ -205,8 +266,6 @@ class _GCCALossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, eps: float, *zs: torch.Tensor) -> torch.Tensor:
-        import numpy as np
-
         for z in zs:
             _require_cuda(z, "GCCALoss")
             if z.dim() != 2 or z.shape[0] != zs[0].shape[0]:
@@ -217,39 +276,22 @@ class _GCCALossFn(torch.autograd.Function):
         dims = [int(z.shape[1]) for z in zs]
         k = dims[0]
         dev = zcat.device
-        h = _backend.default_handle(dev.index or 0)
+        h = _backend.handle_for([zcat])
         mom = torch.empty(D * D + D, dtype=torch.float64, device=dev)
         torch.cuda.current_stream(dev).synchronize()
         h.moments([(zcat.data_ptr(), D, D)], n, _backend.F32 if dt == torch.float32 else _backend.F64, True, mom.data_ptr())
-        h.moments_symmetrize(mom.data_ptr(), D)
-        flat = h.to_host(mom.data_ptr(), (D * D + D,))
-        G, s = flat[: D * D].reshape(D, D), flat[D * D:]
-        Cm = (G - np.outer(s, s) / n) / (n - 1)
-        Bm = np.zeros_like(Cm)
-        mask = np.zeros((D, D), dtype=bool)
-        o = 0
-        for d in dims:
-            Bm[o:o + d, o:o + d] = Cm[o:o + d, o:o + d]
-            mask[o:o + d, o:o + d] = True
-            o += d
-        Bm[np.diag_indices(D)] += eps
-        # top-k generalised eigenpairs on the device; all D x D products below are device GEMMs as well
-        Ad, Bd = h.to_device(Cm), h.to_device(Bm)
-        wd, Vd = h.alloc(k * 8), h.alloc(D * k * 8)
-        h.check(h.lib.ccz_gevp_topk(h.raw, C.c_void_p(Ad.ptr), C.c_void_p(Bd.ptr), D, k, C.c_void_p(wd.ptr), C.c_void_p(Vd.ptr)))
-        lam, U = h.to_host(wd, (k,)), h.to_host(Vd, (D, k))
-        BUd = h.alloc(D * k * 8)
-        h.gemm(0, 0, D, k, D, 1.0, Bd.ptr, D, Vd.ptr, k, 0.0, BUd.ptr, k)
-        U = U / np.sqrt((U * h.to_host(BUd, (D, k))).sum(axis=0))[None, :]          # u' B u = 1
-        loss = torch.tensor(-(n - 1) * float(lam.sum()), dtype=dt, device=dev)
-        if any(ctx.needs_input_grad[1:]):
-            Ud, ULd = h.to_device(U), h.to_device(U * lam[None, :])
-            Pd, Qd = h.alloc(D * D * 8), h.alloc(D * D * 8)
-            h.gemm(0, 1, D, D, k, 1.0, Ud.ptr, k, Ud.ptr, k, 0.0, Pd.ptr, D)          # sum_k u u'
-            h.gemm(0, 1, D, D, k, 1.0, ULd.ptr, k, Ud.ptr, k, 0.0, Qd.ptr, D)         # sum_k lambda u u'
-            Gamma = -2.0 * (h.to_host(Pd, (D, D)) - np.where(mask, h.to_host(Qd, (D, D)), 0.0))
-            gam = torch.as_tensor(Gamma, device=dev)
-            mean = torch.as_tensor(s / n, device=dev)
+        # C, B = blockdiag(C_ii) + eps I, the top-k generalised eigenpairs and Gamma are all built on the device
+        # from the moments (ccz_gcca_loss_moments); only the k eigenvalues (as the loss) come back to the host
+        need = any(ctx.needs_input_grad[1:])
+        loss_h = C.c_double(0.0)
+        gam = torch.empty((D, D), dtype=torch.float64, device=dev) if need else None
+        mean = torch.empty(D, dtype=torch.float64, device=dev) if need else None
+        dims_a = (C.c_int64 * len(dims))(*dims)
+        h.check(h.lib.ccz_gcca_loss_moments(h.raw, C.c_void_p(mom.data_ptr()), n, dims_a, len(dims), float(eps), k,
+                                            C.byref(loss_h), C.c_void_p(gam.data_ptr()) if need else None,
+                                            C.c_void_p(mean.data_ptr()) if need else None))
+        loss = torch.tensor(loss_h.value, dtype=dt, device=dev)
+        if need:
             ctx.save_for_backward(_project(zcat, mean, gam))
             ctx.dims = dims
             ctx.dtypes = [z.dtype for z in zs]

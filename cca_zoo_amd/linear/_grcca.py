@@ -75,7 +75,7 @@ class GRCCA(MCCA):
                               "regularisation a no-op.")
             feature_groups = [np.ones(int(v.shape[1]), dtype=int) for v in views_]
         self.feature_groups_ = feature_groups
-        h = _backend.default_handle()
+        h = _backend.handle_for(views_)
         mom, keep, n, dims, kind = compute_moments(views_, h)
         self.n_samples_ = int(n)
         D = int(sum(dims))

@@ -57,7 +57,7 @@ class PartialCCA(MCCA):
         if int(Z.shape[0]) != self.n_samples_:
             raise ValueError("`partials` must have one row per sample")
         dz = int(Z.shape[1])
-        h = _backend.default_handle()
+        h = _backend.handle_for(views_)
         # K1 over [Z | X_1 .. X_m]: the confound rows of G are the first dz rows (all inside the upper triangle)
         mom, keep, n, dims_all, kind = compute_moments([Z, *views_], h)
         self.n_samples_ = int(n)
@@ -97,13 +97,16 @@ class PartialCCA(MCCA):
         Z = _as_partials(partials, validated[0])
         out = []
         for z, b, w in zip(base, self.confound_betas_, self.weights_):
-            bw = b @ w                                                   # dz x k
+            bw = b @ w                                                   # dz x k  (host, tiny)
             if is_device_tensor(z):
-                import torch
+                from cca_zoo_amd._base import _device_project
 
-                out.append(z - (Z.to(torch.float64) @ torch.as_tensor(bw, device=z.device)).to(z.dtype))
+                # Z (beta W) on the device through ccz_transform (no vendor BLAS on the product path)
+                out.append(z - _device_project(Z.to(z.dtype), np.zeros(bw.shape[0]), bw))
             else:
-                out.append(z - Z @ bw)
+                from cca_zoo_amd._base import _host_project
+
+                out.append(z - _host_project(np.ascontiguousarray(Z, dtype=z.dtype), np.zeros(bw.shape[0]), bw))
         return out
 
     def fit_transform(self, views, y=None, partials=None):

@@ -54,7 +54,7 @@ class rCCA(BaseModel):
     def fit(self, views, y=None):
         views_ = self._setup_fit(views)
         self._check_n_views()
-        h = _backend.default_handle()
+        h = _backend.handle_for(views_)
         mom, keep, n_total, dims, kind = compute_moments(views_, h)
         self.n_samples_ = int(n_total)            # inside row_sharded(): the global row count
         self._fit_moments(h, mom, n_total, dims, kind)

@@ -153,7 +153,7 @@ class GridSearchCV:
         """Inside ``row_sharded()`` the views are this rank's rows: the folds are cut within every shard (global fold f
         = union of the ranks' folds f), ``compute_moments`` all-reduces each fold's moments, and every rank then runs
         the same solves on the same global moments (replicated, like a sharded ``fit``)."""
-        h = _backend.default_handle()
+        h = _backend.handle_for(views)
         candidates = list(ParameterGrid(self.param_grid))
         n_folds = len(splits)
         t_pass = time.perf_counter()
@@ -253,6 +253,13 @@ class GridSearchCV:
     # -- generic route ---------------------------------------------------------------------------
     def _fit_generic(self, views, y=None, **fit_params):
         import sklearn.model_selection as skms
+
+        if _dist.is_sharded():
+            # scikit-learn would fit and score this rank's shard only: every rank a different, non-global cv_results_
+            raise NotImplementedError(
+                "GridSearchCV inside row_sharded() needs the shared-moments route (default scoring, no fit_params, an "
+                "rCCA/CCA/PLS/MCCA/GCCA estimator and a splitter whose test sets partition the rows); this "
+                "configuration would search each rank's local shard separately")
 
         arrays = [v.detach().cpu().numpy() if type(v).__module__.startswith("torch") else np.asarray(v) for v in views]
         widths = tuple(int(a.shape[1]) for a in arrays)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CCZ_VERSION 100 /* 0.1.0 */
+#define CCZ_VERSION 110 /* 0.1.1 */
 
 #if defined(__GNUC__)
 #define CCZ_API __attribute__((visibility("default")))
@@ -114,6 +114,12 @@ CCZ_API int ccz_moments_subset(ccz_handle h, const double* moments_dev, int64_t 
 /* kernel timing of the last ccz_moments call on this handle (HIP events on the
  * handle's stream): milliseconds of the Gram kernel(s) and of the column-sum pass */
 CCZ_API int ccz_moments_last_ms(ccz_handle h, double* gram_ms, double* colsum_ms);
+/* fp32 views whose column means are large against their spread (max_j |mean_j| / std_j > 2, read off the column
+ * sums and sums of squares that K1 forms first) are multiplied as (x - p)(x - p)' with the pilot p = fl32(mean of
+ * the launch's rows) subtracted while staging, and the shift is undone on the d x d side in fp64 -- the reference
+ * centres before any product (_base.py:97-99) and raw fp32 products would cancel catastrophically.  *used = 1 if
+ * the last ccz_moments launch on this handle took that path. */
+CCZ_API int ccz_moments_last_pilot(ccz_handle h, int* used);
 
 /* ---- fused solves on reduced moments (replicated after the all-reduce) ----
  * Inputs: moments (device; only the upper triangle of G is read, so no symmetrisation is
@@ -188,12 +194,52 @@ CCZ_API int ccz_cca_loss(ccz_handle h, int dtype, const void* z1_dev, const void
 CCZ_API int ccz_cca_loss_moments(ccz_handle h, const double* moments_dev, int64_t n_rows, int64_t d1, int64_t d2,
                                  double eps, double* loss_host, double* gamma_dev, double* mean_dev);
 
+/* Sum over all pairs a < b of the CCA loss of views a and b -- MCCALoss, cca_zoo/deep/objectives.py:138-153, which
+ * re-centres every view and recomputes its S_aa^-1/2 once per PAIR -- from ONE set of batch moments of [z_1 .. z_m]
+ * with ONE Cholesky + inverse per VIEW.  Outputs as ccz_cca_loss_moments (n_views = 2 is that entry). */
+CCZ_API int ccz_pair_loss_moments(ccz_handle h, const double* moments_dev, int64_t n_rows, const int64_t* dims,
+                                  int n_views, double eps, double* loss_host, double* gamma_dev, double* mean_dev);
+
+/* MAX-VAR GCCA loss of a batch from its moments (ccz_moments over [z_1 .. z_m], summed over the ranks when the
+ * batch is row-sharded): loss = -(n-1) sum of the top-k generalised eigenvalues of  C u = lam B u  with C the
+ * centred covariance of the stacked views and B = blockdiag(C_ii) + eps I -- the non-zero spectrum of the
+ * reference's n x n matrix sum_i H_i H_i' -- and, if gamma_dev != NULL, the D x D matrix Gamma and the batch mean
+ * (D) with  [dz_1 .. dz_m] = ([z_1 .. z_m] - 1 mean') Gamma  (apply with ccz_transform).  All D x D work stays on
+ * the device.  cca_zoo/deep/objectives.py:155-220 (GCCALoss.forward) + its autograd backward. */
+CCZ_API int ccz_gcca_loss_moments(ccz_handle h, const double* moments_dev, int64_t n_rows, const int64_t* dims,
+                                  int n_views, double eps, int k, double* loss_host, double* gamma_dev,
+                                  double* mean_dev);
+
 /* ---- transform / score -------------------------------
  * out (n x k, dtype) = (X - mean) W ; X,out device; mean (d), W (d x k) device float64.
  * _base.py:108-123 */
 CCZ_API int ccz_transform(ccz_handle h, int dtype, const void* X_dev, int64_t n, int64_t d, int64_t ld,
                   const double* mean_dev, const double* W_dev, int64_t k, void* out_dev,
                   int64_t ldo);
+
+/* Batched Cholesky factor + triangular inverse (building block of the loss and of the blocked solves; exported
+ * for tests): `count` <= 8 SPD matrices A_dev[b] (d[b] x d[b], ld d[b], destroyed), L_dev[b] <- lower factor (the
+ * part above the diagonal is left untouched), X_dev[b] <- L^-1 (lower; blocks of 64 columns strictly above the
+ * diagonal blocks are left untouched -- zero X first if they are read).  X_dev may be NULL (factor only).  All matrices
+ * advance together, d_max / 64 + 1 launches in total.  Pointer arrays are HOST arrays of device pointers.
+ * torch.linalg.eigh + clamp + V diag(L^-1/2) V' in _inv_sqrtm, deep/objectives.py:9-21, as used by :94-97 */
+CCZ_API int ccz_cholinv(ccz_handle h, int count, double* const* A_dev, const int64_t* d, double* const* L_dev,
+                        double* const* X_dev);
+
+/* Counter-based standard normals written straight into HBM (the at-scale JointData inputs):
+ *   out[r][c] = (accumulate ? out[r][c] : 0) + scale * N(seed, (row0 + r) * row_stride + c)
+ * with N(seed, i) a pure function of its arguments (csrc/rng_hash.h::hash_normal_pair; NumPy restatement in
+ * oracle/rng.py), so any row range can be regenerated anywhere.  row_stride even and >= cols; dtype CCZ_F32 / CCZ_F64.
+ * cca_zoo/datasets/_simulated.py:116-130 (rng.standard_normal for z and the per-view noise) */
+CCZ_API int ccz_randn_fill(ccz_handle h, int dtype, void* out_dev, int64_t rows, int64_t cols, int64_t ld, uint64_t seed,
+                           int64_t row0, int64_t row_stride, double scale, int accumulate);
+
+/* Factor loadings of ONE view from its second moments (ccz_moments on that view alone, d x d + d):
+ * out (d x k, device, float64) = corr(feature j, variate t) = (C W)_jt / (std_x_j std_z_t) with C the centred
+ * covariance, std_z^2 = diag(W'CW), and the reference's guards max(std, 1e-12).  W (d x k) device float64.
+ * cca_zoo/_base.py:208-234 (get_factor_loadings: n x d x k products on the host) */
+CCZ_API int ccz_factor_loadings(ccz_handle h, const double* moments_dev, int64_t n_rows, int64_t d,
+                                const double* W_dev, int64_t k, double* out_dev);
 
 #ifdef __cplusplus
 }

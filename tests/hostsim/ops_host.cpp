@@ -30,6 +30,8 @@ void d2d(ccz_ctx*, void* d, const void* s, size_t n) { std::memmove(d, s, n); }
 void zero(ccz_ctx*, void* d, size_t n) { std::memset(d, 0, n); }
 void sync(ccz_ctx*) {}
 void activate(ccz_ctx*) {}
+int device_current() { return 0; }
+void device_set(int) {}
 
 void gemm(ccz_ctx*, bool tA, bool tB, int64_t M, int64_t N, int64_t K, double alpha, const double* A,
           int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc) {
@@ -247,6 +249,7 @@ int ccz_memcpy_h2d(ccz_handle, void* dst, const void* src, size_t bytes) { std::
 int ccz_memcpy_d2h(ccz_handle, void* dst, const void* src, size_t bytes) { std::memcpy(dst, src, bytes); return CCZ_OK; }
 int ccz_memset0(ccz_handle, void* dst, size_t bytes) { std::memset(dst, 0, bytes); return CCZ_OK; }
 int ccz_moments_last_ms(ccz_handle, double* g, double* s) { if (g) *g = 0.0; if (s) *s = 0.0; return CCZ_OK; }
+int ccz_moments_last_pilot(ccz_handle, int* used) { if (used) *used = 0; return CCZ_OK; }
 
 int ccz_moments(ccz_handle h, int dtype, const ccz_view* views, int n_views, int64_t n_rows, int /*on_device*/,
                 double* mom, int accumulate) {

@@ -42,10 +42,11 @@ def _worker(rank, world, port, q):
         views = rf.joint_data(2, 301, 3, [12, 9], 2.0, 5)       # same data on every rank
         lo, hi = _dist.shard_bounds(301, rank, world)
         G, s, n_loc = gf.moments([v[lo:hi] for v in views])
-        mom = torch.from_numpy(np.concatenate([G.ravel(), s]))
+        buf = torch.from_numpy(np.concatenate([G.ravel(), s, [float(n_loc)]]))     # row count in the tail slot
         with _dist.row_sharded():
             assert _dist.is_sharded()
-            n_tot = _dist.allreduce_moments(mom, n_loc, _dist.active_group())
+            n_tot = _dist.allreduce_moments(buf, _dist.active_group())
+        mom = buf[:-1]
         assert not _dist.is_sharded()
         H = hostsim_handle()
         W, means, vals = H.rcca_solve(mom.numpy(), n_tot, [12, 9], [0.1, 0.1], True, 3)
