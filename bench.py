@@ -5,11 +5,16 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one full ``CCA(latent_dimensions=64).fit(views)`` on synthetic latent-variable
-views already resident in HBM (JointData model): K1 Gram + column sums on
-the MFMA pipe, (N > 1) one RCCL all-reduce of the packed moments, replicated device solves,
-weights back on the host.  With N ranks the n rows are split contiguously across the ranks
-(total work fixed -> "scaling": "strong").  Rank 0 prints ONE JSON line.
+A "step" is one full ``CCA(latent_dimensions=64).fit(views)`` on synthetic latent-variable views already resident
+in HBM (JointData model): column sums + K1 Gram on the MFMA pipe, (N > 1) one RCCL all-reduce of the
+packed moments, the device solves, weights back on the host.  With N ranks the n rows of ONE data set are split
+contiguously across the ranks (``sample_device(row0=...)``: the data do not depend on N; total work fixed ->
+"scaling": "strong").  Rank 0 prints ONE JSON line.
+
+Parity gate: before anything is printed the fitted model is checked on the very views that were timed
+(``check_fit_properties``): rows regenerated on the host by the NumPy restatement of the generator, K1 against a
+float64 Gram of those rows, and the size-independent properties of a CCA solution on all n rows.  A failed gate
+aborts the run (no JSON line).
 """
 
 from __future__ import annotations
@@ -24,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}   # dense MFMA peaks, MI355X_MICROARCH.md / datasheet
+DATA_SEED = 20260
 
 
 def parse():
@@ -36,48 +42,174 @@ def parse():
     ap.add_argument("--k", type=int, default=64)
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra configurations (C2, C3, C5, f64, losses, grid search)")
     ap.add_argument("--no-dcca", action="store_true")
     ap.add_argument("--with-sharded-dcca", action="store_true",
                     help="N > 1 only: also time CCALoss fwd+bwd on the batch sharded over the ranks (extra collectives "
                          "after the timed fits; off by default so that nothing can delay the headline result)")
-    ap.add_argument("--cpu-sample-rows", type=int, default=2048)
+    ap.add_argument("--cpu-sample-rows", type=int, default=16384)
     return ap.parse_args()
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# parity gate
+# ---------------------------------------------------------------------------------------------------------------
+def check_fit_properties(model, views, jd, seed, row0=0, sharded=False, n_check=2048):
+    """Is ``model`` (a c = 0 CCA / rCCA fitted on ``views``) a CCA solution of THESE views?
+
+    * generator: rows regenerated on the host (``oracle.rng``, the NumPy restatement) equal the device rows;
+    * K1: the device moments of the first ``n_check`` local rows agree with the float64 Gram of the regenerated rows;
+    * solution (all rows; global under ``sharded``): every canonical variate has unit variance (w'C w = 1), the
+      variates of a view are uncorrelated, the cross-view correlation matrix is diag(singular values), the training
+      score equals the singular values, and those are non-increasing in (0, 1].
+    Returns a dict with ``ok`` and the measured deviations."""
+    import contextlib
+
+    import numpy as np
+
+    from cca_zoo_amd import _backend, row_sharded
+    from cca_zoo_amd._moments import compute_moments
+    from oracle import rng as orng
+
+    rep = {}
+    tol = 1e-3 if views[0].element_size() == 4 else 1e-5
+    ndt = np.float32 if views[0].element_size() == 4 else np.float64
+    n_local = int(views[0].shape[0])
+    m_rows = min(n_check, n_local)
+    host = orng.joint_data_rows(jd._weights, jd._snr_per_view, jd.latent_scales, seed=seed, row0=row0, rows=m_rows, dtype=ndt)
+    rep["generator_max_abs_diff"] = max(float(np.abs(v[:m_rows].cpu().numpy().astype(np.float64) - h.astype(np.float64)).max())
+                                        for v, h in zip(views, host))
+    ok = rep["generator_max_abs_diff"] < (1e-5 if ndt == np.float32 else 1e-10)
+    # K1 on the checked rows (never sharded: a local quantity)
+    h = _backend.handle_for(views)
+    from cca_zoo_amd import _dist
+
+    with _dist.unsharded():
+        mom, keep, _, dims, _ = compute_moments([v[:m_rows] for v in views], h)
+    D = int(sum(dims))
+    flat = h.to_host(mom, (D * D + D,))
+    del keep
+    X = np.hstack([v.astype(np.float64) for v in host])
+    iu = np.triu_indices(D)
+    Gref = X.T @ X
+    scale = np.sqrt(np.outer(np.diag(Gref), np.diag(Gref)))[iu]
+    rep["k1_rel_err"] = float((np.abs(flat[:D * D].reshape(D, D)[iu] - Gref[iu]) / scale).max())
+    ok = ok and rep["k1_rel_err"] < (2e-5 if ndt == np.float32 else 1e-12)
+    # the solution on all rows
+    ctx = row_sharded() if sharded else contextlib.nullcontext()
+    with ctx:
+        zs = model.transform(views)
+        k = int(zs[0].shape[1])
+        momz, keepz, n_tot, _, _ = compute_moments(zs, h)
+        K2 = len(zs) * k
+        h.moments_symmetrize(momz, K2)
+        fz = h.to_host(momz, (K2 * K2 + K2,))
+        del keepz
+        score = model.score(views)
+    Gz, sz = fz[:K2 * K2].reshape(K2, K2), fz[K2 * K2:]
+    Cz = (Gz - np.outer(sz, sz) / n_tot) / (n_tot - 1)
+    sv = np.asarray(model.singular_values_, dtype=np.float64)
+    rep["unit_variance_dev"] = float(np.abs(np.diag(Cz) - 1.0).max())
+    within = max(float(np.abs(Cz[i * k:(i + 1) * k, i * k:(i + 1) * k] - np.eye(k)).max()) for i in range(len(zs)))
+    rep["within_view_corr_dev"] = within
+    rep["cross_view_dev"] = float(np.abs(Cz[:k, k:2 * k] - np.diag(sv)).max())
+    rep["score_vs_singular_values"] = float(np.abs(np.asarray(score, dtype=np.float64) - sv).max())
+    rep["singular_values"] = [float(sv[0]), float(sv[-1])]
+    ok = ok and rep["unit_variance_dev"] < 3 * tol and within < 3 * tol and rep["cross_view_dev"] < 3 * tol
+    ok = ok and rep["score_vs_singular_values"] < 3 * tol and bool(np.all(np.diff(sv) <= 1e-9)) and 0.0 < sv[-1] and sv[0] <= 1.0 + 1e-9
+    rep["ok"] = bool(ok)
+    return rep
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CPU comparators (reference-structured NumPy / torch paths, bounded samples)
+# ---------------------------------------------------------------------------------------------------------------
+def host_cores():
+    """CPUs this process may actually use: scheduler affinity capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()
+            if q != "max":
+                quota = float(q) / float(p)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / p
+        except Exception:
+            pass
+    return n, quota
+
+
 def cpu_baseline(n_full, d, k, sample_rows):
-    """Reference-structured NumPy path (thin SVD of each n x d view, oracle.reference_form) on a
-    bounded row sample of the same workload, extrapolated linearly in n.  The thin SVD costs O(n d^2)
-    for n >= d and less per row below that, so a sample shorter than d UNDER-estimates the CPU time:
-    the reported CPU rate is an upper bound (in the CPU's favour)."""
+    """``oracle.reference_form.rcca_weights`` -- the reference's structure (thin SVD of each centred n x d view,
+    cca_zoo/linear/_rcca.py:92-100) -- on ``sample_rows`` >= 4 d rows of the same kind of data (the tall regime the
+    full problem is in), median of up to three runs; ``value`` is the linear-in-n extrapolation of the measured time
+    (the thin SVD is O(n d^2)), reported next to the measurement itself."""
     import numpy as np
 
     from oracle import reference_form as rf
 
+    affinity, quota = host_cores()
+    threads = None
     try:
         from threadpoolctl import threadpool_info
 
         threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:
-        threads = os.cpu_count() or 1
+        pass
+    cores = int(min(affinity, quota)) if quota else affinity
     views = rf.joint_data(2, sample_rows, k, [d, d], 1.0, 0)
     views = [v.astype(np.float32) for v in views]
-    t0 = time.perf_counter()
-    rf.rcca_weights(views, k, c=0.0)
-    dt = time.perf_counter() - t0
-    full = dt * (n_full / sample_rows)
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        rf.rcca_weights(views, k, c=0.0)
+        times.append(time.perf_counter() - t0)
+        if times[0] > 15.0:        # bounded: a single run already took its share of the bench's wall-clock
+            break
+    med = float(np.median(times))
+    full = med * (n_full / sample_rows)
     return {
-        "value": 1.0 / full, "unit": "fit/s", "cores": int(threads), "kind": "port",
-        "sample": (f"oracle.reference_form.rcca_weights (thin SVD per view, as cca_zoo/linear/_rcca.py) on "
-                   f"{sample_rows} of {n_full} rows, 2x{d} fp32, k={k}: {dt:.2f} s measured; value = 1/(t * n/n_sample) "
-                   f"(linear extrapolation; for n_sample < d it under-estimates the CPU time, i.e. favours the CPU); "
-                   f"host has {os.cpu_count()} logical cores"),
-        "measured_s": dt,
+        "value": 1.0 / full, "unit": "fit/s (extrapolated linearly in n from the measured sample)", "cores": max(cores, 1), "kind": "port",
+        "sample": (f"oracle.reference_form.rcca_weights (thin SVD per view, as cca_zoo/linear/_rcca.py:92-100) on "
+                   f"{sample_rows} rows (>= 4 d) of 2x{d} fp32 JointData, k={k}"),
+        "measured_s": med, "runs_s": [round(t, 3) for t in times], "sample_rows": sample_rows,
+        "extrapolated_full_s": full, "extrapolation": f"measured_s * {n_full}/{sample_rows} (O(n d^2) thin SVD)",
+        "blas_threads": threads, "sched_affinity": affinity, "cgroup_cpu_quota": quota, "logical_cpus": os.cpu_count(),
     }
 
 
+def cpu_loss_baseline(batch=8192, d=512):
+    """The reference's own CCALoss (oracle.losses.cca_loss_autograd: torch eigh + autograd, deep/objectives.py:61-102)
+    forward + backward on the host, BASELINE configs[3] shape, median of three."""
+    import numpy as np
+    import torch
+
+    from oracle import losses as ol
+
+    torch.manual_seed(0)
+    z1 = torch.randn(batch, d, requires_grad=True)
+    z2 = (0.5 * z1.detach() + torch.randn(batch, d)).requires_grad_(True)
+    times = []
+    for _ in range(3):
+        z1.grad = z2.grad = None
+        t0 = time.perf_counter()
+        ol.cca_loss_autograd(z1, z2, 1e-6).backward()
+        times.append(time.perf_counter() - t0)
+    return {"metric": f"CPU CCALoss fwd+bwd (torch eigh autograd, batch {batch}, 2x{d}, fp32)", "ms": float(np.median(times)) * 1e3,
+            "value": 1.0 / float(np.median(times)), "torch_threads": torch.get_num_threads()}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# extras (N = 1): the other BASELINE configurations and the second half of the metric
+# ---------------------------------------------------------------------------------------------------------------
 def dcca_extra(steps=20, warmup=3, batch=8192, d=512, label="BASELINE configs[3]"):
-    """CCALoss forward + backward (ccz_cca_loss through the autograd Function), fp32 embeddings resident in HBM.
-    Called twice: configs[3] (batch 8192, 2 x 512) and the metric's own shape (n = 1e6, d = 4096)."""
+    """CCALoss forward + backward (ccz_cca_loss through the autograd Function), fp32 embeddings resident in HBM."""
+    import numpy as np
     import torch
 
     from cca_zoo_amd.deep.objectives import CCALoss
@@ -91,17 +223,79 @@ def dcca_extra(steps=20, warmup=3, batch=8192, d=512, label="BASELINE configs[3]
     for _ in range(warmup):
         obj([z1, z2]).backward()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    ts = []
     for _ in range(steps):
         z1.grad = None
         z2.grad = None
+        t0 = time.perf_counter()
         obj([z1, z2]).backward()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    # forward Gram n D (D + 1) with D = 2 d, backward two (n x 2d) @ (2d x d) products
-    flops = float(batch) * (2 * d) * (2 * d + 1) + 2.0 * 2.0 * batch * (2 * d) * d
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    dt = float(np.median(ts))
+    # forward Gram n D (D + 1) with D = 2 d, backward (n x 2d) @ (2d x 2d)
+    flops = float(batch) * (2 * d) * (2 * d + 1) + 2.0 * batch * (2 * d) * (2 * d)
     return {"metric": f"DCCA CCALoss fwd+bwd/sec (batch {batch}, 2x{d}, fp32; {label})", "value": 1.0 / dt, "ms": dt * 1e3,
-            "tflops": flops / dt / 1e12}
+            "ms_min": float(min(ts)) * 1e3, "tflops": flops / dt / 1e12, "flop": flops,
+            "roofline": {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": PEAK_TFLOPS["f32"], "unit": "TFLOP/s",
+                         "frac": flops / dt / 1e12 / PEAK_TFLOPS["f32"],
+                         "note": "algorithmic flops of the whole fwd+bwd (K1 + gradient GEMM) over its wall time"}}
+
+
+def timed_fit(make_model, views, runs):
+    import numpy as np
+    import torch
+
+    ts, last = [], None
+    for _ in range(runs + 1):            # first run warms allocator pools / code objects and is dropped
+        t0 = time.perf_counter()
+        last = make_model().fit(views)
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    return float(np.median(ts[1:])), last
+
+
+def config_extras(info):
+    """BASELINE configs[1], [2] and [4] (the last at the largest n one GPU holds) and the metric shape in float64:
+    fit time, K1 rate, solve time.  Each configuration draws its own views and frees them."""
+    import numpy as np
+    import torch
+
+    from cca_zoo_amd import _backend
+    from cca_zoo_amd.datasets import JointData
+    from cca_zoo_amd.linear import CCA, GCCA, MCCA, rCCA
+
+    h = _backend.default_handle()
+    out = {}
+
+    def run(tag, label, dims, n, k, tdt, make_model, runs=2):
+        free, _ = torch.cuda.mem_get_info()
+        need = n * sum(dims) * (4 if tdt == torch.float32 else 8)
+        if need * 1.15 > free:
+            out[tag] = {"config": label, "skipped": f"needs {need / 1e9:.0f} GB of HBM, {free / 1e9:.0f} GB free"}
+            return
+        jd = JointData(n_views=len(dims), n_samples=1, latent_dimensions=k, n_features=list(dims), random_state=1,
+                       latent_scales=list(np.linspace(2.0, 0.5, k)))
+        views = jd.sample_device(device="cuda", dtype=tdt, n_samples=n, seed=DATA_SEED + 1)
+        ms, model = timed_fit(make_model, views, runs)
+        g_ms = h.moments_last_ms()[0]
+        D = sum(dims)
+        flop = float(n) * D * (D + 1)
+        kind = "f32" if tdt == torch.float32 else "f64"
+        out[tag] = {"config": label, "fit_ms": ms, "fits_per_s": 1e3 / ms, "gram_ms": g_ms, "solve_ms": model.timings_["solve_ms"],
+                    "gram_tflops": flop / (g_ms * 1e-3) / 1e12, "gram_frac_of_peak": flop / (g_ms * 1e-3) / 1e12 / PEAK_TFLOPS[kind],
+                    "dtype": kind, "n": n, "score_top": float(np.asarray(model.score(views))[0])}
+        del views, model
+        torch.cuda.empty_cache()
+
+    run("c2_rcca", "configs[1]: rCCA n=100k, 2x1024, k=32, float32", (1024, 1024), 100_000, 32, torch.float32,
+        lambda: rCCA(latent_dimensions=32, c=0.1), runs=5)
+    run("c3_mcca", "configs[2]: MCCA 4x2048, n=1e6, k=64, float32 (one GPU holds all rows)", (2048,) * 4, 1_000_000, 64,
+        torch.float32, lambda: MCCA(latent_dimensions=64))
+    run("ns_f64", "metric shape in float64: CCA n=1e6, 2x4096, k=64", (4096, 4096), 1_000_000, 64, torch.float64,
+        lambda: CCA(latent_dimensions=64))
+    run("c5_gcca", "configs[4] at the largest n one GPU holds: GCCA d=[4096,4096,8192], n=1e6 (of 2e6), k=128, float64",
+        (4096, 4096, 8192), 1_000_000, 128, torch.float64, lambda: GCCA(latent_dimensions=128))
+    return out
 
 
 def sharded_dcca_extra(n_local, d, world, steps=2, warmup=1):
@@ -159,6 +353,25 @@ def grid_extra(views, k, fit_ms):
             "best_score": gs.best_score_}
 
 
+def gram_traffic(dtype, D, n_local):
+    """HBM / fabric bytes of one K1 launch from the newest committed PMC pass for this dtype and width (FETCH_SIZE x 2
+    gfx950 correction + WRITE_SIZE per row, measured at a smaller n on the same kernel and shape; linear in the rows)."""
+    import glob
+
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gram_traffic*.json"))):
+        try:
+            with open(path) as f:
+                tj = json.load(f)
+        except Exception:
+            continue
+        if tj.get("D") == D and tj.get("dtype", "f32") == dtype:
+            best = (tj, os.path.basename(path))
+    if best is None:
+        return None, None
+    return best[0]["bytes_per_row"] * n_local, f"profiles/{best[1]} (PMC pass at n={best[0].get('n')}, scaled by rows)"
+
+
 def main():
     a = parse()
     import numpy as np
@@ -191,7 +404,8 @@ def main():
     tdt = torch.float32 if a.dtype == "f32" else torch.float64
     jd = JointData(n_views=2, n_samples=a.n, latent_dimensions=a.k, n_features=[a.d, a.d],
                    signal_to_noise=1.0, random_state=0, latent_scales=list(np.linspace(2.0, 0.5, a.k)))
-    views = jd.sample_device(device=f"cuda:{local}", dtype=tdt, n_samples=n_local, seed=1000 + rank)
+    # ONE global data set: this rank draws rows [lo, hi) of it, whatever the number of ranks
+    views = jd.sample_device(device=f"cuda:{local}", dtype=tdt, n_samples=n_local, seed=DATA_SEED, row0=lo)
     torch.cuda.synchronize()
     model = CCA(latent_dimensions=a.k)
 
@@ -202,7 +416,7 @@ def main():
         else:
             model.fit(views)
 
-    gram_ms = []
+    gram_ms, colsum_ms, solve_ms, allreduce_ms = [], [], [], []
     # Process warm-up that is not a property of the step: allocator pools, code-object loads and whatever else makes
     # the first two or three fits of a process 15-30 ms slower.  Two untimed fits during set-up, in
     # addition to the W warm-up steps the caller asks for; reported as config.setup_fits.
@@ -216,7 +430,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     # interpreter housekeeping out of the timed region, as timeit does: a generation-2 collection of the
-    # (large, sklearn + torch) heap costs ~30 ms and used to land in the second timed step
+    # (large, sklearn + torch) heap costs ~30 ms and used to land in a timed step
     import gc
 
     gc.collect()
@@ -226,7 +440,11 @@ def main():
     for _ in range(a.steps):
         ts = time.perf_counter()
         step()
-        gram_ms.append(h.moments_last_ms()[0])
+        g, cs = h.moments_last_ms()
+        gram_ms.append(g)
+        colsum_ms.append(cs)
+        solve_ms.append(model.timings_["solve_ms"])
+        allreduce_ms.append(model.timings_["allreduce_ms"])
         step_ms.append((time.perf_counter() - ts) * 1e3)
     torch.cuda.synchronize()
     if distributed:
@@ -239,6 +457,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / a.steps * 1e3
+
+    # ---- parity gate on the views that were timed (every rank takes part: transform / score all-reduce) ----
+    gate = check_fit_properties(model, views, jd, seed=DATA_SEED, row0=lo, sharded=distributed)
+    if not gate["ok"]:
+        sys.stderr.write("bench.py: PARITY GATE FAILED on the timed model: " + json.dumps(gate) + "\n")
+        if distributed:
+            dist.destroy_process_group()
+        sys.exit(3)
 
     sharded_loss_s = None
     if distributed and (a.with_sharded_dcca or os.environ.get("CCZ_BENCH_FORCE_SHARDED")) and 8.0 * n_local * a.d * 4 < 150e9:
@@ -253,47 +479,54 @@ def main():
         g_ms = float(np.mean(gram_ms))
         achieved = flop / (g_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[a.dtype]
-        # HBM/fabric bytes per launch from the committed PMC pass (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
-        # profiles/r01_e_gram_pmc.md), measured at n=262144 on the same kernel/shape and linear in the rows
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_e_gram_traffic.json")) as f:
-                tj = json.load(f)
-            if a.dtype == "f32" and tj.get("D") == D:
-                traffic = tj["bytes_per_row"] * n_local
-        except Exception:
-            traffic = None
+        traffic, traffic_src = gram_traffic(a.dtype, D, n_local)
         out = {
             "metric": "CCA fit()/sec at n=1e6 d=4096 k=64",
             "value": 1e3 / ms_per_step, "unit": "fit/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
             "step_ms": [round(x, 2) for x in step_ms],
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": a.dtype, "data": "synthetic (JointData latent-variable model, generated in HBM)",
+            "dtype": a.dtype, "data": "synthetic (JointData latent-variable model, counter-based generator, drawn in HBM)",
             "config": {"workload": f"CCA(latent_dimensions={a.k}).fit on JointData n={a.n}, 2 views x {a.d}, {a.dtype}; "
-                                   f"rows sharded over {world} GPU(s)", "n": a.n, "d": a.d, "k": a.k, "setup_fits": 2,
+                                   f"rows sharded over {world} GPU(s)", "n": a.n, "d": a.d, "k": a.k, "setup_fits": SETUP_FITS,
                        "device": info["name"], "arch": info["arch"], "compute_units": info["compute_units"]},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic,
-                         "traffic_source": "profiles/r01_e_gram_pmc.md (PMC pass at n=262144, scaled by rows)" if traffic else None,
+                         "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_gram_f32_fifo" if a.dtype == "f32" else "k_gram_f64_fifo",
                          "kernel_ms": g_ms, "flop_per_launch": flop,
                          "bytes_per_launch": float(n_local) * D * (4 if a.dtype == "f32" else 8),
                          "gram_share_of_step": g_ms / ms_per_step},
+            "phases_ms": {"gram": g_ms, "colsum": float(np.mean(colsum_ms)), "allreduce": float(np.mean(allreduce_ms)),
+                          "solve": float(np.mean(solve_ms)), "solve_min": float(np.min(solve_ms))},
+            "parity_gate": gate,
         }
+        extra = {}
         if sharded_loss_s is not None:
-            out["extra"] = {"dcca_loss_metric_shape_sharded": {
+            extra["dcca_loss_metric_shape_sharded"] = {
                 "metric": f"DCCA CCALoss fwd+bwd/sec (batch {a.n} sharded over {world} GPUs, 2x{a.d}, fp32)",
-                "value": 1.0 / sharded_loss_s, "ms": sharded_loss_s * 1e3}}
-        if world == 1 and not a.no_dcca and views is not None:
-            out["extra"] = {"dcca_loss": dcca_extra(), "grid_search": grid_extra(views, a.k, ms_per_step)}
-            if a.n * a.d * 4 * 4 < 200e9:   # z1, z2 and their gradients must fit in HBM next to the views
-                del views
+                "value": 1.0 / sharded_loss_s, "ms": sharded_loss_s * 1e3}
+        if world == 1 and not a.no_extras and views is not None:
+            if not a.no_dcca:
+                extra["dcca_loss"] = dcca_extra()
+            extra["grid_search"] = grid_extra(views, a.k, ms_per_step)
+            del views
+            views = None
+            torch.cuda.empty_cache()
+            if not a.no_dcca and a.n * a.d * 4 * 4 < 200e9:   # z1, z2 and their gradients must fit in HBM
+                extra["dcca_loss_metric_shape"] = dcca_extra(steps=3, warmup=1, batch=a.n, d=a.d, label="metric shape")
                 torch.cuda.empty_cache()
-                out["extra"]["dcca_loss_metric_shape"] = dcca_extra(steps=2, warmup=1, batch=a.n, d=a.d, label="metric shape")
-        # last: its 64 OpenBLAS threads keep spinning for a while and would slow the launch chains of the GPU extras
+            extra["configs"] = config_extras(info)
+        if extra:
+            out["extra"] = extra
+        if "dcca_loss_metric_shape" in extra:
+            # the second half of BASELINE's metric, first-class next to the fit rate
+            out["dcca_loss_fwd_bwd_per_s"] = extra["dcca_loss_metric_shape"]["value"]
+            out["dcca_loss_roofline"] = extra["dcca_loss_metric_shape"]["roofline"]
+        # last: its BLAS threads keep spinning for a while and would slow the launch chains of the GPU extras
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.n, a.d, a.k, a.cpu_sample_rows)
+            if not a.no_extras:
+                out["cpu_baseline"]["dcca_loss_configs3"] = cpu_loss_baseline()
         line = json.dumps(out)
     else:
         line = None

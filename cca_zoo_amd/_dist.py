@@ -54,6 +54,18 @@ def row_sharded(group=None):
         _state.on, _state.group = prev
 
 
+@contextlib.contextmanager
+def unsharded():
+    """Inside ``row_sharded()``: treat the enclosed calls as purely local (no collective) -- e.g. a spot check of this
+    rank's own rows."""
+    prev = (getattr(_state, "on", False), getattr(_state, "group", None))
+    _state.on, _state.group = False, None
+    try:
+        yield
+    finally:
+        _state.on, _state.group = prev
+
+
 def allreduce_moments(buf, group=None):
     """SUM-reduce ``buf`` IN PLACE and return the global row count.
 

@@ -849,12 +849,19 @@ static void factor_loadings_impl(ccz_ctx* c, const double* mom, int64_t n, int64
   transpose(c, d, k, W, k, Wt, d);
   transpose(c, d, k, CW, k, CWt, d);
   row_dots(c, k, d, Wt, d, CWt, d, vt);                      // diag(W' C W)
-  std::vector<double> hx(d), ht(k);
+  std::vector<double> hx(d), ht(k), hg(d);
   d2h(c, hx.data(), vx, size_t(d) * 8);
   d2h(c, ht.data(), vt, size_t(k) * 8);
+  row_dots(c, d, 1, mom, d + 1, ones, 1, vx);                // diag(G): raw second moments
+  d2h(c, hg.data(), vx, size_t(d) * 8);
   std::vector<int64_t> perm(d);
   std::iota(perm.begin(), perm.end(), 0);
-  for (auto& v : hx) v = 1.0 / std::max(std::sqrt(std::max(v, 0.0)), 1e-12);
+  for (int64_t j = 0; j < d; ++j) {
+    // a feature that is constant up to the rounding of G - s s'/n has a centred column of exact zeros in the
+    // reference (covariance 0, loading 0 / 1e-12 = 0): give 0 instead of cancellation noise over 1e-12
+    const double noise = 256.0 * 2.220446049250313e-16 * std::fabs(hg[j]) / double(n - 1);
+    hx[j] = hx[j] <= noise ? 0.0 : 1.0 / std::max(std::sqrt(hx[j]), 1e-12);
+  }
   for (auto& v : ht) v = std::max(std::sqrt(std::max(v, 0.0)), 1e-12);
   DBuf td(c, k);
   h2d(c, td, ht.data(), size_t(k) * 8);

@@ -19,11 +19,12 @@ same device moments.
 
 from __future__ import annotations
 
+import time
 from typing import Any, ClassVar
 
 import numpy as np
 
-from cca_zoo_amd import _backend
+from cca_zoo_amd import _backend, _moments
 from cca_zoo_amd._base import BaseModel
 from cca_zoo_amd._moments import compute_moments
 from cca_zoo_amd._utils._param_constraints import POSITIVE_EPS, RIDGE_PARAMETER
@@ -64,9 +65,14 @@ class MCCA(BaseModel):
     def fit(self, views, y=None):
         views_ = self._setup_fit(views)
         h = _backend.handle_for(views_)
+        t0 = time.perf_counter()
         mom, keep, n_total, dims, kind = compute_moments(views_, h)
+        t1 = time.perf_counter()
         self.n_samples_ = int(n_total)            # inside row_sharded(): the global row count
         self._fit_moments(h, mom, n_total, dims, kind)
+        # wall-clock split of this fit (K1 incl. the all-reduce | the d x d solve incl. the copy of the weights to the host)
+        self.timings_ = {"moments_ms": (t1 - t0) * 1e3, "allreduce_ms": _moments.LAST["allreduce_ms"],
+                         "solve_ms": (time.perf_counter() - t1) * 1e3}
         del keep
         return self
 

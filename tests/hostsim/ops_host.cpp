@@ -249,6 +249,22 @@ int ccz_memcpy_h2d(ccz_handle, void* dst, const void* src, size_t bytes) { std::
 int ccz_memcpy_d2h(ccz_handle, void* dst, const void* src, size_t bytes) { std::memcpy(dst, src, bytes); return CCZ_OK; }
 int ccz_memset0(ccz_handle, void* dst, size_t bytes) { std::memset(dst, 0, bytes); return CCZ_OK; }
 int ccz_moments_last_ms(ccz_handle, double* g, double* s) { if (g) *g = 0.0; if (s) *s = 0.0; return CCZ_OK; }
+// the generator of JointData.sample_device, on the host (rng_hash.h is shared with the device kernel)
+int ccz_randn_fill(ccz_handle, int dtype, void* out, int64_t rows, int64_t cols, int64_t ld, uint64_t seed, int64_t row0,
+                   int64_t row_stride, double scale, int accumulate) {
+  if (!out || cols < 1 || ld < cols || row_stride < cols || (row_stride & 1)) return CCZ_EINVAL;
+  for (int64_t r = 0; r < rows; ++r)
+    for (int64_t q = 0; 2 * q < cols; ++q) {
+      double n0, n1;
+      ccz::hash_normal_pair(seed, (uint64_t(row0 + r) * uint64_t(row_stride)) / 2 + uint64_t(q), n0, n1);
+      for (int e = 0; e < 2 && 2 * q + e < cols; ++e) {
+        const double v = scale * (e ? n1 : n0);
+        if (dtype == CCZ_F32) { float* p = static_cast<float*>(out) + r * ld + 2 * q + e; *p = float((accumulate ? double(*p) : 0.0) + v); }
+        else { double* p = static_cast<double*>(out) + r * ld + 2 * q + e; *p = (accumulate ? *p : 0.0) + v; }
+      }
+    }
+  return CCZ_OK;
+}
 int ccz_moments_last_pilot(ccz_handle, int* used) { if (used) *used = 0; return CCZ_OK; }
 
 int ccz_moments(ccz_handle h, int dtype, const ccz_view* views, int n_views, int64_t n_rows, int /*on_device*/,

@@ -1,0 +1,541 @@
+"""GPU parity, round 2: the building blocks added this round (batched Cholesky + inverse, batched GEMM, pilot-mean
+K1, counter-based generator, device loadings / GCCALoss) and the BASELINE shapes that had no GPU test:
+NS (2 x 4096, k = 64, fp32), C3 (MCCA 4 x 2048, k = 64), C5 (GCCA [4096, 4096, 8192], k = 128, fp64), plus the
+recursive Cholesky / TRSM paths (d >= 6144) and split-K GEMM shapes.
+
+Bars: 1e-5 relative (fp64 inputs) / 1e-3 (fp32 inputs), sign-aligned per column (BASELINE.json north_star).
+"""
+
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import col_rel_err, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def H():
+    from cca_zoo_amd import _backend
+
+    return _backend.default_handle(0)
+
+
+def _spd(rng, d, cond=1e3):
+    q, _ = np.linalg.qr(rng.standard_normal((d, d)))
+    lam = np.geomspace(1.0, 1.0 / cond, d)
+    return (q * lam) @ q.T
+
+
+# ---------------------------------------------------------------------------------------------
+# cholinv.hip
+# ---------------------------------------------------------------------------------------------
+def _cholinv(H, mats, want_x=True):
+    bufs, ptrs_a, ptrs_l, ptrs_x = [], [], [], []
+    for A in mats:
+        d = A.shape[0]
+        a = H.to_device(A)
+        l = H.to_device(np.full((d, d), np.nan))
+        x = H.to_device(np.zeros((d, d)))
+        bufs.append((a, l, x))
+        ptrs_a.append(a.ptr)
+        ptrs_l.append(l.ptr)
+        ptrs_x.append(x.ptr)
+    n = len(mats)
+    arr = lambda p: (C.c_void_p * n)(*p)
+    dd = (C.c_int64 * n)(*[m.shape[0] for m in mats])
+    H.check(H.lib.ccz_cholinv(H.raw, n, arr(ptrs_a), dd, arr(ptrs_l), arr(ptrs_x) if want_x else None))
+    out = []
+    for (a, l, x), A in zip(bufs, mats):
+        d = A.shape[0]
+        out.append((H.to_host(l, (d, d)), H.to_host(x, (d, d))))
+    return out
+
+
+@pytest.mark.parametrize("d", [1, 5, 63, 64, 65, 128, 200, 512, 1000])
+def test_cholinv_single(H, d):
+    rng = np.random.default_rng(d)
+    A = _spd(rng, d)
+    (L, X), = _cholinv(H, [A])
+    Lr = np.linalg.cholesky(A)
+    assert np.abs(np.tril(L) - Lr).max() < 1e-11 * np.abs(Lr).max()
+    assert np.all(np.isnan(L[np.triu_indices(d, 1)]))            # strictly-upper part untouched
+    Xl = np.tril(X)
+    assert np.abs(Xl @ Lr - np.eye(d)).max() < 1e-9
+    # blocks strictly above the block diagonal were left at the zeros we put there
+    for bi in range(0, d, 64):
+        assert np.all(X[bi:bi + 64, bi + 64:] == 0.0)
+
+
+def test_cholinv_batched_mixed_sizes_and_failure(H):
+    rng = np.random.default_rng(7)
+    mats = [_spd(rng, d, 1e4) for d in (512, 70, 512, 1, 333, 64, 129, 200)]
+    for (L, X), A in zip(_cholinv(H, mats), mats):
+        Lr = np.linalg.cholesky(A)
+        assert np.abs(np.tril(L) - Lr).max() < 1e-10 * np.abs(Lr).max()
+        assert np.abs(np.tril(X) @ Lr - np.eye(A.shape[0])).max() < 1e-8
+    # factor only
+    (L, X), = _cholinv(H, [mats[0]], want_x=False)
+    assert np.abs(np.tril(L) - np.linalg.cholesky(mats[0])).max() < 1e-10 and np.all(X == 0.0)
+    # an indefinite matrix is reported, with the others in the batch unaffected up to that point
+    bad = mats[4].copy()
+    bad[150, 150] = -1.0
+    with pytest.raises(np.linalg.LinAlgError, match="not positive definite"):
+        _cholinv(H, [mats[1], bad])
+
+
+# ---------------------------------------------------------------------------------------------
+# fused pairwise loss core
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,d1,d2,dtype,tol", [
+    (300, 8, 8, "f64", 1e-9), (1000, 96, 40, "f64", 1e-9), (777, 130, 65, "f64", 1e-9), (2048, 256, 256, "f64", 1e-9),
+    (2048, 64, 64, "f32", 1e-3), (1000, 100, 37, "f32", 1e-3), (4096, 256, 512, "f32", 1e-3), (8192, 512, 512, "f32", 1e-3),
+])
+def test_cca_loss_fused_core_against_closed_form(n, d1, d2, dtype, tol):
+    """Forward + backward through the C ABI at fused-core shapes (single block, ragged blocks, the split-destination
+    FIFO gradient GEMM at 256-aligned widths) against oracle.losses.cca_loss_closed_form."""
+    import torch
+
+    from cca_zoo_amd.deep.objectives import CCALoss
+    from oracle import losses as ol
+
+    g = torch.Generator().manual_seed(n + d1)
+    tdt = torch.float64 if dtype == "f64" else torch.float32
+    z1 = torch.randn(n, d1, generator=g, dtype=torch.float64)
+    mix = torch.randn(d1, d2, generator=g, dtype=torch.float64) / np.sqrt(d1)
+    z2 = 0.7 * z1 @ mix + torch.randn(n, d2, generator=g, dtype=torch.float64) + 0.5
+    a = z1.to(tdt).cuda().requires_grad_(True)
+    b = z2.to(tdt).cuda().requires_grad_(True)
+    loss = CCALoss(eps=1e-5)([a, b])
+    loss.backward()
+    l, g1, g2 = ol.cca_loss_closed_form(a.detach().cpu().double().numpy(), b.detach().cpu().double().numpy(), 1e-5)
+    assert abs(loss.item() - l) <= tol * abs(l)
+    assert rel_err(a.grad.cpu().numpy(), g1) < tol * 10
+    assert rel_err(b.grad.cpu().numpy(), g2) < tol * 10
+    # forward only, and only one input requiring a gradient
+    assert abs(CCALoss(eps=1e-5)([a.detach(), b.detach()]).item() - l) <= tol * abs(l)
+    a2 = a.detach().clone().requires_grad_(True)
+    CCALoss(eps=1e-5)([a2, b.detach()]).backward()
+    assert rel_err(a2.grad.cpu().numpy(), g1) < tol * 10
+
+
+def test_cca_loss_strided_inputs_and_expanded_gradient():
+    """Row-strided inputs (a column slice of a wider tensor) and a backward whose incoming gradient is an expanded
+    scalar (ld < d used to be rejected)."""
+    import torch
+
+    from cca_zoo_amd.deep.objectives import CCALoss
+    from oracle import losses as ol
+
+    torch.manual_seed(3)
+    wide = torch.randn(600, 50, dtype=torch.float64, device="cuda")
+    a = wide[:, 3:23].detach().requires_grad_(True)           # stride (50, 1)
+    b = wide[:, 25:41].detach().requires_grad_(True)
+    (CCALoss(eps=1e-4)([a, b]) * 2.0).sum().backward()
+    l, g1, g2 = ol.cca_loss_closed_form(a.detach().cpu().numpy(), b.detach().cpu().numpy(), 1e-4)
+    assert rel_err(a.grad.cpu().numpy(), 2 * g1) < 1e-8 and rel_err(b.grad.cpu().numpy(), 2 * g2) < 1e-8
+
+
+def test_mcca_loss_one_pass_matches_pairwise_oracle():
+    """MCCALoss over 4 views of unequal widths: one K1 pass + one factorization per view == sum of the pairwise
+    closed-form losses (value and every view's gradient)."""
+    import torch
+
+    from cca_zoo_amd.deep.objectives import MCCALoss
+    from oracle import losses as ol
+
+    rng = np.random.default_rng(11)
+    n, dims = 900, (40, 70, 33, 64)
+    zlat = rng.standard_normal((n, 6))
+    zs = [zlat @ rng.standard_normal((6, d)) + rng.standard_normal((n, d)) + 0.2 for d in dims]
+    ts = [torch.tensor(z, device="cuda", requires_grad=True) for z in zs]
+    loss = MCCALoss(eps=1e-4)(ts)
+    loss.backward()
+    ref, grads = 0.0, [np.zeros_like(z) for z in zs]
+    for i in range(4):
+        for j in range(i + 1, 4):
+            l, gi, gj = ol.cca_loss_closed_form(zs[i], zs[j], 1e-4)
+            ref += l
+            grads[i] += gi
+            grads[j] += gj
+    assert abs(loss.item() - ref) < 1e-9 * abs(ref)
+    for t, gref in zip(ts, grads):
+        assert rel_err(t.grad.cpu().numpy(), gref) < 1e-8
+
+
+# ---------------------------------------------------------------------------------------------
+# pilot-mean K1 (fp32 views far from zero)
+# ---------------------------------------------------------------------------------------------
+def _offset_views(n, dims, k, offset_sigma, seed):
+    rng = np.random.default_rng(seed)
+    z = rng.standard_normal((n, k)) * np.linspace(2.0, 0.5, k)
+    views = []
+    for d in dims:
+        x = z @ rng.standard_normal((k, d)) + rng.standard_normal((n, d))
+        sd = x.std(axis=0)
+        views.append((x + offset_sigma * sd * rng.choice([-1.0, 1.0], size=d)).astype(np.float32))
+    return views
+
+
+def test_pilot_moments_match_fp64_at_mean_100_sigma(H):
+    """K1 on fp32 views with |mean| = 100 sigma: the centred covariance from the device moments agrees with the
+    fp64 covariance of the same (fp32-rounded) data to ~1e-5 of its scale (raw fp32 products: 5e-2)."""
+    import torch
+
+    from cca_zoo_amd._moments import compute_moments
+
+    n, d = 65536, 512
+    views = _offset_views(n, (d, d), 8, 100.0, 1)
+    tv = [torch.as_tensor(v, device="cuda") for v in views]
+    mom, keep, nt, dims, kind = compute_moments(tv, H)
+    assert kind == "f32" and H.moments_last_pilot()
+    D = 2 * d
+    H.moments_symmetrize(mom, D)
+    flat = H.to_host(mom, (D * D + D,))
+    G, s = flat[:D * D].reshape(D, D), flat[D * D:]
+    X = torch.cat([t.double() for t in tv], dim=1)
+    Cref = torch.cov(X.T).cpu().numpy()
+    Cdev = (G - np.outer(s, s) / n) / (n - 1)
+    scale = np.sqrt(np.outer(np.diag(Cref), np.diag(Cref)))
+    assert np.abs((Cdev - Cref) / scale).max() < 2e-5
+    np.testing.assert_allclose(s / n, X.mean(0).cpu().numpy(), rtol=1e-9)
+    # centred data keeps the FIFO kernel; host-resident offset data takes the pilot path chunk by chunk
+    zero_mean = [t - t.mean(0) for t in tv]
+    compute_moments(zero_mean, H)
+    assert not H.moments_last_pilot()
+    mom2, keep2, _, _, _ = compute_moments(views, H)
+    assert H.moments_last_pilot()
+    flat2 = H.to_host(mom2, (D * D + D,))
+    iu = np.triu_indices(D)
+    G2, s2 = flat2[:D * D].reshape(D, D), flat2[D * D:]
+    C2 = (G2[iu] - (np.outer(s2, s2) / n)[iu]) / (n - 1)
+    assert np.abs((C2 - Cref[iu]) / scale[iu]).max() < 2e-5
+
+
+def test_pilot_ragged_widths_and_short_tail(H):
+    """Unaligned widths / row counts go through the masked staging path: padded rows and columns must stay zero."""
+    import torch
+
+    from cca_zoo_amd._moments import compute_moments
+
+    for n, dims in ((1000, (37, 300)), (4099, (256, 129)), (65, (5, 3))):
+        views = _offset_views(n, dims, 3, 50.0, n)
+        tv = [torch.as_tensor(v, device="cuda") for v in views]
+        mom, keep, _, _, _ = compute_moments(tv, H)
+        assert H.moments_last_pilot()
+        D = sum(dims)
+        flat = H.to_host(mom, (D * D + D,))
+        G, s = flat[:D * D].reshape(D, D), flat[D * D:]
+        X = np.hstack(views).astype(np.float64)
+        iu = np.triu_indices(D)
+        Cref = np.cov(X, rowvar=False)
+        Cdev = ((G - np.outer(s, s) / n) / (n - 1))
+        scale = np.sqrt(np.outer(np.diag(Cref), np.diag(Cref)))
+        assert np.abs(((Cdev - Cref) / scale)[iu]).max() < 2e-5, (n, dims)
+        np.testing.assert_allclose(G[iu], (X.T @ X)[iu], rtol=1e-6)
+
+
+def test_fit_and_loss_with_offset_fp32_inputs():
+    """fp32, n = 65536, d = 2 x 512, mean = 100 sigma -- weights / score within 1e-3 of the fp64
+    oracle on the same data; CCALoss on offset embeddings within 1e-3 of the closed form."""
+    import torch
+
+    from cca_zoo_amd.deep.objectives import CCALoss
+    from cca_zoo_amd.linear import MCCA, rCCA
+    from oracle import gram_form as gf
+    from oracle import losses as ol
+
+    n, d, k = 65536, 512, 8
+    views = _offset_views(n, (d, d), k, 100.0, 2)
+    tv = [torch.as_tensor(v, device="cuda") for v in views]
+    X = torch.cat([t.double() for t in tv], dim=1)
+    G, s = (X.T @ X).cpu().numpy(), X.sum(0).cpu().numpy()
+    W, means, sv = gf.rcca_from_moments(G, s, n, [d, d], k, c=[0.1, 0.1])
+    m = rCCA(latent_dimensions=k, c=0.1).fit(tv)
+    for w, r in zip(m.weights_, W):
+        assert w.dtype == np.float32 and col_rel_err(w, r) < 1e-3
+    np.testing.assert_allclose(m.singular_values_, sv, rtol=1e-3)
+    for mu, r in zip(m.means_, means):
+        np.testing.assert_allclose(mu, r, rtol=1e-6)
+    Wm, _, lam = gf.mcca_from_moments(G, s, n, [d, d], k, c=[0.1, 0.1])
+    mm = MCCA(latent_dimensions=k, c=0.1).fit(tv)
+    for w, r in zip(mm.weights_, Wm):
+        assert col_rel_err(w, r) < 1e-3
+    # score on the training views == mean off-diagonal correlation of the oracle's variates
+    z = [(X[:, i * d:(i + 1) * d] - torch.as_tensor(means[i], device="cuda")) @ torch.as_tensor(W[i], device="cuda") for i in range(2)]
+    zc = [t - t.mean(0) for t in z]
+    ref = ((zc[0] * zc[1]).sum(0) / (zc[0].norm(dim=0) * zc[1].norm(dim=0))).cpu().numpy()
+    np.testing.assert_allclose(m.score(tv), ref, atol=1e-3)
+    # the loss on embeddings that sit far from zero (post-ReLU style)
+    a = tv[0][:8192, :256].contiguous().requires_grad_(True)
+    b = tv[1][:8192, :256].contiguous().requires_grad_(True)
+    loss = CCALoss(eps=1e-3)([a, b])
+    loss.backward()
+    l, g1, g2 = ol.cca_loss_closed_form(a.detach().cpu().double().numpy(), b.detach().cpu().double().numpy(), 1e-3)
+    assert abs(loss.item() - l) < 1e-3 * abs(l)
+    assert rel_err(a.grad.cpu().numpy(), g1) < 2e-3 and rel_err(b.grad.cpu().numpy(), g2) < 2e-3
+
+
+def test_offset_golden_from_the_reference():
+    """The same property against the real reference (tests/golden/offset_two_view_f32.npz, generated by
+    tools/gen_golden.py from cca_zoo itself on fp32 views with mean = 100 sigma, n = 4000)."""
+    import os
+
+    from conftest import GOLDEN, load_golden
+    from cca_zoo_amd.linear import CCA, rCCA
+
+    if not os.path.exists(os.path.join(GOLDEN, "offset_two_view_f32.npz")):
+        pytest.skip("golden not generated")
+    g = load_golden("offset_two_view_f32")
+    train = [g["train0"], g["train1"]]
+    assert train[0].dtype == np.float32
+    for tag, model in (("rcca_0.1", rCCA(latent_dimensions=4, c=0.1)), ("cca", CCA(latent_dimensions=4))):
+        model.fit(train)
+        for i, w in enumerate(model.weights_):
+            assert col_rel_err(w, g[f"{tag}/w{i}"].astype(np.float64)) < 1e-3, (tag, i)
+        np.testing.assert_allclose(model.score(train), g[f"{tag}/score_train"], atol=1e-3)
+
+
+# ---------------------------------------------------------------------------------------------
+# generator
+# ---------------------------------------------------------------------------------------------
+def test_sample_device_is_reproducible_on_the_host():
+    import torch
+
+    from cca_zoo_amd.datasets import JointData
+    from oracle import rng
+
+    jd = JointData(n_views=2, n_samples=50000, latent_dimensions=6, n_features=[300, 257], random_state=0,
+                   latent_scales=list(np.linspace(2.0, 0.5, 6)))
+    full = jd.sample_device(device="cuda", dtype=torch.float32, n_samples=50000, seed=7, row_chunk=16384)
+    for r0, rows in ((0, 64), (16380, 12), (49990, 10)):
+        ref = rng.joint_data_rows(jd._weights, jd._snr_per_view, jd.latent_scales, seed=7, row0=r0, rows=rows)
+        for v, r in zip(full, ref):
+            got = v[r0:r0 + rows].cpu().numpy()
+            np.testing.assert_allclose(got, r, rtol=2e-6, atol=2e-6)
+    # a shard drawn on its own (row0) equals the slice of the full draw, whatever the chunking
+    part = jd.sample_device(device="cuda", dtype=torch.float32, n_samples=5000, seed=7, row0=30000, row_chunk=777)
+    for v, p in zip(full, part):
+        assert torch.equal(v[30000:35000], p)
+    f64 = jd.sample_device(device="cuda", dtype=torch.float64, n_samples=100, seed=7, row0=5)
+    ref = rng.joint_data_rows(jd._weights, jd._snr_per_view, jd.latent_scales, seed=7, row0=5, rows=100, dtype=np.float64)
+    for v, r in zip(f64, ref):
+        np.testing.assert_allclose(v.cpu().numpy(), r, rtol=1e-11, atol=1e-12)
+
+
+# ---------------------------------------------------------------------------------------------
+# device-side loadings / GCCA padding
+# ---------------------------------------------------------------------------------------------
+def test_factor_loadings_on_device_tensors_and_gcca_padding():
+    import torch
+
+    from cca_zoo_amd.linear import GCCA, rCCA
+
+    rng = np.random.default_rng(2)
+    z = rng.standard_normal((5000, 3))
+    views = [(z @ rng.standard_normal((3, d)) + rng.standard_normal((5000, d)) + 3.0).astype(np.float32) for d in (300, 260)]
+    tv = [torch.as_tensor(v, device="cuda") for v in views]
+    m = rCCA(latent_dimensions=3, c=0.05).fit(tv)
+    got = m.get_factor_loadings(tv)
+    zs = m.transform(tv)
+    for v, t, l in zip(tv, zs, got):
+        vc = (v.double() - v.double().mean(0)).cpu().numpy()
+        tc = (t.double() - t.double().mean(0)).cpu().numpy()
+        ref = (vc.T @ tc / 4999) / np.outer(vc.std(0, ddof=1), tc.std(0, ddof=1))
+        np.testing.assert_allclose(l, ref, atol=2e-4)
+    host = m.get_factor_loadings(views)
+    for a, b in zip(host, got):
+        np.testing.assert_allclose(a, b, atol=1e-6)
+    small = [v[:, :10].copy() for v in views]
+    g = GCCA(latent_dimensions=30, c=0.1).fit(small)
+    assert g.weights_[0].shape == (10, 30) and np.all(g.weights_[1][:, 20:] == 0.0)
+
+
+# ---------------------------------------------------------------------------------------------
+# big-d building blocks: recursive Cholesky / TRSM (d >= 6144), split-K and big-tile GEMM shapes
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("d", [2048, 6144, 8192])
+def test_potrf_and_trsm_large(H, d):
+    import torch
+
+    torch.manual_seed(d)
+    M = torch.randn(d, d + 64, dtype=torch.float64, device="cuda")
+    A = (M @ M.T) / (d + 64) + 0.05 * torch.eye(d, dtype=torch.float64, device="cuda")
+    Lref = torch.linalg.cholesky(A)
+    Awork = A.clone()
+    H.check(H.lib.ccz_potrf_lower(H.raw, C.c_void_p(Awork.data_ptr()), d, d))
+    L = torch.tril(Awork)
+    assert float((L - Lref).abs().max() / Lref.abs().max()) < 1e-11
+    # X L' = B and X L = B against torch.linalg.solve_triangular, tall right-hand sides (the recursive TRSM path)
+    r = 6144 if d >= 6144 else 1024
+    B = torch.randn(r, d, dtype=torch.float64, device="cuda")
+    for trans in (1, 0):
+        X = B.clone()
+        H.check(H.lib.ccz_trsm_right_lower(H.raw, trans, r, d, C.c_void_p(L.data_ptr()), d, C.c_void_p(X.data_ptr()), d))
+        back = X @ (L.T if trans else L)
+        assert float((back - B).abs().max() / B.abs().max()) < 1e-9, (d, trans)
+
+
+@pytest.mark.parametrize("tA,tB,M,N,K", [
+    (0, 0, 4096, 80, 4096), (1, 0, 4096, 160, 4096), (0, 0, 16384, 160, 16384 // 4), (1, 0, 80, 80, 8192),
+    (0, 1, 2048, 2048, 512), (0, 0, 8192, 384, 2048), (1, 1, 300, 257, 1111), (0, 0, 128, 128, 65536),
+])
+def test_gemm_f64_solver_shapes(H, tA, tB, M, N, K):
+    """ccz_gemm_f64 at the shapes the solvers issue: skinny subspace blocks (split-K), big-tile eligible products,
+    ragged generic ones, a very deep K."""
+    import torch
+
+    torch.manual_seed(M + N + K)
+    A = torch.randn((K, M) if tA else (M, K), dtype=torch.float64, device="cuda")
+    B = torch.randn((N, K) if tB else (K, N), dtype=torch.float64, device="cuda")
+    Cm = torch.randn(M, N, dtype=torch.float64, device="cuda")
+    ref = 0.7 * ((A.T if tA else A) @ (B.T if tB else B)) - 0.3 * Cm
+    H.check(H.lib.ccz_gemm_f64(H.raw, tA, tB, M, N, K, 0.7, C.c_void_p(A.data_ptr()), A.shape[1], C.c_void_p(B.data_ptr()),
+                               B.shape[1], -0.3, C.c_void_p(Cm.data_ptr()), N))
+    H.sync()
+    assert float((Cm - ref).abs().max() / ref.abs().max()) < 1e-11
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE shapes
+# ---------------------------------------------------------------------------------------------
+def _device_moments_fp64(tv):
+    """Second moments of the stacked CUDA views with torch fp64 (test comparator, not the product path)."""
+    import torch
+
+    X = torch.cat([t.double() for t in tv], dim=1)
+    return (X.T @ X).cpu().numpy(), X.sum(0).cpu().numpy()
+
+
+def test_ns_shape_reduced_rows_against_oracle():
+    """North-star shape (2 x 4096, k = 64, fp32) at n = 32768 against oracle.gram_form on the same data (1e-3)."""
+    import torch
+
+    from cca_zoo_amd.datasets import JointData
+    from cca_zoo_amd.linear import CCA
+    from oracle import gram_form as gf
+
+    n, d, k = 32768, 4096, 64
+    jd = JointData(n_views=2, n_samples=n, latent_dimensions=k, n_features=[d, d], random_state=0,
+                   latent_scales=list(np.linspace(2.0, 0.5, k)))
+    tv = jd.sample_device(device="cuda", dtype=torch.float32, n_samples=n, seed=5)
+    m = CCA(latent_dimensions=k).fit(tv)
+    G, s = _device_moments_fp64(tv)
+    W, means, sv = gf.rcca_from_moments(G, s, n, [d, d], k, c=[0.0, 0.0], fast=True)
+    for w, r in zip(m.weights_, W):
+        assert w.shape == (d, k) and w.dtype == np.float32
+        assert col_rel_err(w, r) < 1e-3
+    np.testing.assert_allclose(m.singular_values_, sv, rtol=1e-4)
+    np.testing.assert_allclose(m.score(tv), sv, atol=1e-3)          # c = 0: training score == singular values
+
+
+def test_ns_shape_full_size_properties():
+    """The metric's own configuration (n = 1e6, 2 x 4096, k = 64, fp32): the property set bench.py gates on."""
+    import torch
+
+    from bench import check_fit_properties
+    from cca_zoo_amd.datasets import JointData
+    from cca_zoo_amd.linear import CCA
+
+    n, d, k = 1_000_000, 4096, 64
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60e9:
+        pytest.skip("needs ~40 GB of HBM")
+    jd = JointData(n_views=2, n_samples=n, latent_dimensions=k, n_features=[d, d], random_state=0,
+                   latent_scales=list(np.linspace(2.0, 0.5, k)))
+    tv = jd.sample_device(device="cuda", dtype=torch.float32, n_samples=n, seed=0)
+    m = CCA(latent_dimensions=k).fit(tv)
+    report = check_fit_properties(m, tv, jd, seed=0)
+    assert report["ok"], report
+
+
+def test_c3_mcca_shape_against_oracle_and_certificate(H):
+    """BASELINE configs[2] shape (MCCA 4 x 2048, k = 64): reduced n, fp64 views, against oracle.gram_form (1e-5) and
+    the pencil certificate; then fp32 views at n = 262144 through the certificate only."""
+    import torch
+
+    from cca_zoo_amd.datasets import JointData
+    from cca_zoo_amd.linear import MCCA
+    from oracle import certificates as ct
+    from oracle import gram_form as gf
+
+    dims, k = [2048] * 4, 64
+    jd = JointData(n_views=4, n_samples=1, latent_dimensions=k, n_features=dims, random_state=3,
+                   latent_scales=list(np.linspace(2.0, 0.5, k)))
+    n = 16384
+    tv = jd.sample_device(device="cuda", dtype=torch.float64, n_samples=n, seed=3)
+    m = MCCA(latent_dimensions=k, c=0.1).fit(tv)
+    G, s = _device_moments_fp64(tv)
+    W, means, lam = gf.mcca_from_moments(G, s, n, dims, k, c=[0.1] * 4, fast=True)
+    for w, r in zip(m.weights_, W):
+        assert w.shape == (2048, k) and col_rel_err(w, r) < 1e-5
+    np.testing.assert_allclose(m.eigenvalues_, lam, rtol=1e-8)
+    A, B = ct.mcca_pencil(G, s, n, dims, [0.1] * 4)
+    r = ct.pencil_certificate(A, B, np.vstack(m.weights_) / 2.0, m.eigenvalues_)
+    assert r["residual"] < 1e-8 and r["orthonormality"] < 1e-8 and r["n_above"] == k, r
+    del tv
+    n = 262144
+    tv = jd.sample_device(device="cuda", dtype=torch.float32, n_samples=n, seed=4)
+    m = MCCA(latent_dimensions=k).fit(tv)                            # c = 0 as BASELINE states it
+    G, s = _device_moments_fp64(tv)
+    A, B = ct.mcca_pencil(G, s, n, dims, [0.0] * 4, shift=0.0)
+    r = ct.pencil_certificate(A, B, np.vstack(m.weights_) / 2.0, m.eigenvalues_, delta=1e-4)
+    assert r["residual"] < 1e-3 and r["orthonormality"] < 1e-3 and r["n_above"] == k, r
+    sc = m.score(tv)
+    assert sc.shape == (k,) and np.all(np.diff(sc) < 1e-3) and sc[0] > 0.9
+
+
+def test_c5_gcca_shape_certificate(H):
+    """BASELINE configs[4] shape (GCCA d = [4096, 4096, 8192], k = 128, fp64) at n = 20480: D = 16384 takes the
+    recursive Cholesky / TRSM (d = 8192), the skinny GEMM at N = 160 and the Chebyshev solver at p = 16384.  A dense
+    oracle eigen-solve at this size takes minutes on the host: the solution is certified instead (oracle.certificates:
+    eigen-residual, B-orthonormality, and exactly k pencil eigenvalues above lambda_k by inertia)."""
+    import torch
+
+    from cca_zoo_amd.datasets import JointData
+    from cca_zoo_amd.linear import GCCA
+    from oracle import certificates as ct
+
+    dims, k, n = [4096, 4096, 8192], 128, 20480
+    jd = JointData(n_views=3, n_samples=1, latent_dimensions=k, n_features=dims, random_state=5,
+                   latent_scales=list(np.linspace(2.0, 0.5, k)))
+    tv = jd.sample_device(device="cuda", dtype=torch.float64, n_samples=n, seed=5)
+    m = GCCA(latent_dimensions=k, c=0.05).fit(tv)
+    assert [w.shape for w in m.weights_] == [(4096, k), (4096, k), (8192, k)] and m.weights_[0].dtype == np.float64
+    G, s = _device_moments_fp64(tv)
+    A, B, V = ct.gcca_pencil(G, s, n, dims, [0.05] * 3, m.weights_, m.eigenvalues_)
+    r = ct.pencil_certificate(A, B, V, m.eigenvalues_)
+    assert r["residual"] < 1e-7 and r["orthonormality"] < 1e-7 and r["n_above"] == k, r
+    # the reference's normalisation: the shared variates T = sum_i X_i B_i have unit 2-norm columns; per view
+    # X_i W_i is the projection of T on the view's column space, so every column norm is <= 1
+    z = m.transform(tv)
+    for t in z:
+        assert float(t.norm(dim=0).max()) <= 1.0 + 1e-6
+    sc = m.score(tv)
+    assert sc.shape == (k,) and sc[0] > 0.9
+
+
+def test_views_on_second_gpu_use_its_handle():
+    """tensors on cuda:1 without LOCAL_RANK / CCZ_DEVICE must run on a device-1 handle and leave the
+    caller's current device alone."""
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    from cca_zoo_amd.linear import CCA
+
+    rng = np.random.default_rng(0)
+    z = rng.standard_normal((2000, 3))
+    views = [(z @ rng.standard_normal((3, d)) + rng.standard_normal((2000, d))).astype(np.float32) for d in (64, 48)]
+    ref = CCA(latent_dimensions=3).fit(views)
+    before = torch.cuda.current_device()
+    tv = [torch.as_tensor(v, device="cuda:1") for v in views]
+    m = CCA(latent_dimensions=3).fit(tv)
+    assert torch.cuda.current_device() == before
+    for a, b in zip(m.weights_, ref.weights_):
+        assert col_rel_err(a, b) < 1e-4
+    assert m.transform(tv)[0].device.index == 1
+    with pytest.raises(ValueError, match="same device"):
+        CCA(latent_dimensions=3).fit([tv[0], torch.as_tensor(views[1], device="cuda:0")])

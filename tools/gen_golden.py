@@ -349,3 +349,22 @@ store["bw/eval_identity"] = np.float64(float((bw(x.detach()) - x.detach()).abs()
 store["bw/num_batches"] = np.int64(int(bw.num_batches_tracked))
 np.savez_compressed(os.path.join(OUT, "deep_next.npz"), **store)
 print("deep_next", len(store), "arrays")
+
+# ---- fp32 views whose means dwarf their spread (mean = 100 sigma): the reference centres BEFORE any product
+# (cca_zoo/_base.py:97-99), so its fp32 thin SVD is unaffected; a second-moment formulation must subtract a pilot
+# mean to match it (VERDICT r1 item 2 / ADVICE r1) ------------------------------------------------------------------
+rng_off = np.random.default_rng(7)
+n_off, k_off = 4000, 4
+z_off = rng_off.standard_normal((n_off, k_off)) * np.linspace(2.0, 0.5, k_off)
+off100_train, off100_fresh = [], []
+for d_off in (40, 30):
+    load = rng_off.standard_normal((k_off, d_off))
+    x = z_off @ load + rng_off.standard_normal((n_off, d_off))
+    shift = 100.0 * x.std(axis=0) * rng_off.choice([-1.0, 1.0], size=d_off)
+    off100_train.append((x + shift).astype(np.float32))
+    y = (rng_off.standard_normal((500, k_off)) * np.linspace(2.0, 0.5, k_off)) @ load + rng_off.standard_normal((500, d_off))
+    off100_fresh.append((y + shift).astype(np.float32))
+linear_case("offset_two_view_f32", off100_train, off100_fresh, {
+    "rcca_0.1": lambda: rCCA(latent_dimensions=4, c=0.1),
+    "cca": lambda: CCA(latent_dimensions=4),
+})
