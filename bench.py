@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--with-sharded-dcca", action="store_true",
                     help="N > 1 only: also time CCALoss fwd+bwd on the batch sharded over the ranks (extra collectives "
                          "after the timed fits; off by default so that nothing can delay the headline result)")
-    ap.add_argument("--cpu-sample-rows", type=int, default=16384)
+    ap.add_argument("--cpu-sample-rows", type=int, default=16384, help="rows of the CPU comparator's sample (>= 4 d keeps it in the tall regime)")
     return ap.parse_args()
 
 
@@ -77,9 +77,11 @@ def check_fit_properties(model, views, jd, seed, row0=0, sharded=False, n_check=
     n_local = int(views[0].shape[0])
     m_rows = min(n_check, n_local)
     host = orng.joint_data_rows(jd._weights, jd._snr_per_view, jd.latent_scales, seed=seed, row0=row0, rows=m_rows, dtype=ndt)
-    rep["generator_max_abs_diff"] = max(float(np.abs(v[:m_rows].cpu().numpy().astype(np.float64) - h.astype(np.float64)).max())
-                                        for v, h in zip(views, host))
-    ok = rep["generator_max_abs_diff"] < (1e-5 if ndt == np.float32 else 1e-10)
+    # the device forms the signal z W' with an fp32 (fp64) GEMM, the restatement in float64 then rounds: a few ulp
+    # of the LARGEST summands -- compare relative to the largest element
+    rep["generator_rel_diff"] = max(float(np.abs(v[:m_rows].cpu().numpy().astype(np.float64) - h.astype(np.float64)).max()
+                                          / np.abs(h.astype(np.float64)).max()) for v, h in zip(views, host))
+    ok = rep["generator_rel_diff"] < (4e-6 if ndt == np.float32 else 1e-12)
     # K1 on the checked rows (never sharded: a local quantity)
     h = _backend.handle_for(views)
     from cca_zoo_amd import _dist
@@ -165,12 +167,25 @@ def cpu_baseline(n_full, d, k, sample_rows):
     views = rf.joint_data(2, sample_rows, k, [d, d], 1.0, 0)
     views = [v.astype(np.float32) for v in views]
     times = []
-    for _ in range(3):
-        t0 = time.perf_counter()
-        rf.rcca_weights(views, k, c=0.0)
-        times.append(time.perf_counter() - t0)
-        if times[0] > 15.0:        # bounded: a single run already took its share of the bench's wall-clock
-            break
+    # one BLAS thread per usable core: the default (one per LOGICAL cpu of the box, 256) oversubscribes a 16-cpu quota
+    # so badly that the same SVD takes 5x longer
+    try:
+        from threadpoolctl import threadpool_limits
+
+        limiter = threadpool_limits(limits=max(cores, 1))
+    except Exception:
+        limiter = None
+    try:
+        for _ in range(3):
+            t0 = time.perf_counter()
+            rf.rcca_weights(views, k, c=0.0)
+            times.append(time.perf_counter() - t0)
+            if times[0] > 12.0:        # bounded: a single run already took its share of the bench's wall-clock
+                break
+    finally:
+        if limiter is not None:
+            limiter.restore_original_limits()
+    threads = max(cores, 1) if limiter is not None else threads
     med = float(np.median(times))
     full = med * (n_full / sample_rows)
     return {
@@ -195,6 +210,8 @@ def cpu_loss_baseline(batch=8192, d=512):
     z1 = torch.randn(batch, d, requires_grad=True)
     z2 = (0.5 * z1.detach() + torch.randn(batch, d)).requires_grad_(True)
     times = []
+    affinity, quota = host_cores()
+    torch.set_num_threads(max(int(min(affinity, quota)) if quota else affinity, 1))
     for _ in range(3):
         z1.grad = z2.grad = None
         t0 = time.perf_counter()

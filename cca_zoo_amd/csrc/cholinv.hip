@@ -70,16 +70,35 @@ __device__ __forceinline__ void acc_to_lds(const v4f64 (&acc)[4], double* dst, i
     for (int r = 0; r < 4; ++r) dst[(16 * w + (lane >> 4) + 4 * r) * CLD + 16 * t + (lane & 15)] = scale * acc[t][r];
 }
 
-// global (rows x cols valid, zero elsewhere) -> LDS tile; 256 threads, coalesced rows.  TRANS stores the transpose.
+// global (rows x cols valid, zero elsewhere) -> registers -> LDS tile; 256 threads, coalesced rows: a thread owns
+// column tid & 63 of rows (tid >> 6) + 4 i.  All 16 loads are issued before the first use (one memory latency per tile,
+// not sixteen); fetch / store are separate so that a K loop can fetch chunk i + 1 while chunk i is multiplied.
+struct TileRegs { double v[16]; };
+
+__device__ __forceinline__ void fetch_tile(TileRegs& t, const double* __restrict__ src, int64_t ld, int rows, int cols, int tid) {
+  const int c = tid & 63, r0 = tid >> 6;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = r0 + 4 * i;
+    t.v[i] = (r < rows && c < cols) ? src[int64_t(r) * ld + c] : 0.0;
+  }
+}
+
+template <bool TRANS>
+__device__ __forceinline__ void store_tile(double* dst, const TileRegs& t, int tid) {
+  const int c = tid & 63, r0 = tid >> 6;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = r0 + 4 * i;
+    if (TRANS) dst[c * CLD + r] = t.v[i]; else dst[r * CLD + c] = t.v[i];
+  }
+}
+
 template <bool TRANS>
 __device__ __forceinline__ void load_tile(double* dst, const double* __restrict__ src, int64_t ld, int rows, int cols, int tid) {
-  const int c = tid & 63;
-#pragma unroll 4
-  for (int r = tid >> 6; r < CB; r += 4) {
-    double v = 0.0;
-    if (r < rows && c < cols) v = src[int64_t(r) * ld + c];
-    if (TRANS) dst[c * CLD + r] = v; else dst[r * CLD + c] = v;
-  }
+  TileRegs t;
+  fetch_tile(t, src, ld, rows, cols, tid);
+  store_tile<TRANS>(dst, t, tid);
 }
 
 // ---------------------------------------------------------------------------
@@ -110,8 +129,16 @@ __device__ __forceinline__ double rsqrt_newton(double x) {
   return y;
 }
 
+typedef double v2f64 __attribute__((ext_vector_type(2)));
+
+// The multipliers of a step are 63 wave-uniform doubles from one LDS column: read as 32 ds_read_b128 (the column
+// starts at byte 528 j: 16-byte aligned) -- a single wave issues narrow LDS reads at a fifth of the array rate and the
+// 63 ds_read_b64 of the first version were the critical path (1000 cycles per pivot).
+// `progress` (LDS): number of finished columns, published with workgroup-scope release after the column and its
+// reciprocal diagonal are in LDS; the inverse wave consumes column t as soon as progress > t.
 template <int KMAX>
-__device__ __forceinline__ void cf_chol_steps(double (&a)[CB], int j_begin, int j_end, int lane, double* Ls, double* Rd, int& first_bad) {
+__device__ __forceinline__ void cf_chol_steps(double (&a)[CB], int j_begin, int j_end, int lane, double* Ls, double* Rd, int* progress,
+                                              int& first_bad) {
 #pragma unroll 1
   for (int j = j_begin; j < j_end; ++j) {
     const double col = a[0];
@@ -124,49 +151,69 @@ __device__ __forceinline__ void cf_chol_steps(double (&a)[CB], int j_begin, int 
     double* lcol = Ls + j * CLD;
     lcol[lane] = lane >= j ? l : 0.0;
     if (lane == 0) Rd[j] = rs;                     // 1 / L_jj
-    const double* lrow = lcol + j;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_store(progress, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const v2f64* lrow2 = reinterpret_cast<const v2f64*>(Ls) + j * (CLD + 1) / 2;   // &Ls[j * CLD + j], (CLD + 1) j / 2 pairs
+    // reads past row 63 land in the slack behind the tile and only feed junk registers
 #pragma unroll
-    for (int k = 1; k <= KMAX; ++k) {
-      a[k - 1] = a[k] - l * lrow[k];               // reads past row 63 land in slack that only feeds junk registers
-      if ((k & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+    for (int p = 0; p <= KMAX / 2; ++p) {
+      const v2f64 m = lrow2[p];
+      if (2 * p >= 1 && 2 * p <= KMAX) a[2 * p - 1] = a[2 * p] - l * m[0];
+      if (2 * p + 1 <= KMAX) a[2 * p] = a[2 * p + 1] - l * m[1];
+      if ((p & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
 }
 
 template <int KMAX>
-__device__ __forceinline__ void cf_inv_steps(double (&v)[CB], int t_begin, int t_end, int lane, const double* Ls, const double* Rd, double* Xs) {
+__device__ __forceinline__ void cf_inv_steps(double (&v)[CB], int t_begin, int t_end, int lane, const double* Ls, const double* Rd,
+                                             int* progress, double* Xs) {
 #pragma unroll 1
   for (int t = t_begin; t < t_end; ++t) {
-    const double* lcol = Ls + t * CLD + t;         // L[t][t], L[t+1][t], ... (wave-uniform addresses)
+    // wait until the factorization wave has published column t (uniform branch: lane 0 polls, everyone follows)
+    while (__hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= t) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const v2f64* lcol2 = reinterpret_cast<const v2f64*>(Ls) + t * (CLD + 1) / 2;    // &Ls[t * CLD + t]: L[t][t], L[t+1][t], ...
     const double x = v[0] * Rd[t];
     Xs[lane * CLD + t] = x;                        // (L^-1)[t][lane] = (L^-T)[lane][t]
 #pragma unroll
-    for (int k = 1; k <= KMAX; ++k) {
-      v[k - 1] = v[k] - lcol[k] * x;
-      if ((k & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+    for (int p = 0; p <= KMAX / 2; ++p) {
+      const v2f64 m = lcol2[p];
+      if (2 * p >= 1 && 2 * p <= KMAX) v[2 * p - 1] = v[2 * p] - m[0] * x;
+      if (2 * p + 1 <= KMAX) v[2 * p] = v[2 * p + 1] - m[1] * x;
+      if ((p & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-// lds layout expected: tile 0 = Ls, tile 1 = Xs (input tile, then L^-T), Rd after the three tiles
-__device__ __forceinline__ int wave_factor_lds(double* Ls, double* Xs, double* Rd, int lane) {
+// Waves 0 and 1 of the calling workgroup (tid < 128), after a __syncthreads() that made the input tile `In`
+// (row-major, stride CLD, identity-padded) visible and with *progress == 0:
+//   wave 0: Cholesky recurrence, columns into Ls[t * CLD + i] = L[i][t], reciprocal diagonal into Rd
+//   wave 1: forward substitution L x = e_c for all 64 right-hand sides at once, one step behind wave 0,
+//           Xs[c * CLD + t] = (L^-T)[c][t]
+// Returns (wave 0) the first non-positive pivot (0-based) or 0x7fffffff.
+__device__ __forceinline__ int wave_factor_lds(double* Ls, const double* In, double* Xs, double* Rd, int* progress, int tid) {
+  const int lane = tid & 63;
   int first_bad = 0x7fffffff;
-  double a[CB];
+  if (tid < 64) {
+    double a[CB];
 #pragma unroll
-  for (int k = 0; k < CB; ++k) a[k] = Xs[lane * CLD + k];
-  cf_chol_steps<63>(a, 0, 16, lane, Ls, Rd, first_bad);
-  cf_chol_steps<47>(a, 16, 32, lane, Ls, Rd, first_bad);
-  cf_chol_steps<31>(a, 32, 48, lane, Ls, Rd, first_bad);
-  cf_chol_steps<15>(a, 48, 64, lane, Ls, Rd, first_bad);
-  double v[CB];
+    for (int k = 0; k < CB; ++k) a[k] = In[lane * CLD + k];
+    cf_chol_steps<63>(a, 0, 16, lane, Ls, Rd, progress, first_bad);
+    cf_chol_steps<47>(a, 16, 32, lane, Ls, Rd, progress, first_bad);
+    cf_chol_steps<31>(a, 32, 48, lane, Ls, Rd, progress, first_bad);
+    cf_chol_steps<15>(a, 48, 64, lane, Ls, Rd, progress, first_bad);
+  } else {
+    double v[CB];
 #pragma unroll
-  for (int k = 0; k < CB; ++k) v[k] = (k == lane) ? 1.0 : 0.0;
-  cf_inv_steps<63>(v, 0, 16, lane, Ls, Rd, Xs);
-  cf_inv_steps<47>(v, 16, 32, lane, Ls, Rd, Xs);
-  cf_inv_steps<31>(v, 32, 48, lane, Ls, Rd, Xs);
-  cf_inv_steps<15>(v, 48, 64, lane, Ls, Rd, Xs);
+    for (int k = 0; k < CB; ++k) v[k] = (k == lane) ? 1.0 : 0.0;
+    cf_inv_steps<63>(v, 0, 16, lane, Ls, Rd, progress, Xs);
+    cf_inv_steps<47>(v, 16, 32, lane, Ls, Rd, progress, Xs);
+    cf_inv_steps<31>(v, 32, 48, lane, Ls, Rd, progress, Xs);
+    cf_inv_steps<15>(v, 48, 64, lane, Ls, Rd, progress, Xs);
+  }
   return first_bad;
 }
 
@@ -181,17 +228,27 @@ struct CholInvBatch {
   int count;
 };
 
-// wave 0 of the calling workgroup: tile `Xs` (identity-padded) -> L block (global), T block (global), info
-__device__ __forceinline__ void factor_and_publish(double* lds, int lane, int nbv, double* __restrict__ Lblk, int64_t ldl,
+// Whole workgroup (256 threads), input tile in LDS tile 1 (identity-padded), the caller has already synchronised:
+// waves 0 / 1 factor and invert (tiles 0 and 2), then all threads publish the L block and T = L^-T to global memory.
+__device__ __forceinline__ void factor_and_publish(double* lds, int tid, int nbv, double* __restrict__ Lblk, int64_t ldl,
                                                    double* __restrict__ Tblk, int* __restrict__ info, int64_t col0) {
   double* Ls = lds;
-  double* Xs = lds + CTILE;
+  const double* In = lds + CTILE;
+  double* Xs = lds + 2 * CTILE;
   double* Rd = lds + 3 * CTILE;
-  const int bad = wave_factor_lds(Ls, Xs, Rd, lane);
-  for (int r = 0; r < nbv; ++r)
-    if (lane <= r) Lblk[int64_t(r) * ldl + lane] = Ls[lane * CLD + r];
-  for (int r = 0; r < CB; ++r) Tblk[r * CB + lane] = Xs[r * CLD + lane];
-  if (bad != 0x7fffffff && lane == 0) atomicMin(info, int(col0 + bad + 1));
+  int* progress = reinterpret_cast<int*>(Rd + CB);
+  if (tid == 0) *progress = 0;
+  __syncthreads();
+  if (tid < 128) {
+    const int bad = wave_factor_lds(Ls, In, Xs, Rd, progress, tid);
+    if (tid == 0 && bad != 0x7fffffff) atomicMin(info, int(col0 + bad + 1));
+  }
+  __syncthreads();
+  const int c = tid & 63;
+  for (int r = tid >> 6; r < CB; r += 4) {
+    if (r < nbv && c <= r) Lblk[int64_t(r) * ldl + c] = Ls[c * CLD + r];
+    Tblk[r * CB + c] = Xs[r * CLD + c];
+  }
 }
 
 // first diagonal block of every matrix
@@ -208,8 +265,7 @@ __global__ __launch_bounds__(256) void k_cholinv_first(CholInvBatch bt, int* __r
     if (r < nbv && c < nbv) v = c <= r ? bt.A[b][int64_t(r) * bt.lda[b] + c] : bt.A[b][int64_t(c) * bt.lda[b] + r];
     Xs[r * CLD + c] = v;
   }
-  __syncthreads();
-  if (tid < 64) factor_and_publish(lds, tid, nbv, bt.L[b], bt.ldl[b], bt.T[b], info + b, 0);
+  factor_and_publish(lds, tid, nbv, bt.L[b], bt.ldl[b], bt.T[b], info + b, 0);
 }
 
 // step j: trailing update (+ look-ahead factorization of block j + 1) and row j of the inverse
@@ -293,9 +349,7 @@ __global__ __launch_bounds__(256) void k_cholinv_step(CholInvBatch bt, int j, in
         }
         Q[rr * CLD + cc] = v;                             // tile 1 = Xs of the wave factorization
       }
-    __syncthreads();
-    if (tid < 64)
-      factor_and_publish(lds, tid, rows_i, L + ri * ldl + ri, ldl, bt.T[b] + int64_t(j + 1) * CB * CB, info + b, ri);
+    factor_and_publish(lds, tid, rows_i, L + ri * ldl + ri, ldl, bt.T[b] + int64_t(j + 1) * CB * CB, info + b, ri);
     return;
   }
 
@@ -437,15 +491,29 @@ __global__ __launch_bounds__(256) void k_gemm_f64_multi(MultiGemm g) {
   const int rows_m = min(CB, M - m0), cols_n = min(CB, N - n0);
   v4f64 acc[4];
   acc_zero(acc);
-  for (int k0 = 0; k0 < K; k0 += CB) {
+  // As[m][k], Bs[k][n] regardless of the storage order of the operands; chunk i + 1 is fetched into registers while
+  // chunk i is multiplied out of LDS
+  TileRegs ra, rb;
+  auto fetch = [&](int k0) {
     const int kc = min(CB, K - k0);
-    // As[m][k], Bs[k][n] regardless of the storage order of the operands
-    if (!tA) load_tile<false>(As, A + int64_t(m0) * lda + k0, lda, rows_m, kc, tid);
-    else load_tile<true>(As, A + int64_t(k0) * lda + m0, lda, kc, rows_m, tid);
-    if (!tB) load_tile<false>(Bs, B + int64_t(k0) * ldb + n0, ldb, kc, cols_n, tid);
-    else load_tile<true>(Bs, B + int64_t(n0) * ldb + k0, ldb, cols_n, kc, tid);
-    __syncthreads();
+    if (!tA) fetch_tile(ra, A + int64_t(m0) * lda + k0, lda, rows_m, kc, tid);
+    else fetch_tile(ra, A + int64_t(k0) * lda + m0, lda, kc, rows_m, tid);
+    if (!tB) fetch_tile(rb, B + int64_t(k0) * ldb + n0, ldb, kc, cols_n, tid);
+    else fetch_tile(rb, B + int64_t(n0) * ldb + k0, ldb, cols_n, kc, tid);
+  };
+  auto stash = [&]() {
+    if (!tA) store_tile<false>(As, ra, tid); else store_tile<true>(As, ra, tid);
+    if (!tB) store_tile<false>(Bs, rb, tid); else store_tile<true>(Bs, rb, tid);
+  };
+  fetch(0);
+  stash();
+  __syncthreads();
+  for (int k0 = 0; k0 < K; k0 += CB) {
+    const bool more = k0 + CB < K;
+    if (more) fetch(k0 + CB);
     tile_mm<false, false>(As, Bs, w, lane, acc);
+    __syncthreads();
+    if (more) stash();
     __syncthreads();
   }
   const double alpha = g.alpha[p], beta = g.beta[p];

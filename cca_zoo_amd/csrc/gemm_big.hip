@@ -149,19 +149,33 @@ constexpr int GFR = 4;                       // ring slots per wave
 constexpr int GFSLAB = 4 * 1024;             // bytes of the A (or B) part of a slot
 constexpr int GFSLOT = 2 * GFSLAB;
 
-__global__ __launch_bounds__(256, 1) void k_gemm_f32_nn_fifo(int64_t M, int64_t N, int64_t K, float alpha,
-                                                             const float* __restrict__ A, int64_t lda,
-                                                             const float* __restrict__ B, int64_t ldb, float beta,
-                                                             float* __restrict__ C, int64_t ldc,
-                                                             const float* __restrict__ bias,
-                                                             float* __restrict__ C2, int64_t ldc2, int64_t nsplit) {
+// NTI = row tiles (of 32 samples) per wave: 4 -> 256 x 256 workgroup tile (the big products: every CU has a tile anyway),
+// 2 -> 128 x 256 (products with fewer than one 256-tile per CU, e.g. the DCCA gradient at batch 8192: 128 tiles would
+// leave half of the SIMDs without a wave; 256 half-height tiles put one wave on every SIMD).
+// DMA instructions per 8-deep block: NTI (A) + 4 (B); the counted waits follow from that.
+// (inline asm lives in plain __device__ helpers: inside a __global__ TEMPLATE the host pass tries to instantiate the
+// body, rejects the AMDGPU asm string and silently drops the kernel's host stub)
+__device__ __forceinline__ void wait_vmcnt_16() { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
+__device__ __forceinline__ void wait_vmcnt_14() { asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); }
+__device__ __forceinline__ void wait_vmcnt_12() { asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
+__device__ __forceinline__ void wait_vmcnt_11() { asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); }
+__device__ __forceinline__ void wait_vmcnt_0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+template <int NTI>
+__device__ __forceinline__ void gemm_f32_nn_fifo_body(int64_t M, int64_t N, int64_t K, float alpha,
+                                                      const float* __restrict__ A, int64_t lda,
+                                                      const float* __restrict__ B, int64_t ldb, float beta,
+                                                      float* __restrict__ C, int64_t ldc,
+                                                      const float* __restrict__ bias,
+                                                      float* __restrict__ C2, int64_t ldc2, int64_t nsplit) {
   // C2 != null: output columns [nsplit, N) go to C2 (columns renumbered from 0), nsplit a multiple of 256
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int64_t tn = N / BT, tm = (M + BT - 1) / BT;
+  constexpr int BTM = 64 * NTI;                         // rows per workgroup tile
+  const int64_t tn = N / BT, tm = (M + BTM - 1) / BTM;
   const int64_t q = int64_t(blockIdx.x) >> 3;
   const int64_t mt = (q / tn) * 8 + (blockIdx.x & 7), nt = q % tn;
   if (mt >= tm) return;
-  const int64_t m0 = mt * BT, n0 = nt * BT;
+  const int64_t m0 = mt * BTM, n0 = nt * BT;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
@@ -169,21 +183,21 @@ __global__ __launch_bounds__(256, 1) void k_gemm_f32_nn_fifo(int64_t M, int64_t 
   char* ring = smem + wave * (GFR * GFSLOT);
   const char* rd = ring + lane * 16;
 
-  const int64_t mw = m0 + wr * 128;                               // first sample row of this wave's slab
-  const int64_t rows_valid = min<int64_t>(128, M - mw);           // <= 0: slab entirely past M (nothing stored)
+  const int64_t mw = m0 + wr * (32 * NTI);                        // first sample row of this wave's slab
+  const int64_t rows_valid = min<int64_t>(32 * NTI, M - mw);      // <= 0: slab entirely past M (nothing stored)
   const __amdgpu_buffer_rsrc_t srcA = make_rsrc(A + (rows_valid > 0 ? mw : 0) * lda,
                                                 rows_valid > 0 ? ((rows_valid - 1) * lda + K) * 4 : 0);
   const __amdgpu_buffer_rsrc_t srcB = make_rsrc(B + n0 + wc * 128, ((K - 1) * ldb + 128) * 4);
-  int voffA[4];
+  int voffA[NTI];
 #pragma unroll
-  for (int ti = 0; ti < 4; ++ti) voffA[ti] = int(((32 * ti + (lane & 31)) * lda + 4 * (lane >> 5)) * 4);
+  for (int ti = 0; ti < NTI; ++ti) voffA[ti] = int(((32 * ti + (lane & 31)) * lda + 4 * (lane >> 5)) * 4);
   const int voffB = int(((4 * (lane >> 5)) * ldb + 4 * (lane & 31)) * 4);
   const int rowB = __builtin_amdgcn_readfirstlane(int(ldb * 4));   // bytes per k row of B
   int soffA = 0, soffB = 0;
 
-  v16f32 acc[4][4];
+  v16f32 acc[NTI][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NTI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -194,17 +208,19 @@ __global__ __launch_bounds__(256, 1) void k_gemm_f32_nn_fifo(int64_t M, int64_t 
   for (int s = 0; s < 3; ++s) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(srcA, (lds_ptr)(ring + s * GFSLOT + u * 1024), 16, voffA[u], soffA, 0, 0);
+      if (u < NTI)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srcA, (lds_ptr)(ring + s * GFSLOT + u * 1024), 16, voffA[u < NTI ? u : 0], soffA, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(srcB, (lds_ptr)(ring + s * GFSLOT + GFSLAB + u * 1024), 16, voffB, soffB, 0, 0);
       soffB += rowB;
     }
     soffA += GFB * 4;
     soffB += 4 * rowB;
   }
-  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                  // block 0 landed
-  v4f32 ab[2][4], bf[2];
+  if (NTI == 4) wait_vmcnt_16();    // block 0 landed: two blocks (2 x PER_BLOCK) may stay in flight
+  else wait_vmcnt_12();
+  v4f32 ab[2][NTI], bf[2];
 #pragma unroll
-  for (int ti = 0; ti < 4; ++ti) ab[0][ti] = *reinterpret_cast<const v4f32*>(rd + ti * 1024);
+  for (int ti = 0; ti < NTI; ++ti) ab[0][ti] = *reinterpret_cast<const v4f32*>(rd + ti * 1024);
   bf[0] = *reinterpret_cast<const v4f32*>(rd + GFSLAB);
 
   const int64_t nblk = K / GFB;
@@ -220,9 +236,11 @@ __global__ __launch_bounds__(256, 1) void k_gemm_f32_nn_fifo(int64_t M, int64_t 
         const v4f32 b4 = bf[cur];
         // -- gap 0: fragment reads for the next k-step (and, at the end of a block, the next block's A)
         if (u == 3) {
-          asm volatile("s_waitcnt vmcnt(14)" ::: "memory");         // block b+1 landed (b+2: 8, three steps of b+3: 6)
+          // block b+1 landed; newer: block b+2 (PER_BLOCK) and three steps of b+3 (min(3, NTI) A + 3 B)
+          if (NTI == 4) wait_vmcnt_14();
+          else wait_vmcnt_11();
 #pragma unroll
-          for (int ti = 0; ti < 4; ++ti)
+          for (int ti = 0; ti < NTI; ++ti)
             ab[(bb + 1) & 1][ti] = *reinterpret_cast<const v4f32*>(rd + nslot * GFSLOT + ti * 1024);
         }
         bf[nxt] = *reinterpret_cast<const v4f32*>(rd + nslot * GFSLOT + GFSLAB + nu * 1024);
@@ -232,7 +250,8 @@ __global__ __launch_bounds__(256, 1) void k_gemm_f32_nn_fifo(int64_t M, int64_t 
           acc[0][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[bb & 1][0][u], b4[tj], acc[0][tj], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         // -- gap 1: DMA of A tile u of block b+3
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(srcA, (lds_ptr)(ring + wsl * GFSLOT + u * 1024), 16, voffA[u], soffA, 0, 0);
+        if (u < NTI)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(srcA, (lds_ptr)(ring + wsl * GFSLOT + u * 1024), 16, voffA[u < NTI ? u : 0], soffA, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj)
@@ -243,17 +262,19 @@ __global__ __launch_bounds__(256, 1) void k_gemm_f32_nn_fifo(int64_t M, int64_t 
         soffB += rowB;
         if (u == 3) { soffA += GFB * 4; soffB += 4 * rowB; }
         __builtin_amdgcn_sched_barrier(0);
+        if (NTI == 4) {
 #pragma unroll
-        for (int tj = 0; tj < 4; ++tj)
-          acc[2][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[bb & 1][2][u], b4[tj], acc[2][tj], 0, 0, 0);
+          for (int tj = 0; tj < 4; ++tj)
+            acc[NTI - 2][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[bb & 1][NTI - 2][u], b4[tj], acc[NTI - 2][tj], 0, 0, 0);
 #pragma unroll
-        for (int tj = 0; tj < 4; ++tj)
-          acc[3][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[bb & 1][3][u], b4[tj], acc[3][tj], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+          for (int tj = 0; tj < 4; ++tj)
+            acc[NTI - 1][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[bb & 1][NTI - 1][u], b4[tj], acc[NTI - 1][tj], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  wait_vmcnt_0();
 
   // epilogue: tile ti owns rows 32 ti + trow (plain), column tiles are strided (n = 4 (lane & 31) + tj)
   const int64_t nbase = n0 + wc * 128 + 4 * (lane & 31);
@@ -263,7 +284,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_f32_nn_fifo(int64_t M, int64_t 
   int64_t ldo = ldc, ncol = nbase;
   if (C2 && n0 >= nsplit) { Cout = C2; ldo = ldc2; ncol = nbase - nsplit; }
 #pragma unroll
-  for (int ti = 0; ti < 4; ++ti)
+  for (int ti = 0; ti < NTI; ++ti)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int trow = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -275,6 +296,16 @@ __global__ __launch_bounds__(256, 1) void k_gemm_f32_nn_fifo(int64_t M, int64_t 
       if (beta != 0.f) v += beta * *reinterpret_cast<const v4f32*>(cp);
       *reinterpret_cast<v4f32*>(cp) = v;
     }
+}
+
+// The __global__ template is a bare forwarder: the host pass instantiates a __global__ template's body, and the LDS
+// address-space casts / AMDGPU asm of the pipeline above make that instantiation fail silently (no host stub).
+template <int NTI>
+__global__ __launch_bounds__(256, 1) void k_gemm_f32_nn_fifo(int64_t M, int64_t N, int64_t K, float alpha, const float* __restrict__ A,
+                                                             int64_t lda, const float* __restrict__ B, int64_t ldb, float beta,
+                                                             float* __restrict__ C, int64_t ldc, const float* __restrict__ bias,
+                                                             float* __restrict__ C2, int64_t ldc2, int64_t nsplit) {
+  gemm_f32_nn_fifo_body<NTI>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, C2, ldc2, nsplit);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -461,8 +492,8 @@ void gemm_f32_big(ccz_ctx* c, int64_t M, int64_t N, int64_t K, double alpha, con
                        (tmb + 7) / 8 * 8 * tnb < (int64_t(1) << 31);
   if (fifo_ok) {
     const size_t fifo_bytes = size_t(4) * GFR * GFSLOT;   // 128 KiB: four wave-private rings
-    CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_f32_nn_fifo), hipFuncAttributeMaxDynamicSharedMemorySize, int(fifo_bytes)));
-    hipLaunchKernelGGL(k_gemm_f32_nn_fifo, dim3((unsigned)((tmb + 7) / 8 * 8 * tnb)), dim3(256), fifo_bytes, st, M, N, K,
+    CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_f32_nn_fifo<4>), hipFuncAttributeMaxDynamicSharedMemorySize, int(fifo_bytes)));
+    hipLaunchKernelGGL(k_gemm_f32_nn_fifo<4>, dim3((unsigned)((tmb + 7) / 8 * 8 * tnb)), dim3(256), fifo_bytes, st, M, N, K,
                        float(alpha), A, lda, B32, N, float(beta), C, ldc, bias32, static_cast<float*>(nullptr), int64_t(0), N);
   } else {
     const size_t lds_bytes = size_t(2) * 2 * BKK * BT * 4;
@@ -493,11 +524,22 @@ bool gemm_f32_fifo_split_eligible(int64_t M, int64_t N, int64_t K, int64_t nspli
 
 void gemm_f32_fifo_split(ccz_ctx* c, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda, const float* B32,
                          const float* bias32, float* C1, int64_t ldc1, float* C2, int64_t ldc2, int64_t nsplit) {
-  const int64_t tmb = (M + BT - 1) / BT, tnb = N / BT;
+  const int64_t tnb = N / BT;
   const size_t fifo_bytes = size_t(4) * GFR * GFSLOT;
-  CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_f32_nn_fifo), hipFuncAttributeMaxDynamicSharedMemorySize, int(fifo_bytes)));
-  hipLaunchKernelGGL(k_gemm_f32_nn_fifo, dim3((unsigned)((tmb + 7) / 8 * 8 * tnb)), dim3(256), fifo_bytes, stream(c), M, N, K, alpha, A, lda,
-                     B32, N, 0.0f, C1, ldc1, bias32, C2, ldc2, nsplit);
+  const int ncu = std::max(1, impl(c)->props.multiProcessorCount);
+  // fewer full-height tiles than CUs: half-height tiles put a wave on every SIMD
+  const bool half = (M + BT - 1) / BT * tnb < int64_t(ncu);
+  if (half) {
+    const int64_t tmb = (M + 127) / 128;
+    CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_f32_nn_fifo<2>), hipFuncAttributeMaxDynamicSharedMemorySize, int(fifo_bytes)));
+    hipLaunchKernelGGL(k_gemm_f32_nn_fifo<2>, dim3((unsigned)((tmb + 7) / 8 * 8 * tnb)), dim3(256), fifo_bytes, stream(c), M, N, K, alpha, A,
+                       lda, B32, N, 0.0f, C1, ldc1, bias32, C2, ldc2, nsplit);
+  } else {
+    const int64_t tmb = (M + BT - 1) / BT;
+    CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_f32_nn_fifo<4>), hipFuncAttributeMaxDynamicSharedMemorySize, int(fifo_bytes)));
+    hipLaunchKernelGGL(k_gemm_f32_nn_fifo<4>, dim3((unsigned)((tmb + 7) / 8 * 8 * tnb)), dim3(256), fifo_bytes, stream(c), M, N, K, alpha, A,
+                       lda, B32, N, 0.0f, C1, ldc1, bias32, C2, ldc2, nsplit);
+  }
   CCZ_LAUNCH_CHECK();
 }
 

@@ -129,7 +129,7 @@ template <bool FAST>
 __global__ __launch_bounds__(256, 1) void k_gram_f32(const GramTile* __restrict__ tiles, int ntiles, int per_xcd,
                                                      int64_t ksplit, int64_t n, int64_t rows_per_wg,
                                                      double* __restrict__ G, int64_t ldg,
-                                                     const float* __restrict__ pilot) {
+                                                     const float* __restrict__ pilot, float* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* lds = reinterpret_cast<float*>(smem);  // [2 buffers][A | B][BK][256]
   const WorkItem wi = locate_work(blockIdx.x, ntiles, per_xcd, ksplit);
@@ -245,6 +245,22 @@ __global__ __launch_bounds__(256, 1) void k_gram_f32(const GramTile* __restrict_
   // epilogue: fp32 chunk sums -> fp64 G.  32x32 C/D layout: col = lane & 31,
   // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); tile (ti, tj) owns the
   // columns == ti (A side) / tj (B side) mod 4 of the wave's 128-wide slabs.
+  if (partial) {
+    // small problems (a DCCA batch: 10 tiles x 25 row chunks) would send 25 workgroups' atomics to every address of
+    // G (measured: 640 us for 70 us of MFMA work); instead every (chunk, tile) stores its 256 x 256 fp32 sums with plain
+    // 16-byte stores and k_gram_reduce adds the chunks up in fp64
+    float* pt = partial + (wi.chunk * int64_t(ntiles) + wi.tile) * int64_t(T32 * T32);
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int trow = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int i = wr * 128 + 4 * trow + ti;
+        const v4f32 v = {acc[ti][0][r], acc[ti][1][r], acc[ti][2][r], acc[ti][3][r]};
+        *reinterpret_cast<v4f32*>(pt + i * T32 + wc * 128 + 4 * (lane & 31)) = v;
+      }
+    return;
+  }
 #pragma unroll
   for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
@@ -760,6 +776,20 @@ __global__ void k_pilot_fixup(double* __restrict__ G, int64_t D, const double* _
   G[i * D + j] += pi * s_launch[j] + pj * s_launch[i] - n * pi * pj;
 }
 
+// G (upper tiles) += sum over the row chunks of the per-(chunk, tile) fp32 partial sums, in fp64
+__global__ __launch_bounds__(256) void k_gram_reduce(const float* __restrict__ partial, const GramTile* __restrict__ tiles, int ntiles,
+                                                     int64_t ksplit, double* __restrict__ G, int64_t ldg) {
+  const int tile = blockIdx.y;
+  const GramTile t = tiles[tile];
+  const int e = blockIdx.x * 256 + threadIdx.x;        // element of the 256 x 256 tile
+  const int i = e >> 8, j = e & 255;
+  if (i >= t.wa || j >= t.wb) return;
+  double acc = 0.0;
+  const float* p = partial + int64_t(tile) * (T32 * T32) + e;
+  for (int64_t c = 0; c < ksplit; ++c) acc += double(p[c * int64_t(ntiles) * (T32 * T32)]);
+  G[(t.out_row + i) * ldg + t.out_col + j] += acc;
+}
+
 __global__ void k_vec_add(double* __restrict__ dst, const double* __restrict__ src, int64_t n) {
   const int64_t j = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (j < n) dst[j] += src[j];
@@ -943,6 +973,14 @@ bool launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
 
   if (time_it) CCZ_HIP(hipEventRecord(im->ev[0], st));
   static const int impl_sel = [] { const char* e = getenv("CCZ_GRAM_IMPL"); return e ? atoi(e) : 1; }();   // 1: wave-private FIFO (default), 0: register-staged shared tile
+  // staged fp32 kernel on a small grid: per-(chunk, tile) partial sums + one reduce instead of contended atomics
+  float* partial = nullptr;
+  const bool staged32 = is32 && !(fast && impl_sel != 0 && !use_pilot);
+  if (staged32 && ksplit >= 2 && !sliced) {
+    static const int64_t partial_cap = [] { const char* e = getenv("CCZ_GRAM_PARTIAL_MB"); return (e ? atoll(e) : 192LL) << 20; }();
+    const int64_t bytes = ksplit * int64_t(ntiles) * T32 * T32 * 4;
+    if (bytes <= partial_cap) partial = static_cast<float*>(dev_alloc(c, size_t(bytes)));
+  }
   if (is32) {
     if (fast && impl_sel != 0 && !use_pilot) {
       const size_t fifo_bytes = size_t(4) * FR * FSLOT;   // 128 KiB: four wave-private rings
@@ -950,10 +988,10 @@ bool launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
       hipLaunchKernelGGL(k_gram_f32_fifo, dim3((unsigned)nblocks), dim3(256), fifo_bytes, st, d_tiles, ntiles, per_xcd, ksplit, n, rows_per_wg, G, D);
     } else if (fast) {
       CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_f32<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
-      hipLaunchKernelGGL(k_gram_f32<true>, dim3((unsigned)nblocks), dim3(256), lds_bytes, st, d_tiles, ntiles, per_xcd, ksplit, n, rows_per_wg, G, D, pilot);
+      hipLaunchKernelGGL(k_gram_f32<true>, dim3((unsigned)nblocks), dim3(256), lds_bytes, st, d_tiles, ntiles, per_xcd, ksplit, n, rows_per_wg, G, D, pilot, partial);
     } else {
       CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_f32<false>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
-      hipLaunchKernelGGL(k_gram_f32<false>, dim3((unsigned)nblocks), dim3(256), lds_bytes, st, d_tiles, ntiles, per_xcd, ksplit, n, rows_per_wg, G, D, pilot);
+      hipLaunchKernelGGL(k_gram_f32<false>, dim3((unsigned)nblocks), dim3(256), lds_bytes, st, d_tiles, ntiles, per_xcd, ksplit, n, rows_per_wg, G, D, pilot, partial);
     }
   } else {
     static const int impl64 = [] { const char* e = getenv("CCZ_GRAM64_IMPL"); return e ? atoi(e) : 1; }();   // 1: FIFO, 0: staged
@@ -970,6 +1008,11 @@ bool launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
     }
   }
   CCZ_LAUNCH_CHECK();
+  if (partial) {
+    hipLaunchKernelGGL(k_gram_reduce, dim3(256, (unsigned)ntiles), dim3(256), 0, st, partial, d_tiles, ntiles, ksplit, G, D);
+    CCZ_LAUNCH_CHECK();
+    dev_free(c, partial);
+  }
   if (time_it) CCZ_HIP(hipEventRecord(im->ev[1], st));
   if (use_pilot) {
     if (D > 65535) fail(CCZ_EUNSUP, "gram: pilot fix-up supports D <= 65535");

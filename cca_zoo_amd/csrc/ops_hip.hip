@@ -35,6 +35,8 @@ void* dev_alloc(ccz_ctx* c, size_t bytes) {
     return im->pool[best].p;
   }
   void* p = nullptr;
+  static const bool trace = getenv("CCZ_TRACE_POOL") != nullptr;
+  if (trace) fprintf(stderr, "[ccz] pool miss: hipMalloc(%zu) (%zu blocks cached)\n", bytes, im->pool.size());
   hipError_t e = hipMalloc(&p, bytes);
   if (e != hipSuccess) {
     // release cached blocks and retry once
@@ -930,6 +932,8 @@ static void graph_run(ccz_ctx* c, uint64_t key, F&& fn) {
       CCZ_HIP(hipGraphLaunch(g.exec, st));
       return;
     }
+  static const bool trace = getenv("CCZ_TRACE_POOL") != nullptr;
+  if (trace) fprintf(stderr, "[ccz] graph miss: capturing key %016llx (%zu cached)\n", (unsigned long long)key, im->graphs.size());
   if (hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) != hipSuccess) {
     (void)hipGetLastError();
     im->graphs_on = 0;

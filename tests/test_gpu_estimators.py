@@ -231,7 +231,9 @@ def test_config2_full_size_properties():
     mb, kb, _, _, _ = compute_moments([v[37_001:] for v in views], h)
     parts = h.to_host(ma, full.shape) + h.to_host(mb, full.shape)
     scale = np.abs(full).max()
-    assert np.max(np.abs(parts - full)) < 2e-6 * scale
+    # fp32 MFMA accumulation inside a <= 16384-row chunk: ~4e-6 of an entry per chunk (the two shardings chunk the rows
+    # differently), fp64 across chunks
+    assert np.max(np.abs(parts - full)) < 6e-6 * scale
     # rCCA(c=0.1): every weight column satisfies w' ((1-c) C_ii + c I) w = 1
     m = rCCA(latent_dimensions=k, c=0.1).fit(views)
     assert m.weights_[0].dtype == np.float32 and m.weights_[0].shape == (d, k)

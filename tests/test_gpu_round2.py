@@ -409,26 +409,61 @@ def _device_moments_fp64(tv):
     return (X.T @ X).cpu().numpy(), X.sum(0).cpu().numpy()
 
 
-def test_ns_shape_reduced_rows_against_oracle():
-    """North-star shape (2 x 4096, k = 64, fp32) at n = 32768 against oracle.gram_form on the same data (1e-3)."""
+def _gram_fp64_chunked(tv, chunk=65536):
+    """float64 second moments of the stacked CUDA views, accumulated over row chunks (test comparator)."""
+    import torch
+
+    D = sum(int(t.shape[1]) for t in tv)
+    G = torch.zeros((D, D), dtype=torch.float64, device=tv[0].device)
+    s = torch.zeros(D, dtype=torch.float64, device=tv[0].device)
+    for r0 in range(0, int(tv[0].shape[0]), chunk):
+        X = torch.cat([t[r0:r0 + chunk].double() for t in tv], dim=1)
+        G += X.T @ X
+        s += X.sum(0)
+    return G.cpu().numpy(), s.cpu().numpy()
+
+
+@pytest.mark.parametrize("n", [32768, 1_000_000])
+def test_ns_shape_against_oracle(n):
+    """North-star shape (CCA, 2 x 4096, k = 64, fp32 views) against oracle.gram_form on the float64 moments of the SAME
+    fp32 data, at a reduced n and at the metric's own n = 1e6.
+
+    What is compared, and why (SURVEY.md 8(d) "parity bar"): on this data (4096 features per view loading on every
+    latent) the canonical correlations are 0.99994 ... 0.9990 -- adjacent ones differ by ~1.4e-5, far less than 100x the
+    1e-3 tolerance, so a single canonical direction is defined only up to a rotation with its neighbours and the
+    SPANNED SUBSPACE is the comparable object: all principal angles between span(W_device) and span(W_oracle), measured
+    in the R_i metric in which both bases are orthonormal, must be below 1e-3 (sin), and the canonical correlations
+    (singular values, == the training score for c = 0) must agree to 1e-4 relative.  Per-column weights are still held
+    to 1e-2 (they sit at ~1e-3 at n = 1e6 and ~3e-3 at n = 32768, where n / d = 8 also makes C_ii ill-conditioned)."""
     import torch
 
     from cca_zoo_amd.datasets import JointData
     from cca_zoo_amd.linear import CCA
     from oracle import gram_form as gf
 
-    n, d, k = 32768, 4096, 64
+    d, k = 4096, 64
+    free, _ = torch.cuda.mem_get_info()
+    if free < n * 2 * d * 4 * 1.3 + 8e9:
+        pytest.skip("not enough free HBM")
     jd = JointData(n_views=2, n_samples=n, latent_dimensions=k, n_features=[d, d], random_state=0,
                    latent_scales=list(np.linspace(2.0, 0.5, k)))
     tv = jd.sample_device(device="cuda", dtype=torch.float32, n_samples=n, seed=5)
     m = CCA(latent_dimensions=k).fit(tv)
-    G, s = _device_moments_fp64(tv)
+    G, s = _gram_fp64_chunked(tv)
     W, means, sv = gf.rcca_from_moments(G, s, n, [d, d], k, c=[0.0, 0.0], fast=True)
-    for w, r in zip(m.weights_, W):
+    C = gf.covariance_from_moments(G, s, n)
+    for i, (w, r) in enumerate(zip(m.weights_, W)):
         assert w.shape == (d, k) and w.dtype == np.float32
-        assert col_rel_err(w, r) < 1e-3
+        R = C[i * d:(i + 1) * d, i * d:(i + 1) * d]
+        w64 = w.astype(np.float64)
+        np.testing.assert_allclose(w64.T @ R @ w64, np.eye(k), atol=2e-3)       # R-orthonormal basis (w'R w = 1)
+        cosines = np.linalg.svd(w64.T @ R @ r, compute_uv=False)
+        assert np.sqrt(max(0.0, 1.0 - cosines.min() ** 2)) < 1e-3, (i, cosines.min())
+        assert col_rel_err(w, r) < 1e-2
     np.testing.assert_allclose(m.singular_values_, sv, rtol=1e-4)
     np.testing.assert_allclose(m.score(tv), sv, atol=1e-3)          # c = 0: training score == singular values
+    for mu, r in zip(m.means_, means):
+        np.testing.assert_allclose(mu, r, rtol=1e-5, atol=1e-6)
 
 
 def test_ns_shape_full_size_properties():
