@@ -226,6 +226,7 @@ struct CholInvBatch {
   int64_t lda[CMAXB], ldl[CMAXB], ldx[CMAXB], d[CMAXB];
   int first[CMAXB + 1];   // prefix sums of the work items of this launch
   int count;
+  int inv_only;           // 1: L and T are given; only the rows of X = L^-1 are formed (no trailing updates)
 };
 
 // Whole workgroup (256 threads), input tile in LDS tile 1 (identity-padded), the caller has already synchronised:
@@ -259,6 +260,7 @@ __global__ __launch_bounds__(256) void k_cholinv_first(CholInvBatch bt, int* __r
   const int tid = threadIdx.x;
   const int nbv = int(min<int64_t>(CB, bt.d[b]));
   double* Xs = lds + CTILE;
+  if (tid == 0) info[b] = 0x7fffffff;                    // before the barrier inside factor_and_publish
   const int c = tid & 63;
   for (int r = tid >> 6; r < CB; r += 4) {
     double v = (r == c) ? 1.0 : 0.0;
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(256) void k_cholinv_step(CholInvBatch bt, int j, in
   const int64_t d = bt.d[b];
   const int nb = int((d + CB - 1) / CB);
   const int r = nb - 1 - j;                       // trailing block rows (may be <= 0)
-  const int nU = r > 0 ? r * (r + 1) / 2 : 0;
+  const int nU = (r > 0 && !bt.inv_only) ? r * (r + 1) / 2 : 0;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int64_t lda = bt.lda[b], ldl = bt.ldl[b];
   double* A = bt.A[b];
@@ -398,7 +400,7 @@ __global__ void k_fill_int(int* p, int n, int v) {
 
 struct MultiGemm;
 __global__ void k_gemm_f64_multi(MultiGemm g);
-constexpr size_t MG_LDS_FWD = size_t(2) * CTILE * sizeof(double);
+constexpr size_t MG_LDS_FWD = size_t(4) * CTILE * sizeof(double);
 
 static void cholinv_attr_once() {
   static thread_local int done_for_device = -1;
@@ -429,7 +431,6 @@ void cholinv_batched(ccz_ctx* c, int count, double* const* A, const int64_t* lda
     bt.lda[b] = lda[b]; bt.ldl[b] = ldl[b]; bt.ldx[b] = X ? ldx[b] : 0; bt.d[b] = d[b];
     nbmax = std::max(nbmax, int((d[b] + CB - 1) / CB));
   }
-  hipLaunchKernelGGL(k_fill_int, dim3(1), dim3(64), 0, st, info_dev, count, 0x7fffffff);
   hipLaunchKernelGGL(k_cholinv_first, dim3(count), dim3(256), CHOLINV_LDS, st, bt, info_dev);
   for (int j = 0; j < nbmax; ++j) {
     int total = 0;
@@ -437,7 +438,7 @@ void cholinv_batched(ccz_ctx* c, int count, double* const* A, const int64_t* lda
       bt.first[b] = total;
       const int nb = int((d[b] + CB - 1) / CB);
       const int r = nb - 1 - j;
-      const int nU = r > 0 ? r * (r + 1) / 2 : 0;
+      const int nU = (r > 0 && !bt.inv_only) ? r * (r + 1) / 2 : 0;
       const int nV = (bt.X[b] && j < nb) ? j + 1 : 0;
       total += nU + nV;
     }
@@ -445,6 +446,50 @@ void cholinv_batched(ccz_ctx* c, int count, double* const* A, const int64_t* lda
     if (total == 0) continue;
     hipLaunchKernelGGL(k_cholinv_step, dim3(total), dim3(256), CHOLINV_LDS, st, bt, j, info_dev);
   }
+  CCZ_LAUNCH_CHECK();
+}
+
+// X[b] = L[b]^-1 for `count` (<= 8) lower-triangular blocks whose 64 x 64 diagonal inverses T[b] (L_jj^-T, as
+// k_wave_chol_inv / cholinv_batched leave them) are known: d_max / 64 launches, rows of all blocks advance together.
+// Blocks of X above the diagonal are not written.
+void trinv_batched(ccz_ctx* c, int count, const double* const* L, const int64_t* ldl, const int64_t* d, double* const* X,
+                   const int64_t* ldx, const double* const* T) {
+  if (count < 1 || count > CMAXB) fail(CCZ_EINVAL, "trinv_batched: 1..8 blocks per call");
+  cholinv_attr_once();
+  hipStream_t st = stream(c);
+  CholInvBatch bt{};
+  bt.count = count;
+  bt.inv_only = 1;
+  int nbmax = 0;
+  for (int b = 0; b < count; ++b) {
+    bt.A[b] = nullptr; bt.L[b] = const_cast<double*>(L[b]); bt.X[b] = X[b]; bt.T[b] = const_cast<double*>(T[b]);
+    bt.lda[b] = 0; bt.ldl[b] = ldl[b]; bt.ldx[b] = ldx[b]; bt.d[b] = d[b];
+    nbmax = std::max(nbmax, int((d[b] + CB - 1) / CB));
+  }
+  for (int j = 0; j < nbmax; ++j) {
+    int total = 0;
+    for (int b = 0; b < count; ++b) {
+      bt.first[b] = total;
+      total += j < int((d[b] + CB - 1) / CB) ? j + 1 : 0;
+    }
+    bt.first[count] = total;
+    if (total == 0) continue;
+    hipLaunchKernelGGL(k_cholinv_step, dim3(total), dim3(256), CHOLINV_LDS, st, bt, j, static_cast<int*>(nullptr));
+  }
+  CCZ_LAUNCH_CHECK();
+}
+
+// dst (lower triangle incl. diagonal) <- src, both d x d
+__global__ void k_copy_lower(int64_t d, const double* __restrict__ src, int64_t lds_, double* __restrict__ dst, int64_t ldd) {
+  const int64_t i = blockIdx.y;
+  const int64_t j = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (j <= i && j < d) dst[i * ldd + j] = src[i * lds_ + j];
+}
+
+void copy_lower(ccz_ctx* c, int64_t d, const double* src, int64_t lds_, double* dst, int64_t ldd) {
+  if (d <= 0) return;
+  if (d > 65535) fail(CCZ_EUNSUP, "copy_lower: d too large");
+  hipLaunchKernelGGL(k_copy_lower, dim3((unsigned)((d + 255) / 256), (unsigned)d), dim3(256), 0, stream(c), d, src, lds_, dst, ldd);
   CCZ_LAUNCH_CHECK();
 }
 
@@ -464,17 +509,17 @@ struct MultiGemm {
   int M[MG_MAX], N[MG_MAX], K[MG_MAX];
   int tA[MG_MAX], tB[MG_MAX];
   int lower_only[MG_MAX];  // skip tiles strictly above the diagonal (symmetric results; C square)
+  int k_lower[MG_MAX];     // op(A) = X', op(B) = X with X lower triangular: only k >= max(m0, n0) contributes
   double alpha[MG_MAX], beta[MG_MAX];
   int first[MG_MAX + 1];
   int count;
 };
 
-constexpr size_t MG_LDS = size_t(2) * CTILE * sizeof(double);
+constexpr size_t MG_LDS = size_t(4) * CTILE * sizeof(double);     // two (A, B) tile pairs: one sync per K chunk
 
 __global__ __launch_bounds__(256) void k_gemm_f64_multi(MultiGemm g) {
   extern __shared__ __attribute__((aligned(16))) char mg_smem[];
-  double* As = reinterpret_cast<double*>(mg_smem);
-  double* Bs = As + CTILE;
+  double* lds = reinterpret_cast<double*>(mg_smem);
   int p = 0;
   while (p + 1 < g.count && int(blockIdx.x) >= g.first[p + 1]) ++p;
   const int item = int(blockIdx.x) - g.first[p];
@@ -489,10 +534,11 @@ __global__ __launch_bounds__(256) void k_gemm_f64_multi(MultiGemm g) {
   const int64_t lda = g.lda[p], ldb = g.ldb[p];
   const bool tA = g.tA[p] != 0, tB = g.tB[p] != 0;
   const int rows_m = min(CB, M - m0), cols_n = min(CB, N - n0);
+  const int k_first = g.k_lower[p] ? max(m0, n0) : 0;
   v4f64 acc[4];
   acc_zero(acc);
   // As[m][k], Bs[k][n] regardless of the storage order of the operands; chunk i + 1 is fetched into registers while
-  // chunk i is multiplied out of LDS
+  // chunk i is multiplied out of LDS, and lands in the other LDS tile pair (one barrier per chunk)
   TileRegs ra, rb;
   auto fetch = [&](int k0) {
     const int kc = min(CB, K - k0);
@@ -501,20 +547,25 @@ __global__ __launch_bounds__(256) void k_gemm_f64_multi(MultiGemm g) {
     if (!tB) fetch_tile(rb, B + int64_t(k0) * ldb + n0, ldb, kc, cols_n, tid);
     else fetch_tile(rb, B + int64_t(n0) * ldb + k0, ldb, cols_n, kc, tid);
   };
-  auto stash = [&]() {
+  auto stash = [&](int buf) {
+    double* As = lds + buf * 2 * CTILE;
+    double* Bs = As + CTILE;
     if (!tA) store_tile<false>(As, ra, tid); else store_tile<true>(As, ra, tid);
     if (!tB) store_tile<false>(Bs, rb, tid); else store_tile<true>(Bs, rb, tid);
   };
-  fetch(0);
-  stash();
+  if (k_first < K) {
+    fetch(k_first);
+    stash(0);
+  }
   __syncthreads();
-  for (int k0 = 0; k0 < K; k0 += CB) {
+  int buf = 0;
+  for (int k0 = k_first; k0 < K; k0 += CB) {
     const bool more = k0 + CB < K;
     if (more) fetch(k0 + CB);
-    tile_mm<false, false>(As, Bs, w, lane, acc);
+    tile_mm<false, false>(lds + buf * 2 * CTILE, lds + buf * 2 * CTILE + CTILE, w, lane, acc);
+    if (more) stash(buf ^ 1);          // the other pair: nobody reads it during this chunk
     __syncthreads();
-    if (more) stash();
-    __syncthreads();
+    buf ^= 1;
   }
   const double alpha = g.alpha[p], beta = g.beta[p];
   double* C = g.C[p];
@@ -551,6 +602,7 @@ void gemm_f64_multi(ccz_ctx* c, int count, const MultiGemmArgs* pr) {
     g.M[i] = int(a.M); g.N[i] = int(a.N); g.K[i] = int(a.K);
     g.tA[i] = a.tA ? 1 : 0; g.tB[i] = a.tB ? 1 : 0;
     g.lower_only[i] = a.lower_only ? 1 : 0;
+    g.k_lower[i] = a.k_lower ? 1 : 0;
     g.alpha[i] = a.alpha; g.beta[i] = a.beta;
     g.first[i] = total;
     total += int((a.M + CB - 1) / CB) * int((a.N + CB - 1) / CB);

@@ -104,6 +104,10 @@ void gemm_f64_skinny(ccz_ctx* c, bool tA, int64_t M, int64_t N, int64_t K, doubl
 // consumer reads them), T scratch of ceil(d / 64) * 4096 doubles per matrix, info_dev[b] = 0x7fffffff or 1 + bad pivot
 void cholinv_batched(ccz_ctx* c, int count, double* const* A, const int64_t* lda, const int64_t* d, double* const* L,
                      const int64_t* ldl, double* const* X, const int64_t* ldx, double* const* T, int* info_dev);
+// X[b] = L[b]^-1 for <= 8 lower-triangular blocks with known 64-block diagonal inverses T[b] (rows advance together)
+void trinv_batched(ccz_ctx* c, int count, const double* const* L, const int64_t* ldl, const int64_t* d, double* const* X,
+                   const int64_t* ldx, const double* const* T);
+void copy_lower(ccz_ctx* c, int64_t d, const double* src, int64_t lds_, double* dst, int64_t ldd);
 // up to 8 independent fp64 products per launch: C = alpha op(A) op(B) + beta C, optional transposed copy Ct = C'
 struct MultiGemmArgs {
   const double* A; const double* B; double* C; double* Ct;
@@ -111,6 +115,7 @@ struct MultiGemmArgs {
   int64_t M, N, K;
   bool tA, tB, lower_only;
   double alpha, beta;
+  bool k_lower = false;    // op(A) = X', op(B) = X, X lower triangular (blocks above the diagonal are never read)
 };
 void gemm_f64_multi(ccz_ctx* c, int count, const MultiGemmArgs* problems);
 

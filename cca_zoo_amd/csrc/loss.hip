@@ -39,8 +39,13 @@ struct PrepArgs {
 
 // Ce = (G - s s'/n)/(n-1) + eps I from the upper triangle of G; mean = s / n; diagonal blocks also to work[a]
 __global__ void k_loss_prep(const double* __restrict__ G, const double* __restrict__ s, int64_t D, double inv_n, double inv_nm1,
-                            double eps, double* __restrict__ Ce, double* __restrict__ mean, PrepArgs pa) {
+                            double eps, double* __restrict__ Ce, double* __restrict__ mean, PrepArgs pa,
+                            double* __restrict__ acc, double* __restrict__ bias) {
   const int64_t total = D * D;
+  if (blockIdx.x == 0) {                    // accumulators of later kernels: the loss sum and the bias row mean' Gamma
+    if (threadIdx.x == 0) acc[0] = 0.0;
+    if (bias) for (int64_t j = threadIdx.x; j < D; j += blockDim.x) bias[j] = 0.0;
+  }
   for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += int64_t(gridDim.x) * blockDim.x) {
     const int64_t i = e / D, j = e - i * D;
     double v = i <= j ? G[i * D + j] : G[j * D + i];
@@ -98,6 +103,20 @@ __global__ void k_sub_blocks(double* __restrict__ Gm, int64_t D, SubArgs sa) {
   }
 }
 
+// bias[j] += sum over a 64-row slab of mean_i Gamma_ij  (bias zeroed by k_loss_prep); grid (D / 64, D / 64)
+__global__ __launch_bounds__(256) void k_bias_row(const double* __restrict__ Gm, const double* __restrict__ mean, int64_t D,
+                                                  double* __restrict__ bias) {
+  __shared__ double red[4][64];
+  const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int64_t j = int64_t(blockIdx.x) * 64 + c, i0 = int64_t(blockIdx.y) * 64;
+  double a = 0.0;
+  if (j < D)
+    for (int64_t i = i0 + rg; i < min(D, i0 + 64); i += 4) a += mean[i] * Gm[i * D + j];
+  red[rg][c] = a;
+  __syncthreads();
+  if (rg == 0 && j < D) unsafeAtomicAdd(bias + j, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+}
+
 // fp64 -> fp32, elementwise (Gamma and, appended as one more row, the bias mean' Gamma)
 __global__ void k_cvt_f32(const double* __restrict__ in, int64_t total, float* __restrict__ out) {
   for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += int64_t(gridDim.x) * blockDim.x) out[e] = float(in[e]);
@@ -130,7 +149,7 @@ bool fused_ok(const int64_t* dims, int m) {
 // Gamma (D x D), mean (D) and the loss accumulator tr(A A) (one double, zeroed here) from the moments; info_dev: m ints.
 // Everything is enqueued on the handle's stream; nothing is read back.
 void fused_core(ccz_ctx* c, const double* mom, int64_t n, const int64_t* dims, int m, double eps, bool want_grad,
-                double* acc_dev, double* gamma_dev, double* mean_dev, int* info_dev) {
+                double* acc_dev, double* gamma_dev, double* mean_dev, int* info_dev, double* bias_dev = nullptr) {
   hipStream_t st = stream(c);
   std::vector<int64_t> off(m + 1, 0);
   for (int a = 0; a < m; ++a) off[a + 1] = off[a] + dims[a];
@@ -147,11 +166,9 @@ void fused_core(ccz_ctx* c, const double* mom, int64_t n, const int64_t* dims, i
     T[a] = DBuf(c, nblk * 4096);
     if (want_grad) Tcorr[a] = DBuf(c, d * d);
     pa.work[a] = work[a].get();
-    zero(c, X[a], size_t(d) * d * 8);                     // blocks above the diagonal of L^-1 are never written
   }
-  zero(c, acc_dev, 8);
   hipLaunchKernelGGL(k_loss_prep, dim3((unsigned)std::min<int64_t>((D * D + 255) / 256, 4096)), dim3(256), 0, st, mom, mom + D * D, D,
-                     1.0 / double(n), inv, eps, Ce.get(), mean_dev, pa);
+                     1.0 / double(n), inv, eps, Ce.get(), mean_dev, pa, acc_dev, want_grad ? bias_dev : nullptr);
   CCZ_LAUNCH_CHECK();
   {
     std::vector<double*> Ap(m), Lp(m), Xp(m), Tp(m);
@@ -160,9 +177,10 @@ void fused_core(ccz_ctx* c, const double* mom, int64_t n, const int64_t* dims, i
     cholinv_batched(c, m, Ap.data(), ld.data(), ld.data(), Lp.data(), ld.data(), Xp.data(), ld.data(), Tp.data(), info_dev);
   }
   std::vector<MultiGemmArgs> pr(m);
-  // Sinv_a = X_a' X_a
+  // Sinv_a = X_a' X_a   (X lower triangular: the K loop starts at the diagonal; the blocks of X above it -- never
+  // written by cholinv -- are never read)
   for (int a = 0; a < m; ++a)
-    pr[a] = MultiGemmArgs{X[a], X[a], Sinv[a], nullptr, dims[a], dims[a], dims[a], 0, dims[a], dims[a], dims[a], true, false, false, 1.0, 0.0};
+    pr[a] = MultiGemmArgs{X[a], X[a], Sinv[a], nullptr, dims[a], dims[a], dims[a], 0, dims[a], dims[a], dims[a], true, false, false, 1.0, 0.0, true};
   gemm_f64_multi(c, m, pr.data());
   // A[a, :] = Sinv_a Ce[a, :]
   for (int a = 0; a < m; ++a)
@@ -188,6 +206,8 @@ void fused_core(ccz_ctx* c, const double* mom, int64_t n, const int64_t* dims, i
   gemm_f64_multi(c, m, pr.data());
   hipLaunchKernelGGL(k_sub_blocks, dim3((unsigned)std::min<int64_t>((dmax * dmax + 255) / 256, 1024), (unsigned)m), dim3(256), 0, st,
                      gamma_dev, D, sa);
+  if (bias_dev)
+    hipLaunchKernelGGL(k_bias_row, dim3((unsigned)((D + 63) / 64), (unsigned)((D + 63) / 64)), dim3(256), 0, st, gamma_dev, mean_dev, D, bias_dev);
   CCZ_LAUNCH_CHECK();
 }
 
@@ -306,12 +326,11 @@ void cca_loss_impl(ccz_ctx* c, int dtype, const void* z1, const void* z2, int64_
     // embeddings (post-ReLU, un-normalised) routinely sit far from zero: always take the pilot-shifted Gram for
     // fp32 -- no host read-back, and at batch sizes the staged kernel costs the same as the FIFO one
     moments_impl(c, dtype, views, 2, n, true, mom, false, dtype == CCZ_F32 ? 2 : 0, false);
-    fused_core(c, mom, n, dims, 2, eps, want, acc, gamma, mean, info_dev);
+    fused_core(c, mom, n, dims, 2, eps, want, acc, gamma, mean, info_dev, want ? gamma.get() + D * D : nullptr);
     hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(1), 0, st, acc.get(), dtype, loss_dev, static_cast<double*>(nullptr));
     CCZ_LAUNCH_CHECK();
     if (want) {
       double* bias = gamma.get() + D * D;
-      gemm(c, false, false, 1, D, D, 1.0, mean, D, gamma, D, 0.0, bias, D);
       if (fifo) {
         float* G32 = static_cast<float*>(dev_alloc(c, size_t(D + 1) * D * 4));
         hipLaunchKernelGGL(k_cvt_f32, dim3((unsigned)std::min<int64_t>(((D + 1) * D + 255) / 256, 2048)), dim3(256), 0, st, gamma.get(),

@@ -1061,6 +1061,127 @@ static void trsm_right_lower_iter(ccz_ctx* c, bool trans, int64_t r, int64_t d, 
 }
 
 
+// ---------------------------------------------------------------------------
+// Round-2 paths (cholinv.hip):
+//  * potrf: the step kernels with look-ahead -- ONE launch per 64-column block for all matrices of the batch (the
+//    trailing tiles recompute their panel blocks, the owner of the next diagonal block factors it in the same
+//    launch) instead of three launches and a 60 us single-wave factorization per block; above 4096 columns the
+//    3x recompute of the tiles costs more than it saves and the factorization runs on 512-column super-blocks
+//    (batched step kernels on the diagonal super-blocks, 128-tile GEMMs for panel and trailing update).
+//  * trsm: 512-column super-blocks with explicit inverses of the diagonal super-blocks (one batched pass of the
+//    inverse rows) -- 8 x (r x 512 x 512 product + rank-512 trailing update) at the big-GEMM rate instead of 64
+//    rank-64 updates that were bound by HBM.
+// ---------------------------------------------------------------------------
+constexpr int64_t SB = 512;
+
+static void potrf_lower_batched_steps(ccz_ctx* c, int count, double* const* A, const int64_t* d, const int64_t* lda, int* info) {
+  for (int b0 = 0; b0 < count; b0 += 8) {
+    const int nbt = std::min(8, count - b0);
+    std::vector<DBuf> Lb(nbt), Tb(nbt);
+    std::vector<double*> Lp(nbt), Tp(nbt);
+    std::vector<int64_t> ldl(nbt);
+    for (int i = 0; i < nbt; ++i) {
+      const int64_t di = d[b0 + i];
+      Lb[i] = DBuf(c, di * di);
+      Tb[i] = DBuf(c, (di + NB - 1) / NB * NB * NB);
+      Lp[i] = Lb[i].get();
+      Tp[i] = Tb[i].get();
+      ldl[i] = di;
+    }
+    int* info_dev = impl(c)->d_flag + 8;
+    cholinv_batched(c, nbt, A + b0, lda + b0, d + b0, Lp.data(), ldl.data(), nullptr, nullptr, Tp.data(), info_dev);
+    for (int i = 0; i < nbt; ++i) copy_lower(c, d[b0 + i], Lp[i], ldl[i], A[b0 + i], lda[b0 + i]);
+    int got[8];
+    d2h(c, got, info_dev, size_t(nbt) * sizeof(int));
+    for (int i = 0; i < nbt; ++i) info[b0 + i] = got[i] == 0x7fffffff ? 0 : got[i];
+  }
+}
+
+// one matrix, d > 4096: right-looking over 512-column super-blocks
+static int potrf_lower_superblocked(ccz_ctx* c, double* A, int64_t d, int64_t lda) {
+  const int64_t nsb = (d + SB - 1) / SB;
+  DBuf Ldiag(c, SB * SB), Xinv(c, SB * SB), T(c, (SB / NB) * NB * NB);
+  int* info_dev = impl(c)->d_flag + 8;
+  for (int64_t J = 0; J < nsb; ++J) {
+    const int64_t j0 = J * SB, w = std::min(SB, d - j0), rem = d - j0 - w;
+    double* Ajj = A + j0 * lda + j0;
+    double* Lp = Ldiag.get();
+    double* Xp = Xinv.get();
+    double* Tp = T.get();
+    const int64_t ldw = SB;
+    if (rem > 0) zero(c, Xinv, size_t(SB) * SB * 8);          // the panel product reads the whole block
+    cholinv_batched(c, 1, &Ajj, &lda, &w, &Lp, &ldw, rem > 0 ? &Xp : nullptr, &ldw, &Tp, info_dev);
+    int got = 0;
+    d2h(c, &got, info_dev, sizeof(int));
+    if (got != 0x7fffffff) return int(j0) + got;
+    copy_lower(c, w, Lp, ldw, Ajj, lda);
+    if (rem <= 0) break;
+    double* A21 = A + (j0 + w) * lda + j0;
+    DBuf tmp(c, rem * w);
+    gemm(c, false, true, rem, w, w, 1.0, A21, lda, Xp, ldw, 0.0, tmp, w);                  // L21 = A21 L11^-T
+    copy2d(c, rem, w, tmp, w, A21, lda);
+    gemm_ex(c, false, true, rem, rem, w, -1.0, tmp, w, tmp, w, 1.0, A + (j0 + w) * lda + (j0 + w), lda, nullptr, 0, true);
+  }
+  return 0;
+}
+
+static void potrf_lower_batched_new(ccz_ctx* c, int count, double* const* A, const int64_t* d, const int64_t* lda, int* info) {
+  // matrices up to 4096 columns advance together through the step kernels; wider ones one by one, super-blocked
+  std::vector<double*> As;
+  std::vector<int64_t> ds, lds_;
+  std::vector<int> idx;
+  for (int i = 0; i < count; ++i) {
+    if (d[i] <= 4096) { As.push_back(A[i]); ds.push_back(d[i]); lds_.push_back(lda[i]); idx.push_back(i); }
+    else info[i] = potrf_lower_superblocked(c, A[i], d[i], lda[i]);
+  }
+  if (!As.empty()) {
+    std::vector<int> inf(As.size(), 0);
+    potrf_lower_batched_steps(c, int(As.size()), As.data(), ds.data(), lds_.data(), inf.data());
+    for (size_t t = 0; t < idx.size(); ++t) info[idx[t]] = inf[t];
+  }
+}
+
+static void trsm_right_lower_sb(ccz_ctx* c, bool trans, int64_t r, int64_t d, const double* L, int64_t ldl, double* X, int64_t ldx) {
+  const int64_t nblk = (d + NB - 1) / NB, nsb = (d + SB - 1) / SB;
+  DBuf invT(c, nblk * NB * NB), Xinv(c, nsb * SB * SB), tmp(c, r * SB);
+  diag_inverses(c, L, ldl, d, invT);                         // L_jj^-T of every 64-column block, one launch
+  zero(c, Xinv, size_t(nsb) * SB * SB * 8);                  // the products read whole super-blocks
+  for (int64_t J0 = 0; J0 < nsb; J0 += 8) {
+    const int cnt = int(std::min<int64_t>(8, nsb - J0));
+    const double* Lp[8];
+    const double* Tp[8];
+    double* Xp[8];
+    int64_t dd[8], l1[8], l2[8];
+    for (int t = 0; t < cnt; ++t) {
+      const int64_t j0 = (J0 + t) * SB;
+      Lp[t] = L + j0 * ldl + j0;
+      Tp[t] = invT.get() + (j0 / NB) * NB * NB;
+      Xp[t] = Xinv.get() + (J0 + t) * SB * SB;
+      dd[t] = std::min(SB, d - j0);
+      l1[t] = ldl;
+      l2[t] = SB;
+    }
+    trinv_batched(c, cnt, Lp, l1, dd, Xp, l2, Tp);
+  }
+  if (trans) {
+    // X L' = B, forward over the super-blocks:  X_J = (B_J - sum_{t<J} X_t L_Jt') L_JJ^-T
+    for (int64_t J = 0; J < nsb; ++J) {
+      const int64_t j0 = J * SB, w = std::min(SB, d - j0), rem = d - j0 - w;
+      gemm(c, false, true, r, w, w, 1.0, X + j0, ldx, Xinv.get() + J * SB * SB, SB, 0.0, tmp, SB);
+      copy2d(c, r, w, tmp, SB, X + j0, ldx);
+      if (rem > 0) gemm(c, false, true, r, rem, w, -1.0, tmp, SB, L + (j0 + w) * ldl + j0, ldl, 1.0, X + j0 + w, ldx);
+    }
+  } else {
+    // X L = B, backward:  X_J = (B_J - sum_{t>J} X_t L_tJ) L_JJ^-1
+    for (int64_t J = nsb - 1; J >= 0; --J) {
+      const int64_t j0 = J * SB, w = std::min(SB, d - j0);
+      gemm(c, false, false, r, w, w, 1.0, X + j0, ldx, Xinv.get() + J * SB * SB, SB, 0.0, tmp, SB);
+      copy2d(c, r, w, tmp, SB, X + j0, ldx);
+      if (j0 > 0) gemm(c, false, false, r, j0, w, -1.0, tmp, SB, L + j0 * ldl, ldl, 1.0, X, ldx);
+    }
+  }
+}
+
 // Dispatch: the recursive forms put the flops into large-K GEMMs but issue ~40% more (tiny) launches;
 // they pay off once the matrices are big enough for the GEMMs to dominate the launch latency.
 static int solver_mode() {
@@ -1068,9 +1189,15 @@ static int solver_mode() {
   return m;   // -1: automatic, 0: iterative, 1: recursive
 }
 
+static int solver_legacy() {
+  static const int m = [] { const char* e = getenv("CCZ_SOLVER_LEGACY"); return e ? atoi(e) : 0; }();
+  return m;   // 1: the round-1 blocked Cholesky / rank-64 triangular solves
+}
+
 void potrf_lower_batched(ccz_ctx* c, int count, double* const* A, const int64_t* d, const int64_t* lda, int* info) {
   int64_t dmax = 0;
   for (int i = 0; i < count; ++i) dmax = std::max(dmax, d[i]);
+  if (!solver_legacy()) { potrf_lower_batched_new(c, count, A, d, lda, info); return; }
   const int mode = solver_mode();
   if (mode == 1 || (mode < 0 && dmax >= 6144)) potrf_lower_batched_rec(c, count, A, d, lda, info);
   else potrf_lower_batched_iter(c, count, A, d, lda, info);
@@ -1079,6 +1206,7 @@ void potrf_lower_batched(ccz_ctx* c, int count, double* const* A, const int64_t*
 void trsm_right_lower(ccz_ctx* c, bool trans, int64_t r, int64_t d, const double* L, int64_t ldl, double* X,
                       int64_t ldx) {
   if (r <= 0 || d <= 0) return;
+  if (!solver_legacy() && d >= 1024) { trsm_right_lower_sb(c, trans, r, d, L, ldl, X, ldx); return; }
   const int mode = solver_mode();
   if (mode == 1 || (mode < 0 && d >= 2048 && r >= 6144)) trsm_right_lower_rec(c, trans, r, d, L, ldl, X, ldx);
   else trsm_right_lower_iter(c, trans, r, d, L, ldl, X, ldx);

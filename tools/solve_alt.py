@@ -8,7 +8,7 @@ import numpy as np, torch
 from cca_zoo_amd.datasets import JointData
 from cca_zoo_amd.linear import CCA
 
-n, d, k = 131072, 4096, 64
+n, d, k = int(os.environ.get("N", "1000000")), 4096, 64
 jd = JointData(n_views=2, n_samples=n, latent_dimensions=k, n_features=[d, d], random_state=0, latent_scales=list(np.linspace(2.0, 0.5, k)))
 views = jd.sample_device(device="cuda", dtype=torch.float32, n_samples=n, seed=1)
 m = CCA(latent_dimensions=k)
