@@ -31,7 +31,7 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 constexpr int CB = 64;          // block edge
 constexpr int CLD = CB + 1;     // LDS tile stride (doubles): row and column walks both conflict-free for the wave code
 constexpr int CTILE = CB * CLD; // doubles per LDS tile
-constexpr size_t CHOLINV_LDS = (size_t(3) * CTILE + 2 * CB + 8) * sizeof(double);
+constexpr size_t CHOLINV_LDS = (size_t(3) * CTILE + 2 * CB + 8 + 4 * CB) * sizeof(double);   // 3 tiles, Rd, flags, 64 x 4 panel
 
 // ---------------------------------------------------------------------------
 // 64 x 64 tile products on the fp64 matrix pipe, operands in LDS tiles (stride CLD).
@@ -229,20 +229,172 @@ struct CholInvBatch {
   int inv_only;           // 1: L and T are given; only the rows of X = L^-1 are formed (no trailing updates)
 };
 
-// Whole workgroup (256 threads), input tile in LDS tile 1 (identity-padded), the caller has already synchronised:
-// waves 0 / 1 factor and invert (tiles 0 and 2), then all threads publish the L block and T = L^-T to global memory.
-__device__ __forceinline__ void factor_and_publish(double* lds, int tid, int nbv, double* __restrict__ Lblk, int64_t ldl,
-                                                   double* __restrict__ Tblk, int* __restrict__ info, int64_t col0) {
+// ---------------------------------------------------------------------------
+// MFMA form of the 64 x 64 factorization (default).  The shift-register recurrence above spends ~1000 cycles per
+// pivot on the rank-1 update (63 FMAs + 32 wave-uniform LDS reads issued by ONE wave); here the Schur complement
+// lives in v_mfma_f64_16x16x4_f64 accumulators (10 lower 16 x 16 tiles, 40 registers) and is updated once per
+// PANEL of four pivots by <= 10 MFMAs; only the 4-column panel itself goes through the scalar recurrence
+// (lane = row: four values per lane, multipliers by v_readlane, no LDS on the pivot chain):
+//   per panel:  panel columns accumulators -> LDS (64 x 4)  ->  4 pivots in registers  ->  L panel -> LDS
+//               ->  four ds_read_b64 give the A (and, by symmetry, B) fragments  ->  acc[ti][tj] -= L_ti L_tj'
+// All 16 panels are unrolled (every register / lane index is a constant).
+// The inverse is blocked as well: the four 16 x 16 diagonal blocks are inverted by substitution (one wave each, 16
+// steps), the six blocks below the diagonal follow from 16 x 16 MFMA products, column j on wave j:
+//   X_ij = -X_ii sum_{t=j}^{i-1} L_it X_tj
+// ---------------------------------------------------------------------------
+template <int Q>
+__device__ __forceinline__ void chol_panel(v4f64 (&acc)[4][4], int lane, double* Ls, double* Rd, double* PL, int& first_bad) {
+  constexpr int C0 = 4 * Q, TJ0 = Q / 4, CL = C0 % 16;
+  // 1. the panel's four columns of the Schur complement: accumulators -> PL[row][0..3]
+  const int pc = (lane & 15) - CL;
+  if (pc >= 0 && pc < 4) {
+#pragma unroll
+    for (int ti = TJ0; ti < 4; ++ti)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) PL[(16 * ti + (lane >> 4) + 4 * r) * 4 + pc] = acc[ti][TJ0][r];
+  }
+  // 2. lane = row: its four panel values (rows above the panel's tile row were not written: never used)
+  const v2f64 p01 = *reinterpret_cast<const v2f64*>(PL + lane * 4);
+  const v2f64 p23 = *reinterpret_cast<const v2f64*>(PL + lane * 4 + 2);
+  double pv[4] = {p01[0], p01[1], p23[0], p23[1]};
+  double l[4];
+  // 3. four pivots: everything in registers, multipliers by v_readlane with constant lane numbers
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    double piv = bcast_lane(pv[t], C0 + t);
+    const bool bad = !(piv > 0.0);
+    first_bad = bad ? min(first_bad, C0 + t) : first_bad;
+    piv = bad ? 1.0 : piv;
+    const double rs = rsqrt_newton(piv);
+    l[t] = lane >= C0 + t ? pv[t] * rs : 0.0;       // select, not multiply: rows above hold stale values
+    if (lane == 0) Rd[C0 + t] = rs;                 // 1 / L_jj for the substitution of the inverse
+#pragma unroll
+    for (int u = t + 1; u < 4; ++u) pv[u] -= l[t] * bcast_lane(l[t], C0 + u);
+  }
+  // 4. L panel: column-major factor Ls[col][row] (final output) and the 64 x 4 operand image PL[row][0..3]
+#pragma unroll
+  for (int t = 0; t < 4; ++t) Ls[(C0 + t) * CLD + lane] = l[t];
+  v2f64 q01 = {l[0], l[1]}, q23 = {l[2], l[3]};
+  *reinterpret_cast<v2f64*>(PL + lane * 4) = q01;
+  *reinterpret_cast<v2f64*>(PL + lane * 4 + 2) = q23;
+  if (Q == 15) return;
+  // 5. acc[ti][tj] -= L[rows of ti][panel] L[rows of tj][panel]'   (A fragment: (m = lane & 15, k = lane >> 4);
+  //    the B fragment of tile column tj is the A fragment of tile row tj)
+  double a[4];
+#pragma unroll
+  for (int t4 = TJ0; t4 < 4; ++t4) a[t4] = PL[(16 * t4 + (lane & 15)) * 4 + (lane >> 4)];
+#pragma unroll
+  for (int tj = TJ0; tj < 4; ++tj)
+#pragma unroll
+    for (int ti = tj; ti < 4; ++ti)
+      acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[ti], a[tj], acc[ti][tj], 0, 0, 0);
+}
+
+template <int Q>
+struct CholPanels {
+  static __device__ __forceinline__ void run(v4f64 (&acc)[4][4], int lane, double* Ls, double* Rd, double* PL, int& first_bad) {
+    CholPanels<Q - 1>::run(acc, lane, Ls, Rd, PL, first_bad);
+    chol_panel<Q>(acc, lane, Ls, Rd, PL, first_bad);
+  }
+};
+template <>
+struct CholPanels<-1> {
+  static __device__ __forceinline__ void run(v4f64 (&)[4][4], int, double*, double*, double*, int&) {}
+};
+
+// wave 0: In (row-major, stride CLD) -> Ls[col * CLD + row] = L[row][col] (whole columns, zeros above the diagonal),
+// Rd[j] = 1 / L_jj.  Returns the first non-positive pivot or 0x7fffffff.
+__device__ __forceinline__ int chol64_mfma(const double* In, double* Ls, double* Rd, double* PL, int lane) {
+  v4f64 acc[4][4];
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        acc[ti][tj][r] = tj <= ti ? In[(16 * ti + (lane >> 4) + 4 * r) * CLD + 16 * tj + (lane & 15)] : 0.0;
+  int first_bad = 0x7fffffff;
+  CholPanels<15>::run(acc, lane, Ls, Rd, PL, first_bad);
+  return first_bad;
+}
+
+// all four waves: Xs[col * CLD + row] = (L^-1)[row][col]  (== row-major L^-T) from Ls / Rd
+__device__ __forceinline__ void inv64_mfma(const double* Ls, const double* Rd, double* Xs, int tid) {
+  const int lane = tid & 63, w = tid >> 6;
+  // zero the blocks above the block diagonal (the substitution leaves exact zeros inside the diagonal blocks)
+  for (int e = tid; e < CB * CB; e += 256) {
+    const int row = e & 63, col = e >> 6;
+    if ((row >> 4) < (col >> 4)) Xs[col * CLD + row] = 0.0;
+  }
+  // phase A: wave w inverts the 16 x 16 diagonal block w by forward substitution, lane c < 16 = right-hand side e_c
+  {
+    const int o = 16 * w;
+    double v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = (k == lane) ? 1.0 : 0.0;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const double x = v[0] * Rd[o + t];
+      if (lane < 16) Xs[(o + lane) * CLD + o + t] = x;           // (L^-1)[o + t][o + lane]
+      const double* lcol = Ls + (o + t) * CLD + o + t;            // L[o + t + k][o + t], wave-uniform
+#pragma unroll
+      for (int k = 1; k < 16; ++k) v[k - 1] = (t + k < 16) ? v[k] - lcol[k] * x : 0.0;
+    }
+  }
+  __syncthreads();
+  // phase B: wave j forms column block j below the diagonal, top to bottom
+  const int j = w;
+  const int lr = lane & 15, lk = lane >> 4;
+  for (int i = j + 1; i < 4; ++i) {
+    v4f64 sacc = {0.0, 0.0, 0.0, 0.0};
+    for (int t = j; t < i; ++t) {
+#pragma unroll
+      for (int k0 = 0; k0 < 16; k0 += 4) {
+        const int k = k0 + lk;
+        const double a = Ls[(16 * t + k) * CLD + 16 * i + lr];      // L[16 i + lr][16 t + k]
+        const double b = Xs[(16 * j + lr) * CLD + 16 * t + k];      // (L^-1)[16 t + k][16 j + lr]
+        sacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, sacc, 0, 0, 0);
+      }
+    }
+    // X_ij = -X_ii S : the B fragment of k-step k0 = 4 r is accumulator register r of S (row = lk + 4 r, col = lr)
+    v4f64 xacc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double a = Xs[(16 * i + 4 * r + lk) * CLD + 16 * i + lr];   // (L^-1)[16 i + lr][16 i + 4 r + lk]
+      xacc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a, sacc[r], xacc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Xs[(16 * j + lr) * CLD + 16 * i + lk + 4 * r] = xacc[r];   // (L^-1)[16 i + lk + 4 r][16 j + lr]
+    // the next block row of this column reads what this wave has just written (same wave: in order)
+  }
+}
+
+// Whole workgroup (256 threads), input tile in LDS tile 1 (identity-padded): factor (tile 0 <- L, column-major),
+// invert (tile 2 <- L^-T, row-major), publish the L block and T = L^-T to global memory.
+template <bool MFMA_FORM>
+__device__ __forceinline__ void factor_and_publish_t(double* lds, int tid, int nbv, double* __restrict__ Lblk, int64_t ldl,
+                                                     double* __restrict__ Tblk, int* __restrict__ info, int64_t col0) {
   double* Ls = lds;
   const double* In = lds + CTILE;
   double* Xs = lds + 2 * CTILE;
   double* Rd = lds + 3 * CTILE;
   int* progress = reinterpret_cast<int*>(Rd + CB);
-  if (tid == 0) *progress = 0;
-  __syncthreads();
-  if (tid < 128) {
-    const int bad = wave_factor_lds(Ls, In, Xs, Rd, progress, tid);
-    if (tid == 0 && bad != 0x7fffffff) atomicMin(info, int(col0 + bad + 1));
+  double* PL = Rd + CB + 8;
+  if (MFMA_FORM) {
+    __syncthreads();
+    if (tid < 64) {
+      const int bad = chol64_mfma(In, Ls, Rd, PL, tid);
+      if (tid == 0 && bad != 0x7fffffff) atomicMin(info, int(col0 + bad + 1));
+    }
+    __syncthreads();
+    inv64_mfma(Ls, Rd, Xs, tid);
+  } else {
+    if (tid == 0) *progress = 0;
+    __syncthreads();
+    if (tid < 128) {
+      const int bad = wave_factor_lds(Ls, In, Xs, Rd, progress, tid);
+      if (tid == 0 && bad != 0x7fffffff) atomicMin(info, int(col0 + bad + 1));
+    }
   }
   __syncthreads();
   const int c = tid & 63;
@@ -253,6 +405,7 @@ __device__ __forceinline__ void factor_and_publish(double* lds, int tid, int nbv
 }
 
 // first diagonal block of every matrix
+template <bool MFMA_FORM>
 __global__ __launch_bounds__(256) void k_cholinv_first(CholInvBatch bt, int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) char ci_smem[];
   double* lds = reinterpret_cast<double*>(ci_smem);
@@ -267,10 +420,11 @@ __global__ __launch_bounds__(256) void k_cholinv_first(CholInvBatch bt, int* __r
     if (r < nbv && c < nbv) v = c <= r ? bt.A[b][int64_t(r) * bt.lda[b] + c] : bt.A[b][int64_t(c) * bt.lda[b] + r];
     Xs[r * CLD + c] = v;
   }
-  factor_and_publish(lds, tid, nbv, bt.L[b], bt.ldl[b], bt.T[b], info + b, 0);
+  factor_and_publish_t<MFMA_FORM>(lds, tid, nbv, bt.L[b], bt.ldl[b], bt.T[b], info + b, 0);
 }
 
 // step j: trailing update (+ look-ahead factorization of block j + 1) and row j of the inverse
+template <bool MFMA_FORM>
 __global__ __launch_bounds__(256) void k_cholinv_step(CholInvBatch bt, int j, int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) char ci_smem[];
   double* lds = reinterpret_cast<double*>(ci_smem);
@@ -351,7 +505,7 @@ __global__ __launch_bounds__(256) void k_cholinv_step(CholInvBatch bt, int j, in
         }
         Q[rr * CLD + cc] = v;                             // tile 1 = Xs of the wave factorization
       }
-    factor_and_publish(lds, tid, rows_i, L + ri * ldl + ri, ldl, bt.T[b] + int64_t(j + 1) * CB * CB, info + b, ri);
+    factor_and_publish_t<MFMA_FORM>(lds, tid, rows_i, L + ri * ldl + ri, ldl, bt.T[b] + int64_t(j + 1) * CB * CB, info + b, ri);
     return;
   }
 
@@ -407,8 +561,10 @@ static void cholinv_attr_once() {
   int dev = -1;
   CCZ_HIP(hipGetDevice(&dev));
   if (done_for_device == dev) return;
-  CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholinv_first), hipFuncAttributeMaxDynamicSharedMemorySize, int(CHOLINV_LDS)));
-  CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholinv_step), hipFuncAttributeMaxDynamicSharedMemorySize, int(CHOLINV_LDS)));
+  CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholinv_first<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(CHOLINV_LDS)));
+  CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholinv_step<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(CHOLINV_LDS)));
+  CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholinv_first<false>), hipFuncAttributeMaxDynamicSharedMemorySize, int(CHOLINV_LDS)));
+  CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholinv_step<false>), hipFuncAttributeMaxDynamicSharedMemorySize, int(CHOLINV_LDS)));
   CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_f64_multi), hipFuncAttributeMaxDynamicSharedMemorySize, int(MG_LDS_FWD)));
   done_for_device = dev;
 }
@@ -431,7 +587,10 @@ void cholinv_batched(ccz_ctx* c, int count, double* const* A, const int64_t* lda
     bt.lda[b] = lda[b]; bt.ldl[b] = ldl[b]; bt.ldx[b] = X ? ldx[b] : 0; bt.d[b] = d[b];
     nbmax = std::max(nbmax, int((d[b] + CB - 1) / CB));
   }
-  hipLaunchKernelGGL(k_cholinv_first, dim3(count), dim3(256), CHOLINV_LDS, st, bt, info_dev);
+  // CCZ_CHOLINV_MFMA=0 selects the shift-register (two-wave) form of the 64 x 64 factorization
+  static const int mfma_form = [] { const char* e = getenv("CCZ_CHOLINV_MFMA"); return e ? atoi(e) : 1; }();
+  if (mfma_form) hipLaunchKernelGGL(k_cholinv_first<true>, dim3(count), dim3(256), CHOLINV_LDS, st, bt, info_dev);
+  else hipLaunchKernelGGL(k_cholinv_first<false>, dim3(count), dim3(256), CHOLINV_LDS, st, bt, info_dev);
   for (int j = 0; j < nbmax; ++j) {
     int total = 0;
     for (int b = 0; b < count; ++b) {
@@ -444,7 +603,8 @@ void cholinv_batched(ccz_ctx* c, int count, double* const* A, const int64_t* lda
     }
     bt.first[count] = total;
     if (total == 0) continue;
-    hipLaunchKernelGGL(k_cholinv_step, dim3(total), dim3(256), CHOLINV_LDS, st, bt, j, info_dev);
+    if (mfma_form) hipLaunchKernelGGL(k_cholinv_step<true>, dim3(total), dim3(256), CHOLINV_LDS, st, bt, j, info_dev);
+    else hipLaunchKernelGGL(k_cholinv_step<false>, dim3(total), dim3(256), CHOLINV_LDS, st, bt, j, info_dev);
   }
   CCZ_LAUNCH_CHECK();
 }
@@ -474,7 +634,7 @@ void trinv_batched(ccz_ctx* c, int count, const double* const* L, const int64_t*
     }
     bt.first[count] = total;
     if (total == 0) continue;
-    hipLaunchKernelGGL(k_cholinv_step, dim3(total), dim3(256), CHOLINV_LDS, st, bt, j, static_cast<int*>(nullptr));
+    hipLaunchKernelGGL(k_cholinv_step<true>, dim3(total), dim3(256), CHOLINV_LDS, st, bt, j, static_cast<int*>(nullptr));
   }
   CCZ_LAUNCH_CHECK();
 }

@@ -1097,47 +1097,92 @@ static void potrf_lower_batched_steps(ccz_ctx* c, int count, double* const* A, c
   }
 }
 
-// one matrix, d > 4096: right-looking over 512-column super-blocks
-static int potrf_lower_superblocked(ccz_ctx* c, double* A, int64_t d, int64_t lda) {
-  const int64_t nsb = (d + SB - 1) / SB;
-  DBuf Ldiag(c, SB * SB), Xinv(c, SB * SB), T(c, (SB / NB) * NB * NB);
-  int* info_dev = impl(c)->d_flag + 8;
-  for (int64_t J = 0; J < nsb; ++J) {
-    const int64_t j0 = J * SB, w = std::min(SB, d - j0), rem = d - j0 - w;
-    double* Ajj = A + j0 * lda + j0;
-    double* Lp = Ldiag.get();
-    double* Xp = Xinv.get();
-    double* Tp = T.get();
-    const int64_t ldw = SB;
-    if (rem > 0) zero(c, Xinv, size_t(SB) * SB * 8);          // the panel product reads the whole block
-    cholinv_batched(c, 1, &Ajj, &lda, &w, &Lp, &ldw, rem > 0 ? &Xp : nullptr, &ldw, &Tp, info_dev);
-    int got = 0;
-    d2h(c, &got, info_dev, sizeof(int));
-    if (got != 0x7fffffff) return int(j0) + got;
-    copy_lower(c, w, Lp, ldw, Ajj, lda);
-    if (rem <= 0) break;
-    double* A21 = A + (j0 + w) * lda + j0;
-    DBuf tmp(c, rem * w);
-    gemm(c, false, true, rem, w, w, 1.0, A21, lda, Xp, ldw, 0.0, tmp, w);                  // L21 = A21 L11^-T
-    copy2d(c, rem, w, tmp, w, A21, lda);
-    gemm_ex(c, false, true, rem, rem, w, -1.0, tmp, w, tmp, w, 1.0, A + (j0 + w) * lda + (j0 + w), lda, nullptr, 0, true);
+// d > 1024: right-looking over 512-column super-blocks, all matrices of the batch together -- the diagonal
+// super-blocks of every matrix are factored (+ inverted) in ONE batched pass of the step kernels (the chain of nine
+// dependent launches is shared), panel and trailing update are 128-tile GEMMs with K = 512.  (The step kernels
+// alone on a 4096-column matrix are rank-64 updates of the whole trailing matrix -- HBM-bound, measured 8 ms for two
+// matrices; the super-blocked form moves 8x less.)  Pivot failures are collected at the end: one host read.
+static void potrf_lower_batched_sb(ccz_ctx* c, int count, double* const* A, const int64_t* d, const int64_t* lda, int* info) {
+  if (count > 8) fail(CCZ_EUNSUP, "potrf_lower_batched_sb: at most 8 matrices per call");
+  int64_t dmax = 0;
+  for (int i = 0; i < count; ++i) dmax = std::max(dmax, d[i]);
+  const int64_t nsb = (dmax + SB - 1) / SB;
+  std::vector<DBuf> Ld(count), Xv(count), Tv(count);
+  for (int i = 0; i < count; ++i) {
+    Ld[i] = DBuf(c, SB * SB);
+    Xv[i] = DBuf(c, SB * SB);
+    Tv[i] = DBuf(c, (SB / NB) * NB * NB);
+    zero(c, Xv[i], size_t(SB) * SB * 8);       // the panel products read whole blocks; the inverse rows overwrite the lower blocks
   }
-  return 0;
+  // info of super-step J of matrix i: slot J * 8 + i (all slots start at "no failure")
+  const int nslots = int(nsb) * 8;
+  int* info_dev = static_cast<int*>(dev_alloc(c, size_t(nslots) * sizeof(int)));
+  for (int64_t J = 0; J < nsb; ++J) {
+    const int64_t j0 = J * SB;
+    double* Ap[8]; double* Lp[8]; double* Xp[8]; double* Tp[8];
+    int64_t la[8], dd[8], ll[8];
+    int idx[8], cnt = 0;
+    bool any_rem = false;
+    for (int i = 0; i < count; ++i) {
+      if (j0 >= d[i]) continue;
+      idx[cnt] = i;
+      Ap[cnt] = A[i] + j0 * lda[i] + j0;
+      la[cnt] = lda[i];
+      dd[cnt] = std::min(SB, d[i] - j0);
+      Lp[cnt] = Ld[i].get(); Xp[cnt] = Xv[i].get(); Tp[cnt] = Tv[i].get();
+      ll[cnt] = SB;
+      any_rem = any_rem || d[i] - j0 - dd[cnt] > 0;
+      ++cnt;
+    }
+    if (cnt == 0) break;
+    cholinv_batched(c, cnt, Ap, la, dd, Lp, ll, any_rem ? Xp : nullptr, ll, Tp, info_dev + J * 8);
+    for (int t = 0; t < cnt; ++t) {
+      const int i = idx[t];
+      const int64_t w = dd[t], rem = d[i] - j0 - w;
+      copy_lower(c, w, Lp[t], SB, Ap[t], la[t]);
+      if (rem <= 0) continue;
+      double* A21 = A[i] + (j0 + w) * lda[i] + j0;
+      DBuf tmp(c, rem * w);
+      gemm(c, false, true, rem, w, w, 1.0, A21, lda[i], Xp[t], SB, 0.0, tmp, w);                 // L21 = A21 L11^-T
+      copy2d(c, rem, w, tmp, w, A21, lda[i]);
+      gemm_ex(c, false, true, rem, rem, w, -1.0, tmp, w, tmp, w, 1.0, A[i] + (j0 + w) * lda[i] + (j0 + w), lda[i], nullptr, 0, true);
+    }
+  }
+  std::vector<int> got(nslots, 0x7fffffff);
+  // slots of (J, t) with t >= cnt of that super-step were never written: only read what cholinv_batched initialised
+  d2h(c, got.data(), info_dev, size_t(nslots) * sizeof(int));
+  dev_free(c, info_dev);
+  for (int i = 0; i < count; ++i) info[i] = 0;
+  for (int64_t J = 0; J < nsb; ++J) {
+    int cnt = 0;
+    for (int i = 0; i < count; ++i) {
+      if (J * SB >= d[i]) continue;
+      const int v = got[J * 8 + cnt];
+      if (v != 0x7fffffff && info[i] == 0) info[i] = int(J * SB) + v;
+      ++cnt;
+    }
+  }
 }
 
 static void potrf_lower_batched_new(ccz_ctx* c, int count, double* const* A, const int64_t* d, const int64_t* lda, int* info) {
-  // matrices up to 4096 columns advance together through the step kernels; wider ones one by one, super-blocked
-  std::vector<double*> As;
-  std::vector<int64_t> ds, lds_;
-  std::vector<int> idx;
+  // matrices up to 1024 columns go through the step kernels directly; wider ones super-blocked; both batched by 8
+  std::vector<double*> As, Ab;
+  std::vector<int64_t> ds, lds_, db, ldb_;
+  std::vector<int> idx, idb;
   for (int i = 0; i < count; ++i) {
-    if (d[i] <= 4096) { As.push_back(A[i]); ds.push_back(d[i]); lds_.push_back(lda[i]); idx.push_back(i); }
-    else info[i] = potrf_lower_superblocked(c, A[i], d[i], lda[i]);
+    if (d[i] <= 1024) { As.push_back(A[i]); ds.push_back(d[i]); lds_.push_back(lda[i]); idx.push_back(i); }
+    else { Ab.push_back(A[i]); db.push_back(d[i]); ldb_.push_back(lda[i]); idb.push_back(i); }
   }
   if (!As.empty()) {
     std::vector<int> inf(As.size(), 0);
     potrf_lower_batched_steps(c, int(As.size()), As.data(), ds.data(), lds_.data(), inf.data());
     for (size_t t = 0; t < idx.size(); ++t) info[idx[t]] = inf[t];
+  }
+  for (size_t b0 = 0; b0 < Ab.size(); b0 += 8) {
+    const int nbt = int(std::min<size_t>(8, Ab.size() - b0));
+    int inf[8];
+    potrf_lower_batched_sb(c, nbt, Ab.data() + b0, db.data() + b0, ldb_.data() + b0, inf);
+    for (int t = 0; t < nbt; ++t) info[idb[b0 + t]] = inf[t];
   }
 }
 
