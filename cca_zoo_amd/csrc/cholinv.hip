@@ -129,7 +129,9 @@ __device__ __forceinline__ double rsqrt_newton(double x) {
   return y;
 }
 
-typedef double v2f64 __attribute__((ext_vector_type(2)));
+// 16-byte reads of a buffer that is written through plain `double` lvalues: may_alias, or type-based alias analysis
+// may reorder / forward across the two access types
+typedef double v2f64 __attribute__((ext_vector_type(2), may_alias));
 
 // The multipliers of a step are 63 wave-uniform doubles from one LDS column: read as 32 ds_read_b128 (the column
 // starts at byte 528 j: 16-byte aligned) -- a single wave issues narrow LDS reads at a fifth of the array rate and the
@@ -242,6 +244,16 @@ struct CholInvBatch {
 // steps), the six blocks below the diagonal follow from 16 x 16 MFMA products, column j on wave j:
 //   X_ij = -X_ii sum_{t=j}^{i-1} L_it X_tj
 // ---------------------------------------------------------------------------
+// Lanes of ONE wave exchange data through LDS below.  LDS operations of a wave execute in order, but the COMPILER
+// reasons per thread: without a fence it forwards a thread's own earlier store to its later load of the same address
+// even though another lane has overwritten it in between (first version of chol_panel: rows 8..15 of every panel
+// kept the previous panel's values).  A wavefront-scope release/acquire pair is the (free) way to say "shared".
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <int Q>
 __device__ __forceinline__ void chol_panel(v4f64 (&acc)[4][4], int lane, double* Ls, double* Rd, double* PL, int& first_bad) {
   constexpr int C0 = 4 * Q, TJ0 = Q / 4, CL = C0 % 16;
@@ -253,10 +265,11 @@ __device__ __forceinline__ void chol_panel(v4f64 (&acc)[4][4], int lane, double*
 #pragma unroll
       for (int r = 0; r < 4; ++r) PL[(16 * ti + (lane >> 4) + 4 * r) * 4 + pc] = acc[ti][TJ0][r];
   }
+  wave_lds_sync();
   // 2. lane = row: its four panel values (rows above the panel's tile row were not written: never used)
-  const v2f64 p01 = *reinterpret_cast<const v2f64*>(PL + lane * 4);
-  const v2f64 p23 = *reinterpret_cast<const v2f64*>(PL + lane * 4 + 2);
-  double pv[4] = {p01[0], p01[1], p23[0], p23[1]};
+  // (plain double accesses on purpose: reading this buffer through a vector type while it is written through
+  // `double` lets type-based alias analysis forward the PREVIOUS panel's stores to the lanes that did not write)
+  double pv[4] = {PL[lane * 4 + 0], PL[lane * 4 + 1], PL[lane * 4 + 2], PL[lane * 4 + 3]};
   double l[4];
   // 3. four pivots: everything in registers, multipliers by v_readlane with constant lane numbers
 #pragma unroll
@@ -274,10 +287,10 @@ __device__ __forceinline__ void chol_panel(v4f64 (&acc)[4][4], int lane, double*
   // 4. L panel: column-major factor Ls[col][row] (final output) and the 64 x 4 operand image PL[row][0..3]
 #pragma unroll
   for (int t = 0; t < 4; ++t) Ls[(C0 + t) * CLD + lane] = l[t];
-  v2f64 q01 = {l[0], l[1]}, q23 = {l[2], l[3]};
-  *reinterpret_cast<v2f64*>(PL + lane * 4) = q01;
-  *reinterpret_cast<v2f64*>(PL + lane * 4 + 2) = q23;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) PL[lane * 4 + t] = l[t];
   if (Q == 15) return;
+  wave_lds_sync();
   // 5. acc[ti][tj] -= L[rows of ti][panel] L[rows of tj][panel]'   (A fragment: (m = lane & 15, k = lane >> 4);
   //    the B fragment of tile column tj is the A fragment of tile row tj)
   double a[4];
@@ -288,6 +301,7 @@ __device__ __forceinline__ void chol_panel(v4f64 (&acc)[4][4], int lane, double*
 #pragma unroll
     for (int ti = tj; ti < 4; ++ti)
       acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[ti], a[tj], acc[ti][tj], 0, 0, 0);
+  wave_lds_sync();          // the next panel overwrites PL
 }
 
 template <int Q>
@@ -365,7 +379,7 @@ __device__ __forceinline__ void inv64_mfma(const double* Ls, const double* Rd, d
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) Xs[(16 * j + lr) * CLD + 16 * i + lk + 4 * r] = xacc[r];   // (L^-1)[16 i + lk + 4 r][16 j + lr]
-    // the next block row of this column reads what this wave has just written (same wave: in order)
+    wave_lds_sync();        // the next block row of this column reads what OTHER lanes of this wave have just written
   }
 }
 
