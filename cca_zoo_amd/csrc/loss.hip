@@ -15,8 +15,8 @@
 // (for m = 2 these are the G12, G11 + G11', G22 + G22' of the two-view closed form).  Launch sequence, all on the
 // handle's stream with no host synchronisation until the very end:
 //   K1 (pilot-shifted for fp32) -> prep (Ce, mean, per-view copies) -> batched Cholesky + inverse (cholinv.hip,
-//   d/64 + 1 launches for all views together) -> 4 batched 64-tile GEMM launches (Sinv; A; Gamma = -2 M / (n-1);
-//   the diagonal correction) -> loss reduction -> ONE sample-side GEMM (Z - mean) Gamma on the fp32 MFMA pipe.
+//   d/64 + 1 launches for all views together) -> 4 batched 64-tile GEMM launches (Sinv_a; A_ab; Gamma_ab;
+//   Gamma_aa = -sum_b A_ab Gamma_ba) -> loss reduction -> ONE sample-side GEMM (Z - mean) Gamma on the fp32 MFMA pipe.
 // The previous formulation (blocked potrf + two triangular solves against the identity + 14 GEMMs + a host round
 // trip for the loss value) was ~70 dependent launches and 3.1 ms at batch 8192, 2 x 512.
 #include <cmath>
@@ -88,21 +88,6 @@ __global__ void k_loss_finish(const double* __restrict__ acc, int dtype, void* _
   if (out64) *out64 = l;
 }
 
-struct SubArgs {
-  int64_t off[LMAXV + 1];
-  const double* t[LMAXV];
-  int m;
-};
-// Gamma_aa -= T_a   (T_a = A[a, :] Gamma[:, a], formed into scratch so that no product reads a block while it changes)
-__global__ void k_sub_blocks(double* __restrict__ Gm, int64_t D, SubArgs sa) {
-  const int a = blockIdx.y;
-  const int64_t da = sa.off[a + 1] - sa.off[a], o = sa.off[a];
-  for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < da * da; e += int64_t(gridDim.x) * blockDim.x) {
-    const int64_t i = e / da, j = e - i * da;
-    Gm[(o + i) * D + o + j] -= sa.t[a][e];
-  }
-}
-
 // bias[j] += sum over a 64-row slab of mean_i Gamma_ij  (bias zeroed by k_loss_prep); grid (D / 64, D / 64)
 __global__ __launch_bounds__(256) void k_bias_row(const double* __restrict__ Gm, const double* __restrict__ mean, int64_t D,
                                                   double* __restrict__ bias) {
@@ -156,7 +141,7 @@ void fused_core(ccz_ctx* c, const double* mom, int64_t n, const int64_t* dims, i
   const int64_t D = off[m];
   const double inv = 1.0 / double(n - 1);
   DBuf Ce(c, D * D), Am(c, D * D);
-  std::vector<DBuf> work(m), Lf(m), X(m), T(m), Sinv(m), Tcorr(m);
+  std::vector<DBuf> work(m), Lf(m), X(m), T(m), Sinv(m);
   PrepArgs pa{};
   pa.m = m;
   for (int a = 0; a <= m; ++a) pa.off[a] = off[a];
@@ -164,7 +149,6 @@ void fused_core(ccz_ctx* c, const double* mom, int64_t n, const int64_t* dims, i
     const int64_t d = dims[a], nblk = (d + 63) / 64;
     work[a] = DBuf(c, d * d); Lf[a] = DBuf(c, d * d); X[a] = DBuf(c, d * d); Sinv[a] = DBuf(c, d * d);
     T[a] = DBuf(c, nblk * 4096);
-    if (want_grad) Tcorr[a] = DBuf(c, d * d);
     pa.work[a] = work[a].get();
   }
   hipLaunchKernelGGL(k_loss_prep, dim3((unsigned)std::min<int64_t>((D * D + 255) / 256, 4096)), dim3(256), 0, st, mom, mom + D * D, D,
@@ -176,36 +160,47 @@ void fused_core(ccz_ctx* c, const double* mom, int64_t n, const int64_t* dims, i
     for (int a = 0; a < m; ++a) { Ap[a] = work[a].get(); Lp[a] = Lf[a].get(); Xp[a] = X[a].get(); Tp[a] = T[a].get(); }
     cholinv_batched(c, m, Ap.data(), ld.data(), ld.data(), Lp.data(), ld.data(), Xp.data(), ld.data(), Tp.data(), info_dev);
   }
-  std::vector<MultiGemmArgs> pr(m);
+  // Only the blocks that are not trivially known are formed: A_aa = I is never computed, Gamma's diagonal blocks come
+  // straight from  Gamma_aa = -sum_{b != a} A_ab Gamma_ba  ( = 2/(n-1) ((A M)_aa - M_aa) ).
+  auto launch = [&](std::vector<MultiGemmArgs>& v) {
+    for (size_t i0 = 0; i0 < v.size(); i0 += 8) gemm_f64_multi(c, int(std::min<size_t>(8, v.size() - i0)), v.data() + i0);
+  };
+  std::vector<MultiGemmArgs> pr;
   // Sinv_a = X_a' X_a   (X lower triangular: the K loop starts at the diagonal; the blocks of X above it -- never
   // written by cholinv -- are never read)
   for (int a = 0; a < m; ++a)
-    pr[a] = MultiGemmArgs{X[a], X[a], Sinv[a], nullptr, dims[a], dims[a], dims[a], 0, dims[a], dims[a], dims[a], true, false, false, 1.0, 0.0, true};
-  gemm_f64_multi(c, m, pr.data());
-  // A[a, :] = Sinv_a Ce[a, :]
+    pr.push_back(MultiGemmArgs{X[a], X[a], Sinv[a], nullptr, dims[a], dims[a], dims[a], 0, dims[a], dims[a], dims[a], true, false, false, 1.0, 0.0, true});
+  launch(pr);
+  // A_ab = Sinv_a Ce_ab   (a != b)
+  pr.clear();
   for (int a = 0; a < m; ++a)
-    pr[a] = MultiGemmArgs{Sinv[a], Ce.get() + off[a] * D, Am.get() + off[a] * D, nullptr, dims[a], D, D, 0, dims[a], D, dims[a], false, false, false, 1.0, 0.0};
-  gemm_f64_multi(c, m, pr.data());
+    for (int b = 0; b < m; ++b)
+      if (a != b)
+        pr.push_back(MultiGemmArgs{Sinv[a], Ce.get() + off[a] * D + off[b], Am.get() + off[a] * D + off[b], nullptr, dims[a], D, D, 0,
+                                   dims[a], dims[b], dims[a], false, false, false, 1.0, 0.0});
+  launch(pr);
   hipLaunchKernelGGL(k_trace_sq, dim3((unsigned)std::min<int64_t>((D * D + 255) / 256, 1024)), dim3(256), 0, st, Am.get(), D, pa, acc_dev);
   CCZ_LAUNCH_CHECK();
   if (!want_grad) return;
-  // Gamma[:, b] = -2/(n-1) A[:, b] Sinv_b
-  for (int b = 0; b < m; ++b)
-    pr[b] = MultiGemmArgs{Am.get() + off[b], Sinv[b], gamma_dev + off[b], nullptr, D, dims[b], D, 0, D, dims[b], dims[b], false, false, false, -2.0 * inv, 0.0};
-  gemm_f64_multi(c, m, pr.data());
-  // T_a = A[a, :] Gamma[:, a];  Gamma_aa -= T_a     ( = + 2/(n-1) (A M)_aa )
-  SubArgs sa{};
-  sa.m = m;
-  for (int a = 0; a <= m; ++a) sa.off[a] = off[a];
-  int64_t dmax = 0;
-  for (int a = 0; a < m; ++a) {
-    pr[a] = MultiGemmArgs{Am.get() + off[a] * D, gamma_dev + off[a], Tcorr[a], nullptr, D, D, dims[a], 0, dims[a], dims[a], D, false, false, false, 1.0, 0.0};
-    sa.t[a] = Tcorr[a].get();
-    dmax = std::max(dmax, dims[a]);
+  // Gamma_ab = -2/(n-1) A_ab Sinv_b   (a != b)
+  pr.clear();
+  for (int a = 0; a < m; ++a)
+    for (int b = 0; b < m; ++b)
+      if (a != b)
+        pr.push_back(MultiGemmArgs{Am.get() + off[a] * D + off[b], Sinv[b], gamma_dev + off[a] * D + off[b], nullptr, D, dims[b], D, 0,
+                                   dims[a], dims[b], dims[b], false, false, false, -2.0 * inv, 0.0});
+  launch(pr);
+  // Gamma_aa = -sum_{b != a} A_ab Gamma_ba : one launch per offset s (b = a + s mod m), so that no two problems of a
+  // launch write the same block; the first one overwrites, the others accumulate
+  for (int sft = 1; sft < m; ++sft) {
+    pr.clear();
+    for (int a = 0; a < m; ++a) {
+      const int b = (a + sft) % m;
+      pr.push_back(MultiGemmArgs{Am.get() + off[a] * D + off[b], gamma_dev + off[b] * D + off[a], gamma_dev + off[a] * D + off[a], nullptr,
+                                 D, D, D, 0, dims[a], dims[a], dims[b], false, false, false, -1.0, sft > 1 ? 1.0 : 0.0});
+    }
+    launch(pr);
   }
-  gemm_f64_multi(c, m, pr.data());
-  hipLaunchKernelGGL(k_sub_blocks, dim3((unsigned)std::min<int64_t>((dmax * dmax + 255) / 256, 1024), (unsigned)m), dim3(256), 0, st,
-                     gamma_dev, D, sa);
   if (bias_dev)
     hipLaunchKernelGGL(k_bias_row, dim3((unsigned)((D + 63) / 64), (unsigned)((D + 63) / 64)), dim3(256), 0, st, gamma_dev, mean_dev, D, bias_dev);
   CCZ_LAUNCH_CHECK();
@@ -312,20 +307,21 @@ void cca_loss_impl(ccz_ctx* c, int dtype, const void* z1, const void* z2, int64_
                       gemm_f32_fifo_split_eligible(n, D, D, d1, g1, ldg1, g2, ldg2);
     void* zcat = nullptr;
     ccz_view views[2] = {{z1, d1, ld1}, {z2, d2, ld2}};
+    int nviews = 2;
     if (fifo) {
       zcat = dev_alloc(c, size_t(n) * D * es);
       CCZ_HIP(hipMemcpy2DAsync(zcat, size_t(D) * es, z1, size_t(ld1) * es, size_t(d1) * es, size_t(n), hipMemcpyDeviceToDevice, st));
       CCZ_HIP(hipMemcpy2DAsync(static_cast<char*>(zcat) + size_t(d1) * es, size_t(D) * es, z2, size_t(ld2) * es, size_t(d2) * es, size_t(n),
                                hipMemcpyDeviceToDevice, st));
-      views[0] = ccz_view{zcat, d1, D};
-      views[1] = ccz_view{static_cast<char*>(zcat) + size_t(d1) * es, d2, D};
+      views[0] = ccz_view{zcat, D, D};                        // one n x D view: one column-sum launch, same tiles
+      nviews = 1;
     }
     // Gamma and, as row D of the same buffer, the bias row mean' Gamma (the centring of the batch)
     DBuf mom(c, D * D + D), gamma(c, want ? (D + 1) * D : 0), mean(c, D), acc(c, 1);
     int* info_dev = static_cast<int*>(dev_alloc(c, LMAXV * sizeof(int)));
     // embeddings (post-ReLU, un-normalised) routinely sit far from zero: always take the pilot-shifted Gram for
     // fp32 -- no host read-back, and at batch sizes the staged kernel costs the same as the FIFO one
-    moments_impl(c, dtype, views, 2, n, true, mom, false, dtype == CCZ_F32 ? 2 : 0, false);
+    moments_impl(c, dtype, views, nviews, n, true, mom, false, dtype == CCZ_F32 ? 2 : 0, false);
     fused_core(c, mom, n, dims, 2, eps, want, acc, gamma, mean, info_dev, want ? gamma.get() + D * D : nullptr);
     hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(1), 0, st, acc.get(), dtype, loss_dev, static_cast<double*>(nullptr));
     CCZ_LAUNCH_CHECK();
