@@ -224,3 +224,36 @@ def test_offset_golden_pins_the_oracle_and_the_estimators(host_handle):
         for i, w in enumerate(model.weights_):
             assert w.dtype == np.float32 and col_rel_err(w, g[f"{tag}/w{i}"].astype(np.float64)) < 1e-4
         np.testing.assert_allclose(model.score(train), g[f"{tag}/score_train"], atol=1e-4)
+
+
+def _all_model_classes():
+    import cca_zoo_amd.linear as lin
+    from cca_zoo_amd._base import BaseModel
+
+    return [getattr(lin, n) for n in getattr(lin, "__all__", dir(lin))
+            if isinstance(getattr(lin, n), type) and issubclass(getattr(lin, n), BaseModel) and getattr(lin, n) is not BaseModel]
+
+
+@pytest.mark.parametrize("check_name", ["check_no_attributes_set_in_init", "check_get_params_invariance", "check_set_params",
+                                        "check_estimator_repr"])
+def test_sklearn_estimator_contract_sweep(check_name):
+    """The reference's sklearn-compat sweep (tests/test_sklearn_compat.py:61-75): the four scikit-learn checks that only
+    touch the constructor / get_params / set_params / repr, over every estimator class the package exports."""
+    import sklearn.utils.estimator_checks as ec
+
+    classes = _all_model_classes()
+    assert {"CCA", "rCCA", "PLS", "MCCA", "GCCA", "PartialCCA", "GRCCA"} <= {c.__name__ for c in classes}
+    check = getattr(ec, check_name)
+    for cls in classes:
+        check(cls.__name__, cls())
+
+
+def test_grid_search_generic_route_refuses_row_shards(monkeypatch):
+    from cca_zoo_amd import _dist
+    from cca_zoo_amd.linear import rCCA
+    from cca_zoo_amd.model_selection import GridSearchCV
+
+    monkeypatch.setattr(_dist, "is_sharded", lambda: True)
+    views = _data(9, 60, (5, 4), 2)
+    with pytest.raises(NotImplementedError, match="row_sharded"):
+        GridSearchCV(rCCA(latent_dimensions=1), {"c": [0.1]}, cv=3, scoring="r2")._fit_generic(views)
