@@ -16,10 +16,10 @@ and a candidate ``(lam, V)`` is the wanted eigen-system iff
     (1) the residual  A V - B V diag(lam)  vanishes,
     (2) V' B V = I,
     (3) exactly k eigenvalues of the pencil exceed ``lam_k (1 - delta)``   -- Sylvester's law of inertia on
-        ``A - sigma B`` through one symmetric-indefinite factorization (LAPACK sytrf via ``scipy.linalg.ldl``).
+        ``A - sigma B`` through one symmetric-indefinite factorization (LAPACK ``dsytrf``, ``_count_positive``).
 
 (1)-(2) cost D^2 k flops, (3) one D^3/3 factorization: seconds where the full eigen-solve takes minutes.
-``tests/test_certificates.py`` checks on small problems that the oracle's own solutions pass and that perturbed ones
+``tests/test_round2_host.py`` checks on small problems that the oracle's own solutions pass and that perturbed ones
 fail.
 """
 
