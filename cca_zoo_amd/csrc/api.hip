@@ -101,6 +101,8 @@ int ccz_destroy(ccz_handle h) {
       if (im->small_pin[i]) (void)hipHostFree(im->small_pin[i]);
     }
     if (im->copy_stream) (void)hipStreamDestroy(im->copy_stream);
+    for (int i = 0; i < 2; ++i) if (im->aux_ev[i]) (void)hipEventDestroy(im->aux_ev[i]);
+    if (im->aux_stream) (void)hipStreamDestroy(im->aux_stream);
     (void)hipFree(im->d_flag);
     (void)hipFree(im->d_small);
     delete im;

@@ -684,6 +684,7 @@ struct MultiGemm {
   int tA[MG_MAX], tB[MG_MAX];
   int lower_only[MG_MAX];  // skip tiles strictly above the diagonal (symmetric results; C square)
   int k_lower[MG_MAX];     // op(A) = X', op(B) = X with X lower triangular: only k >= max(m0, n0) contributes
+  int ksplit[MG_MAX];      // > 1: the K range is cut into this many slices, C += alpha * (slice product) atomically
   double alpha[MG_MAX], beta[MG_MAX];
   int first[MG_MAX + 1];
   int count;
@@ -699,7 +700,9 @@ __global__ __launch_bounds__(256) void k_gemm_f64_multi(MultiGemm g) {
   const int item = int(blockIdx.x) - g.first[p];
   const int M = g.M[p], N = g.N[p], K = g.K[p];
   const int tn = (N + CB - 1) / CB;
-  const int bm = item / tn, bn = item % tn;
+  const int ks = g.ksplit[p];
+  const int tile = item / ks, slice = item - tile * ks;
+  const int bm = tile / tn, bn = tile % tn;
   if (g.lower_only[p] && bn > bm) return;
   const int m0 = bm * CB, n0 = bn * CB;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -708,14 +711,21 @@ __global__ __launch_bounds__(256) void k_gemm_f64_multi(MultiGemm g) {
   const int64_t lda = g.lda[p], ldb = g.ldb[p];
   const bool tA = g.tA[p] != 0, tB = g.tB[p] != 0;
   const int rows_m = min(CB, M - m0), cols_n = min(CB, N - n0);
-  const int k_first = g.k_lower[p] ? max(m0, n0) : 0;
+  int k_first = g.k_lower[p] ? max(m0, n0) : 0;
+  int K_end = K;
+  if (ks > 1) {                                            // this slice's run of 64-wide K chunks
+    const int nch = (K - k_first + CB - 1) / CB, per = (nch + ks - 1) / ks;
+    k_first += slice * per * CB;
+    K_end = min(K, k_first + per * CB);
+    if (k_first >= K_end) return;
+  }
   v4f64 acc[4];
   acc_zero(acc);
   // As[m][k], Bs[k][n] regardless of the storage order of the operands; chunk i + 1 is fetched into registers while
   // chunk i is multiplied out of LDS, and lands in the other LDS tile pair (one barrier per chunk)
   TileRegs ra, rb;
   auto fetch = [&](int k0) {
-    const int kc = min(CB, K - k0);
+    const int kc = min(CB, K_end - k0);
     if (!tA) fetch_tile(ra, A + int64_t(m0) * lda + k0, lda, rows_m, kc, tid);
     else fetch_tile(ra, A + int64_t(k0) * lda + m0, lda, kc, rows_m, tid);
     if (!tB) fetch_tile(rb, B + int64_t(k0) * ldb + n0, ldb, kc, cols_n, tid);
@@ -727,14 +737,14 @@ __global__ __launch_bounds__(256) void k_gemm_f64_multi(MultiGemm g) {
     if (!tA) store_tile<false>(As, ra, tid); else store_tile<true>(As, ra, tid);
     if (!tB) store_tile<false>(Bs, rb, tid); else store_tile<true>(Bs, rb, tid);
   };
-  if (k_first < K) {
+  if (k_first < K_end) {
     fetch(k_first);
     stash(0);
   }
   __syncthreads();
   int buf = 0;
-  for (int k0 = k_first; k0 < K; k0 += CB) {
-    const bool more = k0 + CB < K;
+  for (int k0 = k_first; k0 < K_end; k0 += CB) {
+    const bool more = k0 + CB < K_end;
     if (more) fetch(k0 + CB);
     tile_mm<false, false>(lds + buf * 2 * CTILE, lds + buf * 2 * CTILE + CTILE, w, lane, acc);
     if (more) stash(buf ^ 1);          // the other pair: nobody reads it during this chunk
@@ -752,6 +762,10 @@ __global__ __launch_bounds__(256) void k_gemm_f64_multi(MultiGemm g) {
       const int rr = 16 * w + (lane >> 4) + 4 * rg, cc = 16 * t + (lane & 15);
       if (rr < rows_m && cc < cols_n) {
         double v = alpha * acc[t][rg];
+        if (ks > 1) {
+          atomicAdd(C + int64_t(m0 + rr) * ldc + n0 + cc, v);
+          continue;
+        }
         if (C) {
           double* q = C + int64_t(m0 + rr) * ldc + n0 + cc;
           if (beta != 0.0) v += beta * *q;
@@ -777,9 +791,11 @@ void gemm_f64_multi(ccz_ctx* c, int count, const MultiGemmArgs* pr) {
     g.tA[i] = a.tA ? 1 : 0; g.tB[i] = a.tB ? 1 : 0;
     g.lower_only[i] = a.lower_only ? 1 : 0;
     g.k_lower[i] = a.k_lower ? 1 : 0;
+    g.ksplit[i] = std::max(1, a.ksplit);
+    if (g.ksplit[i] > 1 && (a.beta != 1.0 || a.Ct || !a.C)) fail(CCZ_EINVAL, "gemm_f64_multi: split-K accumulates into C (beta = 1, no Ct)");
     g.alpha[i] = a.alpha; g.beta[i] = a.beta;
     g.first[i] = total;
-    total += int((a.M + CB - 1) / CB) * int((a.N + CB - 1) / CB);
+    total += int((a.M + CB - 1) / CB) * int((a.N + CB - 1) / CB) * g.ksplit[i];
   }
   g.first[count] = total;
   cholinv_attr_once();

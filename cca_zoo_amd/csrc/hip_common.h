@@ -46,6 +46,9 @@ struct Impl {
   void* small_pin[kSmallSlots] = {};
   hipEvent_t small_ev[kSmallSlots] = {};
   int small_next = 0;
+  // second stream + events for the look-ahead of the super-blocked Cholesky (ops_hip.hip), created on first use
+  hipStream_t aux_stream = nullptr;
+  hipEvent_t aux_ev[2] = {nullptr, nullptr};
 };
 
 inline Impl* impl(ccz_ctx* c) { return static_cast<Impl*>(c->impl); }
@@ -116,6 +119,7 @@ struct MultiGemmArgs {
   bool tA, tB, lower_only;
   double alpha, beta;
   bool k_lower = false;    // op(A) = X', op(B) = X, X lower triangular (blocks above the diagonal are never read)
+  int ksplit = 1;          // > 1: K cut into slices over extra workgroups, C += alpha * product atomically (beta must be 1)
 };
 void gemm_f64_multi(ccz_ctx* c, int count, const MultiGemmArgs* problems);
 

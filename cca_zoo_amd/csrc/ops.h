@@ -104,6 +104,15 @@ void potrf_lower_batched(ccz_ctx* c, int count, double* const* A, const int64_t*
 // X (r x d) <- X L^-T (trans) or X L^-1 (!trans); L lower triangular d x d
 void trsm_right_lower(ccz_ctx* c, bool trans, int64_t r, int64_t d, const double* L, int64_t ldl,
                       double* X, int64_t ldx);
+// Factor-time by-products for later triangular solves with the same factor.  trsm_aux_size(d): doubles of auxiliary
+// storage per matrix (0: this backend / size keeps none).  potrf_lower_batched_aux fills aux[b] (when non-null) next
+// to the factor; trsm_right_lower_aux(aux != null) then skips recomputing them.  (HIP backend: the explicit inverses
+// of the 512-column diagonal super-blocks, which the super-blocked factorization forms anyway.)
+int64_t trsm_aux_size(ccz_ctx* c, int64_t d);
+void potrf_lower_batched_aux(ccz_ctx* c, int count, double* const* A, const int64_t* d, const int64_t* lda, int* info,
+                             double* const* aux);
+void trsm_right_lower_aux(ccz_ctx* c, bool trans, int64_t r, int64_t d, const double* L, int64_t ldl, double* X,
+                          int64_t ldx, const double* aux);
 // out (cols x rows) = in (rows x cols)'
 void transpose(ccz_ctx* c, int64_t rows, int64_t cols, const double* in, int64_t ldi, double* out,
                int64_t ldo);
@@ -141,6 +150,13 @@ double norm_inf(ccz_ctx* c, int64_t rows, int64_t cols, const double* A, int64_t
 // used; throws ENOCONV beyond max_sweeps.
 int jacobi_rows(ccz_ctx* c, int64_t p, int64_t q, double* W, int64_t ldw, double* Q, int64_t qc,
                 int64_t ldq, int max_sweeps);
+// Two-sided Jacobi EVD of a small symmetric A (d x d, d <= syev_small_max(c); only read, symmetrised on load):
+// w_dev[i] = eigenvalue i (unsorted), row i of Vrows (d x d, ld ldv) = its eigenvector.  Needs no definiteness and no
+// shift.  Returns sweeps; throws EINVAL on non-finite input, ENOCONV beyond max_sweeps.  syev_small_max: largest
+// supported d (0: the backend has no such kernel).
+int syev_small_max(ccz_ctx* c);
+int syev_small(ccz_ctx* c, const double* A, int64_t d, int64_t lda, double* w_dev, double* Vrows, int64_t ldv,
+               int max_sweeps);
 // out[i] = dot(A[i,:], B[i,:]) for i < rows
 void row_dots(ccz_ctx* c, int64_t rows, int64_t cols, const double* A, int64_t lda,
               const double* B, int64_t ldb, double* out);

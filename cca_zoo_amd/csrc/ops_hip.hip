@@ -1102,51 +1102,162 @@ static void potrf_lower_batched_steps(ccz_ctx* c, int count, double* const* A, c
 // dependent launches is shared), panel and trailing update are 128-tile GEMMs with K = 512.  (The step kernels
 // alone on a 4096-column matrix are rank-64 updates of the whole trailing matrix -- HBM-bound, measured 8 ms for two
 // matrices; the super-blocked form moves 8x less.)  Pivot failures are collected at the end: one host read.
-static void potrf_lower_batched_sb(ccz_ctx* c, int count, double* const* A, const int64_t* d, const int64_t* lda, int* info) {
+//
+// Look-ahead: super-block J + 1 can be factored as soon as ITS diagonal block has received update J, i.e. after the
+// top 512 rows of panel J -- not after the whole trailing update.  The factorization is a latency chain on a handful
+// of workgroups, the rest of the update is throughput work, so the chain moves to a second stream and the two overlap:
+//   main:  copy L_JJ | panel top | diag (J+1,J+1) update | ev_a | panel rest | column J+1 | trailing rest | wait ev_b
+//   aux :                                      wait ev_a | factor + invert (J+1,J+1) ......................| ev_b
+// CCZ_POTRF_LOOKAHEAD=0 keeps everything on the handle's stream (same order of operations).
+//
+// keep[i] (optional, nsb * 512 * 512 doubles): receives the inverses of matrix i's diagonal super-blocks for later
+// triangular solves with the factor (trsm_right_lower_aux).
+static int potrf_lookahead() {
+  static const int m = [] { const char* e = getenv("CCZ_POTRF_LOOKAHEAD"); return e ? atoi(e) : 1; }();
+  return m;
+}
+
+struct StreamSwap {
+  ccz_ctx* c;
+  void* prev;
+  StreamSwap(ccz_ctx* c_, hipStream_t s) : c(c_), prev(c_->stream) { c->stream = s; }
+  ~StreamSwap() { c->stream = prev; }
+};
+
+static void potrf_lower_batched_sb(ccz_ctx* c, int count, double* const* A, const int64_t* d, const int64_t* lda, int* info,
+                                   double* const* keep) {
   if (count > 8) fail(CCZ_EUNSUP, "potrf_lower_batched_sb: at most 8 matrices per call");
+  Impl* im = impl(c);
   int64_t dmax = 0;
   for (int i = 0; i < count; ++i) dmax = std::max(dmax, d[i]);
   const int64_t nsb = (dmax + SB - 1) / SB;
   std::vector<DBuf> Ld(count), Xv(count), Tv(count);
   for (int i = 0; i < count; ++i) {
     Ld[i] = DBuf(c, SB * SB);
-    Xv[i] = DBuf(c, SB * SB);
     Tv[i] = DBuf(c, (SB / NB) * NB * NB);
-    zero(c, Xv[i], size_t(SB) * SB * 8);       // the panel products read whole blocks; the inverse rows overwrite the lower blocks
+    // the panel products read whole blocks; the inverse rows overwrite only the lower blocks
+    if (keep && keep[i]) {
+      zero(c, keep[i], size_t((d[i] + SB - 1) / SB) * SB * SB * 8);
+    } else {
+      Xv[i] = DBuf(c, 2 * SB * SB);       // two halves: factor(J + 1) writes one while update J still reads the other
+      zero(c, Xv[i], size_t(2) * SB * SB * 8);
+    }
   }
-  // info of super-step J of matrix i: slot J * 8 + i (all slots start at "no failure")
+  // info of super-step J of matrix i: slot J * 8 + (position among the matrices alive at J); all start at "no failure"
   const int nslots = int(nsb) * 8;
   int* info_dev = static_cast<int*>(dev_alloc(c, size_t(nslots) * sizeof(int)));
-  for (int64_t J = 0; J < nsb; ++J) {
+
+  hipStream_t s_main = stream(c), s_aux = s_main;
+  bool la = potrf_lookahead() != 0 && nsb > 1;
+  if (la) {
+    if (!im->aux_stream) {
+      hipStream_t st = nullptr;
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
+          hipEventCreateWithFlags(&e0, hipEventDisableTiming) == hipSuccess &&
+          hipEventCreateWithFlags(&e1, hipEventDisableTiming) == hipSuccess) {
+        im->aux_stream = st; im->aux_ev[0] = e0; im->aux_ev[1] = e1;
+      } else {
+        (void)hipGetLastError();
+        if (e0) (void)hipEventDestroy(e0);
+        if (st) (void)hipStreamDestroy(st);
+        la = false;
+      }
+    }
+    if (la) s_aux = im->aux_stream;
+  }
+
+  // diagonal super-block J of every matrix still alive: factor, invert (on the CURRENT c->stream)
+  auto factor = [&](int64_t J) {
     const int64_t j0 = J * SB;
     double* Ap[8]; double* Lp[8]; double* Xp[8]; double* Tp[8];
-    int64_t la[8], dd[8], ll[8];
-    int idx[8], cnt = 0;
-    bool any_rem = false;
+    int64_t la_[8], dd[8], ll[8];
+    int cnt = 0;
+    bool need_x = false;
     for (int i = 0; i < count; ++i) {
       if (j0 >= d[i]) continue;
-      idx[cnt] = i;
       Ap[cnt] = A[i] + j0 * lda[i] + j0;
-      la[cnt] = lda[i];
+      la_[cnt] = lda[i];
       dd[cnt] = std::min(SB, d[i] - j0);
-      Lp[cnt] = Ld[i].get(); Xp[cnt] = Xv[i].get(); Tp[cnt] = Tv[i].get();
+      Lp[cnt] = Ld[i].get();
+      Xp[cnt] = (keep && keep[i]) ? keep[i] + J * SB * SB : Xv[i].get() + (J & 1) * SB * SB;
+      Tp[cnt] = Tv[i].get();
       ll[cnt] = SB;
-      any_rem = any_rem || d[i] - j0 - dd[cnt] > 0;
+      need_x = need_x || (keep && keep[i]) || d[i] - j0 - dd[cnt] > 0;
       ++cnt;
     }
-    if (cnt == 0) break;
-    cholinv_batched(c, cnt, Ap, la, dd, Lp, ll, any_rem ? Xp : nullptr, ll, Tp, info_dev + J * 8);
-    for (int t = 0; t < cnt; ++t) {
-      const int i = idx[t];
-      const int64_t w = dd[t], rem = d[i] - j0 - w;
-      copy_lower(c, w, Lp[t], SB, Ap[t], la[t]);
-      if (rem <= 0) continue;
-      double* A21 = A[i] + (j0 + w) * lda[i] + j0;
-      DBuf tmp(c, rem * w);
-      gemm(c, false, true, rem, w, w, 1.0, A21, lda[i], Xp[t], SB, 0.0, tmp, w);                 // L21 = A21 L11^-T
-      copy2d(c, rem, w, tmp, w, A21, lda[i]);
-      gemm_ex(c, false, true, rem, rem, w, -1.0, tmp, w, tmp, w, 1.0, A[i] + (j0 + w) * lda[i] + (j0 + w), lda[i], nullptr, 0, true);
+    if (cnt > 0) cholinv_batched(c, cnt, Ap, la_, dd, Lp, ll, need_x ? Xp : nullptr, ll, Tp, info_dev + J * 8);
+  };
+
+  factor(0);
+  for (int64_t J = 0; J < nsb; ++J) {
+    const int64_t j0 = J * SB;
+    std::vector<DBuf> tmp(count);
+    // ---- the part super-block J + 1 waits for: top block of panel J and the update of diagonal block J + 1.
+    // Two 512^3 products per matrix -- far too small for a launch each (40 us on 64 workgroups): one batched,
+    // split-K launch per stage for all matrices (512 workgroups, ~12 us)
+    {
+      MultiGemmArgs top[8], dg[8];
+      int nt = 0;
+      for (int i = 0; i < count; ++i) {
+        if (j0 >= d[i]) continue;
+        const int64_t w = std::min(SB, d[i] - j0), rem = d[i] - j0 - w;
+        copy_lower(c, w, Ld[i], SB, A[i] + j0 * lda[i] + j0, lda[i]);
+        if (rem <= 0) continue;
+        const int64_t w1 = std::min(SB, rem);
+        const double* Xj = (keep && keep[i]) ? keep[i] + J * SB * SB : Xv[i].get() + (J & 1) * SB * SB;
+        tmp[i] = DBuf(c, rem * w);
+        zero(c, tmp[i], size_t(w1) * w * 8);
+        MultiGemmArgs& a = top[nt];                                                     // top of L21 = A21 L11^-T
+        a = MultiGemmArgs{};
+        a.A = A[i] + (j0 + w) * lda[i] + j0; a.lda = lda[i]; a.tA = false;
+        a.B = Xj; a.ldb = SB; a.tB = true;
+        a.C = tmp[i]; a.ldc = w; a.Ct = nullptr; a.ldct = 0;
+        a.M = w1; a.N = w; a.K = w; a.alpha = 1.0; a.beta = 1.0; a.lower_only = false; a.ksplit = 4;
+        MultiGemmArgs& b = dg[nt];                                                      // A(J+1,J+1) -= top top'
+        b = MultiGemmArgs{};
+        b.A = tmp[i]; b.lda = w; b.tA = false;
+        b.B = tmp[i]; b.ldb = w; b.tB = true;
+        b.C = A[i] + (j0 + w) * lda[i] + (j0 + w); b.ldc = lda[i]; b.Ct = nullptr; b.ldct = 0;
+        b.M = w1; b.N = w1; b.K = w; b.alpha = -1.0; b.beta = 1.0; b.lower_only = true; b.ksplit = 4;
+        ++nt;
+      }
+      if (nt > 0) {
+        gemm_f64_multi(c, nt, top);
+        gemm_f64_multi(c, nt, dg);
+      }
     }
+    if (J + 1 < nsb) {
+      if (la) {
+        CCZ_HIP(hipEventRecord(im->aux_ev[0], s_main));
+        CCZ_HIP(hipStreamWaitEvent(s_aux, im->aux_ev[0], 0));
+        {
+          StreamSwap sw(c, s_aux);
+          factor(J + 1);
+        }
+        CCZ_HIP(hipEventRecord(im->aux_ev[1], s_aux));
+      } else {
+        factor(J + 1);
+      }
+    }
+    // ---- the rest of update J (overlaps the factorization of super-block J + 1) ----
+    for (int i = 0; i < count; ++i) {
+      if (j0 >= d[i]) continue;
+      const int64_t w = std::min(SB, d[i] - j0), rem = d[i] - j0 - w;
+      if (rem <= 0) continue;
+      const int64_t w1 = std::min(SB, rem), rem2 = rem - w1;
+      const int64_t j1 = j0 + w;
+      copy2d(c, w1, w, tmp[i], w, A[i] + j1 * lda[i] + j0, lda[i]);                                  // top of L21 -> the factor
+      if (rem2 <= 0) continue;
+      double* A31 = A[i] + (j1 + w1) * lda[i] + j0;
+      double* t2 = tmp[i].get() + w1 * w;
+      const double* Xj = (keep && keep[i]) ? keep[i] + J * SB * SB : Xv[i].get() + (J & 1) * SB * SB;
+      gemm(c, false, true, rem2, w, w, 1.0, A31, lda[i], Xj, SB, 0.0, t2, w);                       // rest of L21
+      copy2d(c, rem2, w, t2, w, A31, lda[i]);
+      gemm(c, false, true, rem2, w1, w, -1.0, t2, w, tmp[i], w, 1.0, A[i] + (j1 + w1) * lda[i] + j1, lda[i]);   // column J + 1
+      gemm_ex(c, false, true, rem2, rem2, w, -1.0, t2, w, t2, w, 1.0, A[i] + (j1 + w1) * lda[i] + (j1 + w1), lda[i], nullptr, 0, true);
+    }
+    if (la && J + 1 < nsb) CCZ_HIP(hipStreamWaitEvent(s_main, im->aux_ev[1], 0));
   }
   std::vector<int> got(nslots, 0x7fffffff);
   // slots of (J, t) with t >= cnt of that super-step were never written: only read what cholinv_batched initialised
@@ -1164,14 +1275,15 @@ static void potrf_lower_batched_sb(ccz_ctx* c, int count, double* const* A, cons
   }
 }
 
-static void potrf_lower_batched_new(ccz_ctx* c, int count, double* const* A, const int64_t* d, const int64_t* lda, int* info) {
+static void potrf_lower_batched_new(ccz_ctx* c, int count, double* const* A, const int64_t* d, const int64_t* lda, int* info,
+                                    double* const* aux = nullptr) {
   // matrices up to 1024 columns go through the step kernels directly; wider ones super-blocked; both batched by 8
-  std::vector<double*> As, Ab;
+  std::vector<double*> As, Ab, Kb;
   std::vector<int64_t> ds, lds_, db, ldb_;
   std::vector<int> idx, idb;
   for (int i = 0; i < count; ++i) {
     if (d[i] <= 1024) { As.push_back(A[i]); ds.push_back(d[i]); lds_.push_back(lda[i]); idx.push_back(i); }
-    else { Ab.push_back(A[i]); db.push_back(d[i]); ldb_.push_back(lda[i]); idb.push_back(i); }
+    else { Ab.push_back(A[i]); db.push_back(d[i]); ldb_.push_back(lda[i]); idb.push_back(i); Kb.push_back(aux ? aux[i] : nullptr); }
   }
   if (!As.empty()) {
     std::vector<int> inf(As.size(), 0);
@@ -1181,38 +1293,45 @@ static void potrf_lower_batched_new(ccz_ctx* c, int count, double* const* A, con
   for (size_t b0 = 0; b0 < Ab.size(); b0 += 8) {
     const int nbt = int(std::min<size_t>(8, Ab.size() - b0));
     int inf[8];
-    potrf_lower_batched_sb(c, nbt, Ab.data() + b0, db.data() + b0, ldb_.data() + b0, inf);
+    potrf_lower_batched_sb(c, nbt, Ab.data() + b0, db.data() + b0, ldb_.data() + b0, inf, Kb.data() + b0);
     for (int t = 0; t < nbt; ++t) info[idb[b0 + t]] = inf[t];
   }
 }
 
-static void trsm_right_lower_sb(ccz_ctx* c, bool trans, int64_t r, int64_t d, const double* L, int64_t ldl, double* X, int64_t ldx) {
+static void trsm_right_lower_sb(ccz_ctx* c, bool trans, int64_t r, int64_t d, const double* L, int64_t ldl, double* X, int64_t ldx,
+                                const double* aux = nullptr) {
   const int64_t nblk = (d + NB - 1) / NB, nsb = (d + SB - 1) / SB;
-  DBuf invT(c, nblk * NB * NB), Xinv(c, nsb * SB * SB), tmp(c, r * SB);
-  diag_inverses(c, L, ldl, d, invT);                         // L_jj^-T of every 64-column block, one launch
-  zero(c, Xinv, size_t(nsb) * SB * SB * 8);                  // the products read whole super-blocks
-  for (int64_t J0 = 0; J0 < nsb; J0 += 8) {
-    const int cnt = int(std::min<int64_t>(8, nsb - J0));
-    const double* Lp[8];
-    const double* Tp[8];
-    double* Xp[8];
-    int64_t dd[8], l1[8], l2[8];
-    for (int t = 0; t < cnt; ++t) {
-      const int64_t j0 = (J0 + t) * SB;
-      Lp[t] = L + j0 * ldl + j0;
-      Tp[t] = invT.get() + (j0 / NB) * NB * NB;
-      Xp[t] = Xinv.get() + (J0 + t) * SB * SB;
-      dd[t] = std::min(SB, d - j0);
-      l1[t] = ldl;
-      l2[t] = SB;
+  DBuf tmp(c, r * SB), Xown;
+  const double* Xinv = aux;                                    // inverses of the diagonal super-blocks, kept by potrf
+  if (!Xinv) {
+    DBuf invT(c, nblk * NB * NB);
+    Xown = DBuf(c, nsb * SB * SB);
+    diag_inverses(c, L, ldl, d, invT);                         // L_jj^-T of every 64-column block, one launch
+    zero(c, Xown, size_t(nsb) * SB * SB * 8);                  // the products read whole super-blocks
+    for (int64_t J0 = 0; J0 < nsb; J0 += 8) {
+      const int cnt = int(std::min<int64_t>(8, nsb - J0));
+      const double* Lp[8];
+      const double* Tp[8];
+      double* Xp[8];
+      int64_t dd[8], l1[8], l2[8];
+      for (int t = 0; t < cnt; ++t) {
+        const int64_t j0 = (J0 + t) * SB;
+        Lp[t] = L + j0 * ldl + j0;
+        Tp[t] = invT.get() + (j0 / NB) * NB * NB;
+        Xp[t] = Xown.get() + (J0 + t) * SB * SB;
+        dd[t] = std::min(SB, d - j0);
+        l1[t] = ldl;
+        l2[t] = SB;
+      }
+      trinv_batched(c, cnt, Lp, l1, dd, Xp, l2, Tp);
     }
-    trinv_batched(c, cnt, Lp, l1, dd, Xp, l2, Tp);
+    Xinv = Xown.get();
   }
   if (trans) {
     // X L' = B, forward over the super-blocks:  X_J = (B_J - sum_{t<J} X_t L_Jt') L_JJ^-T
     for (int64_t J = 0; J < nsb; ++J) {
       const int64_t j0 = J * SB, w = std::min(SB, d - j0), rem = d - j0 - w;
-      gemm(c, false, true, r, w, w, 1.0, X + j0, ldx, Xinv.get() + J * SB * SB, SB, 0.0, tmp, SB);
+      gemm(c, false, true, r, w, w, 1.0, X + j0, ldx, Xinv + J * SB * SB, SB, 0.0, tmp, SB);
       copy2d(c, r, w, tmp, SB, X + j0, ldx);
       if (rem > 0) gemm(c, false, true, r, rem, w, -1.0, tmp, SB, L + (j0 + w) * ldl + j0, ldl, 1.0, X + j0 + w, ldx);
     }
@@ -1220,7 +1339,7 @@ static void trsm_right_lower_sb(ccz_ctx* c, bool trans, int64_t r, int64_t d, co
     // X L = B, backward:  X_J = (B_J - sum_{t>J} X_t L_tJ) L_JJ^-1
     for (int64_t J = nsb - 1; J >= 0; --J) {
       const int64_t j0 = J * SB, w = std::min(SB, d - j0);
-      gemm(c, false, false, r, w, w, 1.0, X + j0, ldx, Xinv.get() + J * SB * SB, SB, 0.0, tmp, SB);
+      gemm(c, false, false, r, w, w, 1.0, X + j0, ldx, Xinv + J * SB * SB, SB, 0.0, tmp, SB);
       copy2d(c, r, w, tmp, SB, X + j0, ldx);
       if (j0 > 0) gemm(c, false, false, r, j0, w, -1.0, tmp, SB, L + j0 * ldl, ldl, 1.0, X, ldx);
     }
@@ -1246,6 +1365,24 @@ void potrf_lower_batched(ccz_ctx* c, int count, double* const* A, const int64_t*
   const int mode = solver_mode();
   if (mode == 1 || (mode < 0 && dmax >= 6144)) potrf_lower_batched_rec(c, count, A, d, lda, info);
   else potrf_lower_batched_iter(c, count, A, d, lda, info);
+}
+
+int64_t trsm_aux_size(ccz_ctx*, int64_t d) {
+  if (solver_legacy() || d <= 1024) return 0;
+  return (d + SB - 1) / SB * SB * SB;
+}
+
+void potrf_lower_batched_aux(ccz_ctx* c, int count, double* const* A, const int64_t* d, const int64_t* lda, int* info,
+                             double* const* aux) {
+  if (solver_legacy() || !aux) { potrf_lower_batched(c, count, A, d, lda, info); return; }
+  potrf_lower_batched_new(c, count, A, d, lda, info, aux);
+}
+
+void trsm_right_lower_aux(ccz_ctx* c, bool trans, int64_t r, int64_t d, const double* L, int64_t ldl, double* X,
+                          int64_t ldx, const double* aux) {
+  if (r <= 0 || d <= 0) return;
+  if (aux && !solver_legacy() && d > 1024) { trsm_right_lower_sb(c, trans, r, d, L, ldl, X, ldx, aux); return; }
+  trsm_right_lower(c, trans, r, d, L, ldl, X, ldx);
 }
 
 void trsm_right_lower(ccz_ctx* c, bool trans, int64_t r, int64_t d, const double* L, int64_t ldl, double* X,
@@ -1430,6 +1567,252 @@ int jacobi_rows(ccz_ctx* c, int64_t p, int64_t q, double* W, int64_t ldw, double
     if (rot == 0) return sweep;
   }
   fail(CCZ_ENOCONV, "Jacobi did not converge in %d sweeps (p=%lld, q=%lld)", max_sweeps, (long long)p, (long long)q);
+}
+
+// ===========================================================================
+// Two-sided (classical) Jacobi for the small symmetric eigenproblems of the Rayleigh-Ritz steps (d <= 96)
+// ===========================================================================
+// The one-sided kernel above spends a round on three length-d inner products per row pair before it can rotate;
+// on a symmetric H the rotation of pair (p, q) follows from h_pp, h_qq, h_pq alone, and one round of the tournament
+// (d/2 disjoint pairs) is   H <- J' H J,  V' <- J' V'   with J = product of the round's rotations: every 2 x 2 block
+// (row pair a, column pair b) becomes R_a' M R_b independently of all others.  One workgroup, H and V' in LDS, a
+// two-stage pipeline per round (parameters double-buffered):
+//   A: all 16 waves apply round g to H                                                  | barrier
+//   B: wave 0 derives the parameters of round g + 1 from the new H  ||  waves 1..15 apply round g to V'   | barrier
+// Every thread owns the same blocks / V' items in every round and gets the round's row indices by two integer
+// adds (the tournament shifts positions by one per round): no index tables, no divisions inside the loop, one level
+// of LDS latency per stage.  The long-latency part of a round is wave 0's (sqrt, divide, reciprocal sqrt) chain: done
+// with v_rsq / v_rcp seeds and two Newton steps each (~200 cycles instead of ~550 for the IEEE expansions).
+// Stopping: a sweep without a rotation; a pair is rotated when |h_pq| > tol * max|H| (absolute: the Rayleigh-Ritz
+// matrices are indefinite, zero diagonals happen -- MCCA with two views has exact +lam / -lam pairs).
+// Rows/columns are padded to an even count; the pad row/column is zero and stays zero (its pair never rotates).
+__device__ __forceinline__ double rsq_nr(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  return y;
+}
+__device__ __forceinline__ double rsq_nr3(double x) {      // the cosine: c^2 + s^2 = 1 must hold to rounding
+  double y = rsq_nr(x);
+  return y * fma(-0.5 * x * y, y, 1.5);
+}
+__device__ __forceinline__ double rcp_nr(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = y * fma(-x, y, 2.0);
+  y = y * fma(-x, y, 2.0);
+  return y;
+}
+typedef double jac_cs __attribute__((ext_vector_type(2)));   // (cosine, sine) of one rotation
+__device__ __forceinline__ void pair_of(int round, int k, int m1, int& a, int& b) {
+  if (k == 0) { a = m1; b = round; return; }
+  a = round + k; if (a >= m1) a -= m1;
+  b = round - k; if (b < 0) b += m1;
+}
+
+template <int NB_, int NV_>   // H blocks / V' items per thread (compile-time: the slot arrays must stay in registers)
+__device__ __forceinline__ void syev_small_body(char* smem, int d, const double* __restrict__ A, int64_t lda, double* __restrict__ w,
+                                                double* __restrict__ Vt, int64_t ldv, double tol, int max_sweeps,
+                                                int* __restrict__ status) {
+  const int pe = (d + 1) & ~1, m1 = pe - 1, np = pe >> 1, sd = pe | 1;
+  double* Hs = reinterpret_cast<double*>(smem);
+  double* Vs = Hs + pe * sd;
+  double* red = Vs + pe * sd;                              // 16 wave maxima
+  int* rot = reinterpret_cast<int*>(red + 16);             // [2]: rotations of the even / odd sweeps (+ 2 ints of padding)
+  jac_cs* csn = reinterpret_cast<jac_cs*>(red + 18);       // [2][np] (cosine, sine), 16-byte aligned: (2 pe sd + 18) is even
+  const int tid = threadIdx.x, nt = blockDim.x;            // nt == 1024
+  double mx = 0.0;
+  for (int i = tid; i < pe * pe; i += nt) {
+    const int r = i / pe, c = i - r * pe;
+    double h = 0.0;
+    if (r < d && c < d) {
+      h = 0.5 * (A[int64_t(r) * lda + c] + A[int64_t(c) * lda + r]);
+      const double a = fabs(h);
+      mx = (a <= 1.79769313486231570e308) ? fmax(mx, a) : __builtin_inf();   // NaN / inf poison the maximum
+    }
+    Hs[r * sd + c] = h;
+    Vs[r * sd + c] = (r == c && r < d) ? 1.0 : 0.0;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  if (tid < 2) rot[tid] = 0;
+  __syncthreads();
+  double hmax = 0.0;
+  for (int i = 0; i < (nt + 63) >> 6; ++i) hmax = fmax(hmax, red[i]);
+  if (!(hmax < __builtin_inf())) {
+    if (tid == 0) *status = -2;
+    return;
+  }
+  if (hmax == 0.0) {                                       // the zero matrix: eigenvalues 0, V = I
+    for (int i = tid; i < d; i += nt) w[i] = 0.0;
+    for (int i = tid; i < d * d; i += nt) Vt[int64_t(i / d) * ldv + i % d] = (i / d == i % d) ? 1.0 : 0.0;
+    if (tid == 0) *status = 1;
+    return;
+  }
+  const double thr = tol * hmax, ih = 1.0 / hmax;
+
+  // This thread's blocks of H and items of V': the same in every round.  np <= 48: at most 2304 blocks (3 per
+  // thread) and 48 * 96 = 4608 V' items on the 960 threads of waves 1..15 (5 per thread; d <= 80: 2 and 4).  Slots past the end are
+  // pointed at block / item 0 and masked at the store, so that every load below is unconditional.
+  const int nblk = np * np, nitem = np * d;
+  int bka[NB_], bkb[NB_];
+  bool bon[NB_];
+#pragma unroll
+  for (int j = 0; j < NB_; ++j) {
+    const int b = tid + j * nt;
+    bon[j] = b < nblk;
+    bka[j] = bon[j] ? b / np : 0;
+    bkb[j] = bon[j] ? b - bka[j] * np : 0;
+  }
+  const int vt = tid - 64, nvt = nt - 64;                  // waves 1..15 rotate V'
+  int vk[NV_], vr[NV_];
+  bool von[NV_];
+#pragma unroll
+  for (int j = 0; j < NV_; ++j) {
+    const int it = vt + j * nvt;
+    von[j] = vt >= 0 && it < nitem;
+    vk[j] = von[j] ? it / d : 0;
+    vr[j] = von[j] ? it - vk[j] * d : 0;
+  }
+
+  auto params = [&](int round, int buf, int sweep_parity) {              // lanes < np of wave 0
+    const int k = tid;
+    int a, b;
+    pair_of(round, k, m1, a, b);
+    const double hpq = Hs[a * sd + b], hqq = Hs[b * sd + b], hpp = Hs[a * sd + a];
+    jac_cs r = {1.0, 0.0};
+    if (fabs(hpq) > thr) {
+      const double al = 0.5 * (hqq - hpp) * ih, hq = hpq * ih;          // scaled: no under/overflow
+      const double x = fma(al, al, hq * hq);
+      const double rr = x * rsq_nr(x);
+      const double t = (al >= 0.0 ? hq : -hq) * rcp_nr(fabs(al) + rr);
+      r.x = rsq_nr3(fma(t, t, 1.0));
+      r.y = t * r.x;
+      atomicAdd(rot + sweep_parity, 1);
+    }
+    csn[buf * np + k] = r;
+  };
+
+  if (tid < np) params(0, 0, 1);                           // sweep 1 is odd
+  __syncthreads();
+  int sweep = 0, g = 0;
+  bool done = false;
+  while (sweep < max_sweeps && !done) {
+    ++sweep;
+    const int par = sweep & 1;
+    if (tid == 0) rot[par ^ 1] = 0;                        // next sweep's counter: first incremented in this sweep's last stage B
+    for (int round = 0; round < m1; ++round, ++g) {
+      const jac_cs* cur = csn + (g & 1) * np;
+      // ---- stage A: H <- J' H J, this thread's 2 x 2 blocks; all loads first (one level of LDS latency) ----
+      {
+        int o[NB_][4];
+        double m[NB_][4];
+        jac_cs ra[NB_], rb[NB_];
+#pragma unroll
+        for (int j = 0; j < NB_; ++j) {
+            int p1, q1, p2, q2;
+            pair_of(round, bka[j], m1, p1, q1);
+            pair_of(round, bkb[j], m1, p2, q2);
+            o[j][0] = p1 * sd + p2;
+            o[j][1] = p1 * sd + q2;
+            o[j][2] = q1 * sd + p2;
+            o[j][3] = q1 * sd + q2;
+            ra[j] = cur[bka[j]];
+            rb[j] = cur[bkb[j]];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m[j][e] = Hs[o[j][e]];
+          }
+#pragma unroll
+        for (int j = 0; j < NB_; ++j) {
+            const double ca = ra[j].x, sa = ra[j].y, cb = rb[j].x, sb = rb[j].y;
+            const double n00 = cb * m[j][0] - sb * m[j][1], n01 = sb * m[j][0] + cb * m[j][1];
+            const double n10 = cb * m[j][2] - sb * m[j][3], n11 = sb * m[j][2] + cb * m[j][3];
+            double o00 = ca * n00 - sa * n10, o10 = sa * n00 + ca * n10;
+            double o01 = ca * n01 - sa * n11, o11 = sa * n01 + ca * n11;
+            if (bka[j] == bkb[j] && sa != 0.0) { o01 = 0.0; o10 = 0.0; }   // the rotated pair itself: annihilated by construction
+            if (bon[j]) { Hs[o[j][0]] = o00; Hs[o[j][1]] = o01; Hs[o[j][2]] = o10; Hs[o[j][3]] = o11; }
+          }
+      }
+      __syncthreads();
+      // ---- stage B: wave 0 prepares round g + 1 from the new H; the other waves rotate the rows of V' ----
+      if (tid < 64) {
+        if (tid < np) {
+          const bool last = round + 1 == m1;
+          params(last ? 0 : round + 1, (g & 1) ^ 1, last ? (par ^ 1) : par);
+        }
+      } else {
+        int op[NV_], oq[NV_];
+        double x[NV_], y[NV_];
+        jac_cs r[NV_];
+#pragma unroll
+        for (int j = 0; j < NV_; ++j) {
+            int p, q;
+            pair_of(round, vk[j], m1, p, q);
+            op[j] = p * sd + vr[j];
+            oq[j] = q * sd + vr[j];
+            r[j] = cur[vk[j]];
+            x[j] = Vs[op[j]];
+            y[j] = Vs[oq[j]];
+          }
+#pragma unroll
+        for (int j = 0; j < NV_; ++j)
+          if (von[j]) { Vs[op[j]] = r[j].x * x[j] - r[j].y * y[j]; Vs[oq[j]] = r[j].y * x[j] + r[j].x * y[j]; }
+      }
+      __syncthreads();
+    }
+    done = (rot[par] == 0);
+    __syncthreads();                                       // everyone has read the counter before thread 0 recycles it
+  }
+  for (int i = tid; i < d; i += nt) w[i] = Hs[i * sd + i];
+  for (int i = tid; i < d * d; i += nt) {
+    const int r = i / d, c = i - r * d;
+    Vt[int64_t(r) * ldv + c] = Vs[r * sd + c];
+  }
+  if (tid == 0) *status = done ? sweep : -1;
+}
+
+__global__ __launch_bounds__(1024) void k_syev_small(int d, const double* __restrict__ A, int64_t lda, double* __restrict__ w,
+                                                     double* __restrict__ Vt, int64_t ldv, double tol, int max_sweeps,
+                                                     int* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) char jac_smem[];
+  syev_small_body<2, 4>(jac_smem, d, A, lda, w, Vt, ldv, tol, max_sweeps, status);      // d <= 80
+}
+__global__ __launch_bounds__(1024) void k_syev_small_wide(int d, const double* __restrict__ A, int64_t lda, double* __restrict__ w,
+                                                          double* __restrict__ Vt, int64_t ldv, double tol, int max_sweeps,
+                                                          int* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) char jac_smem[];
+  syev_small_body<3, 5>(jac_smem, d, A, lda, w, Vt, ldv, tol, max_sweeps, status);      // 80 < d <= 96
+}
+
+static size_t syev_small_lds(int64_t d) {
+  const int64_t pe = (d + 1) & ~int64_t(1), np = pe / 2, sd = pe | 1;
+  return size_t(2 * pe * sd + 18 + 4 * np) * 8;          // H, V', 16 maxima, 2 counters (+ pad), 2 x np (c, s)
+}
+
+int syev_small_max(ccz_ctx*) {
+  static const int on = [] { const char* e = getenv("CCZ_SYEV_TWOSIDED"); return e ? atoi(e) : 1; }();
+  return on ? 96 : 0;
+}
+
+int syev_small(ccz_ctx* c, const double* A, int64_t d, int64_t lda, double* w_dev, double* Vrows, int64_t ldv, int max_sweeps) {
+  if (d < 1 || d > 96) fail(CCZ_EINVAL, "syev_small: 1 <= d <= 96 required, got %lld", (long long)d);
+  Impl* im = impl(c);
+  const size_t lds_need = syev_small_lds(d);
+  if (d <= 80) {
+    CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_syev_small), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_need)));
+    hipLaunchKernelGGL(k_syev_small, dim3(1), dim3(1024), lds_need, stream(c), int(d), A, lda, w_dev, Vrows, ldv,
+                       2.220446049250313e-16, max_sweeps, im->d_flag + 1);
+  } else {
+    CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_syev_small_wide), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_need)));
+    hipLaunchKernelGGL(k_syev_small_wide, dim3(1), dim3(1024), lds_need, stream(c), int(d), A, lda, w_dev, Vrows, ldv,
+                       2.220446049250313e-16, max_sweeps, im->d_flag + 1);
+  }
+  CCZ_LAUNCH_CHECK();
+  int sw = 0;
+  d2h(c, &sw, im->d_flag + 1, sizeof(int));
+  if (sw == -2) fail(CCZ_EINVAL, "syev: matrix has non-finite entries");
+  if (sw < 0) fail(CCZ_ENOCONV, "Jacobi did not converge in %d sweeps (d=%lld)", max_sweeps, (long long)d);
+  return sw;
 }
 
 }  // namespace ccz

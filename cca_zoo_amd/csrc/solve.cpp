@@ -58,6 +58,20 @@ std::vector<int64_t> offsets(const int64_t* dims, int m) {
 // eigenvalues of a covariance / Gram matrix.
 static int syev_full_impl(ccz_ctx* c, double* A, int64_t d, bool psd, std::vector<double>& w,
                           double* Vrows, int64_t ldv) {
+  if (!psd && d >= 2 && d <= syev_small_max(c)) {
+    // Rayleigh-Ritz sized problems: two-sided Jacobi in one workgroup (no shift needed, no definiteness assumed)
+    DBuf wd(c, d), V(c, d * d);
+    const int sweeps = syev_small(c, A, d, d, wd, V, d, kMaxSweeps);
+    std::vector<double> lh(d);
+    d2h(c, lh.data(), wd, size_t(d) * 8);
+    std::vector<int64_t> perm(d);
+    std::iota(perm.begin(), perm.end(), 0);
+    std::stable_sort(perm.begin(), perm.end(), [&](int64_t a, int64_t b) { return lh[a] > lh[b]; });
+    w.resize(d);
+    for (int64_t i = 0; i < d; ++i) w[i] = lh[perm[i]];
+    if (Vrows) gather_rows(c, d, d, V, d, perm.data(), nullptr, Vrows, ldv);
+    return sweeps;
+  }
   double shift = 0.0;
   if (!psd) {
     shift = norm_inf(c, d, d, A, d);
@@ -142,12 +156,13 @@ bool cholqr_pass(ccz_ctx* c, int64_t p, int64_t b, double* X, int64_t ldx, doubl
   return true;
 }
 
-void orthonormalize(ccz_ctx* c, int64_t p, int64_t b, double* X, int64_t ldx) {
+void orthonormalize(ccz_ctx* c, int64_t p, int64_t b, double* X, int64_t ldx, bool refine = true) {
   // pass 1 may meet a numerically singular Gram (filtered block nearly rank deficient):
   // retry with a growing diagonal shift; pass 2/3 restore orthogonality.
   double shift = 0.0;
   for (int attempt = 0; attempt < 6; ++attempt) {
     if (cholqr_pass(c, p, b, X, ldx, shift)) {
+      if (!refine && shift == 0.0) return;            // a block that is only being kept from collapsing (power steps)
       if (!cholqr_pass(c, p, b, X, ldx, 0.0)) { shift = shift > 0 ? shift * 100 : 1e-14; continue; }
       if (shift > 0.0 && !cholqr_pass(c, p, b, X, ldx, 0.0)) { shift *= 100; continue; }
       return;
@@ -171,8 +186,9 @@ struct RitzState {
   std::vector<double> resid;   // b residual norms
 };
 
-// Rayleigh-Ritz on span(X): X <- X C, Y <- (S X) C, theta, residual norms.
-void rayleigh_ritz(ccz_ctx* c, const SymOp& op, int64_t b, double* X, double* Y, double* tmp,
+// Rayleigh-Ritz on span(X): X <- X C, Y <- (S X) C, theta, residual norms.  The three block pointers rotate (the
+// products land in scratch blocks that then become X / Y): no block copies.
+void rayleigh_ritz(ccz_ctx* c, const SymOp& op, int64_t b, double*& X, double*& Y, double*& tmp,
                    RitzState& st) {
   const int64_t p = op.p;
   op.apply(X, b, b, Y, b);
@@ -182,9 +198,9 @@ void rayleigh_ritz(ccz_ctx* c, const SymOp& op, int64_t b, double* X, double* Y,
   axpby2d(c, b, b, 0.5, H, b, 0.5, Hs, b);            // symmetrise
   syev_full_impl(c, H, b, false, st.theta, Vr, b);      // rows of Vr = Ritz coefficient vectors
   gemm(c, false, true, p, b, b, 1.0, X, b, Vr, b, 0.0, tmp, b);
-  d2d(c, X, tmp, size_t(p) * b * 8);
+  std::swap(X, tmp);                                    // X = X C ; tmp = old X (free)
   gemm(c, false, true, p, b, b, 1.0, Y, b, Vr, b, 0.0, tmp, b);
-  d2d(c, Y, tmp, size_t(p) * b * 8);
+  std::swap(Y, tmp);                                    // Y = Y C ; tmp free
   // residual R = Y - X diag(theta)
   DBuf th(c, b), rn(c, b);
   h2d(c, th, st.theta.data(), size_t(b) * 8);
@@ -200,7 +216,8 @@ void rayleigh_ritz(ccz_ctx* c, const SymOp& op, int64_t b, double* X, double* Y,
 // Degree-m Chebyshev filter damping [a, cut], scaled at aL (Zhou & Saad).
 // In: X (p x b).  Out: result left in X.  Y, Z are work blocks.
 void chebyshev_filter(ccz_ctx* c, const SymOp& op, int64_t b, int m, double a, double cut,
-                      double aL, double* X, double* Y, double* Z) {
+                      double aL, double*& X, double*& Y, double*& Z) {
+  // three-term recurrence on rotating block pointers (the result ends up in X; Y, Z hold scratch): no block copies
   const int64_t p = op.p;
   const double e = 0.5 * (cut - a), c0 = 0.5 * (cut + a);
   double sigma1 = e / (aL - c0);
@@ -212,12 +229,11 @@ void chebyshev_filter(ccz_ctx* c, const SymOp& op, int64_t b, int m, double a, d
     const double sn = 1.0 / (tau - sigma);
     op.apply(Y, b, b, Z, b);
     axpby2d(c, p, b, 2.0 * sn / e, Z, b, -c0 * 2.0 * sn / e, Y, b);
-    axpby2d(c, p, b, 1.0, Z, b, -sigma * sn, X, b);              // Z -= sigma sn X
-    d2d(c, X, Y, size_t(p) * b * 8);
-    d2d(c, Y, Z, size_t(p) * b * 8);
+    axpby2d(c, p, b, 1.0, Z, b, -sigma * sn, X, b);              // Z = 2 sn/e (S Y - c0 Y) - sigma sn X
+    double* t = X; X = Y; Y = Z; Z = t;                          // (X, Y) <- (Y, Z)
     sigma = sn;
   }
-  d2d(c, X, Y, size_t(p) * b * 8);
+  std::swap(X, Y);                                               // the last iterate is the result
 }
 
 // Returns theta (k, descending) on the host and the eigenvectors as the first k
@@ -226,19 +242,22 @@ void topk_symmetric(ccz_ctx* c, const SymOp& op, int k, std::vector<double>& the
   const int64_t p = op.p;
   if (k > p) k = int(p);
   int64_t b = std::min<int64_t>(p, k + std::max(8, k / 4));
-  DBuf X(c, p * b), Y(c, p * b), Z(c, p * b);
+  DBuf Xb(c, p * b), Yb(c, p * b), Zb(c, p * b);
+  double *X = Xb, *Y = Yb, *Z = Zb;                  // rotating block pointers (rayleigh_ritz, chebyshev_filter)
   randn_fill(c, p, b, X, b, 0x9E3779B97F4A7C15ull);
-  orthonormalize(c, p, b, X, b);
   // warm start: two power steps on the shifted operator S - lower I (positive semi-definite, so the
   // top of the spectrum dominates even for indefinite S); a random block has Ritz values that all sit
-  // at the spectral mean and would tell the first filter nothing about the gap
+  // at the spectral mean and would tell the first filter nothing about the gap.  A Gaussian block is
+  // well conditioned as it is (singular values within 1 +- sqrt(b/p) of sqrt(p)): it is not orthonormalised first.
   if (b < p) {
     for (int it = 0; it < 2; ++it) {
       op.apply(X, b, b, Y, b);
       if (op.lower != 0.0) axpby2d(c, p, b, 1.0, Y, b, -op.lower, X, b);
-      d2d(c, X, Y, size_t(p) * b * 8);
-      orthonormalize(c, p, b, X, b);
+      std::swap(X, Y);
+      orthonormalize(c, p, b, X, b, /*refine=*/it == 1);   // only the block that enters Rayleigh-Ritz must be orthonormal
     }
+  } else {
+    orthonormalize(c, p, b, X, b);
   }
   RitzState st;
   rayleigh_ritz(c, op, b, X, Y, Z, st);
@@ -396,12 +415,13 @@ void svd_topk_dense(ccz_ctx* c, const double* Tt, int64_t p, int64_t q, int k,
 struct Whitener {
   int64_t d = 0, r = 0;
   bool chol = true;
-  DBuf L;  // chol: lower factor (d x d) ; else explicit F (d x r)
+  DBuf L;    // chol: lower factor (d x d) ; else explicit F (d x r)
+  DBuf aux;  // chol: by-products of the factorization that later triangular solves reuse (trsm_aux_size; may be empty)
 
   // X (m x d, ld ldx)  ->  X F   in place for chol (r == d); explicit: into out (m x r)
   void right_apply(ccz_ctx* c, int64_t m, double* X, int64_t ldx, double* out, int64_t ldo) const {
     if (chol) {
-      trsm_right_lower(c, true, m, d, L, d, X, ldx);
+      trsm_right_lower_aux(c, true, m, d, L, d, X, ldx, aux.get());
       if (out != X) copy2d(c, m, d, X, ldx, out, ldo);
     } else {
       gemm(c, false, false, m, r, d, 1.0, X, ldx, L, r, 0.0, out, ldo);
@@ -410,7 +430,7 @@ struct Whitener {
   // Ut (k x r) -> (F U)' = Ut F'  (k x d)
   void back_project_rows(ccz_ctx* c, int64_t k, double* Ut, int64_t ldu, double* out, int64_t ldo) const {
     if (chol) {
-      trsm_right_lower(c, false, k, d, L, d, Ut, ldu);
+      trsm_right_lower_aux(c, false, k, d, L, d, Ut, ldu, aux.get());
       if (out != Ut) copy2d(c, k, d, Ut, ldu, out, ldo);
     } else {
       gemm(c, false, true, k, d, r, 1.0, Ut, ldu, L, r, 0.0, out, ldo);
@@ -427,11 +447,15 @@ std::vector<Whitener> make_whiteners(ccz_ctx* c, std::vector<DBuf>& R, const std
   std::vector<double*> ptr(m);
   std::vector<int64_t> ld(dims);
   std::vector<int> info(m, 0);
+  std::vector<DBuf> aux(m);
+  std::vector<double*> auxp(m, nullptr);
   for (int i = 0; i < m; ++i) {
     if (allow_floor) { keep[i] = DBuf(c, dims[i] * dims[i]); d2d(c, keep[i], R[i], size_t(dims[i]) * dims[i] * 8); }
     ptr[i] = R[i].get();
+    const int64_t na = trsm_aux_size(c, dims[i]);
+    if (na > 0) { aux[i] = DBuf(c, na); auxp[i] = aux[i].get(); }
   }
-  potrf_lower_batched(c, m, ptr.data(), dims.data(), ld.data(), info.data());
+  potrf_lower_batched_aux(c, m, ptr.data(), dims.data(), ld.data(), info.data(), auxp.data());
   std::vector<Whitener> out(m);
   for (int i = 0; i < m; ++i) {
     Whitener& w = out[i];
@@ -441,6 +465,7 @@ std::vector<Whitener> make_whiteners(ccz_ctx* c, std::vector<DBuf>& R, const std
       w.chol = true;
       w.r = d;
       w.L = std::move(R[i]);
+      w.aux = std::move(aux[i]);
       continue;
     }
     if (!allow_floor) fail(CCZ_ENOTSPD, "regularised covariance block %d (%lld x %lld) is not positive definite", i, (long long)d, (long long)d);
@@ -574,15 +599,16 @@ static void rcca_solve_impl(ccz_ctx* c, const double* mom, int64_t n, const int6
   kk = int(std::min<int64_t>({int64_t(kk), r1, r2}));
 
   // Y = M12 F2 (d1 x r2);  Tt = Y' F1 = (F1' M12 F2)'  (r2 x r1)
-  DBuf Y(c, d1 * r2);
-  F2.right_apply(c, d1, M12, d2, Y, r2);
+  // (Cholesky whiteners work in place: r_i = d_i, no copies; the eigen-floored fallback has an explicit F)
+  DBuf Y;
+  if (F2.chol) { F2.right_apply(c, d1, M12, d2, M12, d2); Y = std::move(M12); }
+  else { Y = DBuf(c, d1 * r2); F2.right_apply(c, d1, M12, d2, Y, r2); M12.reset(); }
   DBuf Yt(c, r2 * d1);
   transpose(c, d1, r2, Y, r2, Yt, d1);
   Y.reset();
-  M12.reset();
-  DBuf Tt(c, r2 * r1);
-  F1.right_apply(c, r2, Yt, d1, Tt, r1);
-  Yt.reset();
+  DBuf Tt;
+  if (F1.chol) { F1.right_apply(c, r2, Yt, d1, Yt, d1); Tt = std::move(Yt); }
+  else { Tt = DBuf(c, r2 * r1); F1.right_apply(c, r2, Yt, d1, Tt, r1); Yt.reset(); }
 
   std::vector<double> sv;
   DBuf Ut(c, int64_t(kk) * r1), Vt(c, int64_t(kk) * r2);

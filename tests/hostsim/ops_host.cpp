@@ -207,6 +207,95 @@ int jacobi_rows(ccz_ctx*, int64_t p, int64_t q, double* W, int64_t ldw, double* 
   fail(CCZ_ENOCONV, "Jacobi did not converge in %d sweeps", max_sweeps);
 }
 
+int64_t trsm_aux_size(ccz_ctx*, int64_t) { return 0; }
+void potrf_lower_batched_aux(ccz_ctx* c, int count, double* const* A, const int64_t* d, const int64_t* lda, int* info,
+                             double* const*) {
+  potrf_lower_batched(c, count, A, d, lda, info);
+}
+void trsm_right_lower_aux(ccz_ctx* c, bool trans, int64_t r, int64_t d, const double* L, int64_t ldl, double* X,
+                          int64_t ldx, const double*) {
+  trsm_right_lower(c, trans, r, d, L, ldl, X, ldx);
+}
+
+// Two-sided Jacobi in the device kernel's own formulation (k_syev_small, ops_hip.hip): round-robin tournament,
+// all rotation parameters of a round from the current H, then every 2 x 2 block R_a' M R_b and the rows of V'.
+int syev_small_max(ccz_ctx*) { return 96; }
+int syev_small(ccz_ctx*, const double* A, int64_t d, int64_t lda, double* w, double* Vt, int64_t ldv, int max_sweeps) {
+  if (d < 1 || d > 96) fail(CCZ_EINVAL, "syev_small: 1 <= d <= 96 required, got %lld", (long long)d);
+  const int64_t pe = (d + 1) & ~int64_t(1), m1 = pe - 1, np = pe / 2;
+  std::vector<double> H(size_t(pe) * pe, 0.0), V(size_t(pe) * pe, 0.0), cs(np), sn(np), tn(np);
+  std::vector<int64_t> pa(np), qa(np);
+  double hmax = 0.0;
+  for (int64_t r = 0; r < d; ++r) {
+    V[r * pe + r] = 1.0;
+    for (int64_t c = 0; c < d; ++c) {
+      const double h = 0.5 * (A[r * lda + c] + A[c * lda + r]);
+      if (!(std::fabs(h) <= 1.79769313486231570e308)) fail(CCZ_EINVAL, "syev: matrix has non-finite entries");
+      H[r * pe + c] = h;
+      hmax = std::max(hmax, std::fabs(h));
+    }
+  }
+  const double thr = 2.220446049250313e-16 * hmax;
+  for (int sweep = 1; sweep <= max_sweeps; ++sweep) {
+    int64_t rot = 0;
+    for (int64_t round = 0; round < m1; ++round) {
+      for (int64_t k = 0; k < np; ++k) {
+        int64_t a, b;
+        if (k == 0) { a = m1; b = round; } else { a = (round + k) % m1; b = (round - k + m1) % m1; }
+        pa[k] = a; qa[k] = b;
+        const double hpq = H[a * pe + b];
+        double c = 1.0, s = 0.0, t = 0.0;
+        if (std::fabs(hpq) > thr) {
+          const double al = 0.5 * (H[b * pe + b] - H[a * pe + a]);
+          const double r = std::sqrt(al * al + hpq * hpq);
+          t = (al >= 0.0 ? hpq : -hpq) / (std::fabs(al) + r);
+          c = 1.0 / std::sqrt(1.0 + t * t);
+          s = t * c;
+          ++rot;
+        }
+        cs[k] = c; sn[k] = s; tn[k] = t;
+      }
+      for (int64_t ka = 0; ka < np; ++ka)
+        for (int64_t kb = 0; kb < np; ++kb) {
+          const double sa = sn[ka], sb = sn[kb];
+          if (sa == 0.0 && sb == 0.0) continue;
+          double& h00 = H[pa[ka] * pe + pa[kb]];
+          double& h01 = H[pa[ka] * pe + qa[kb]];
+          double& h10 = H[qa[ka] * pe + pa[kb]];
+          double& h11 = H[qa[ka] * pe + qa[kb]];
+          const double m00 = h00, m01 = h01, m10 = h10, m11 = h11;
+          if (ka == kb) {
+            h00 = m00 - tn[ka] * m01; h11 = m11 + tn[ka] * m01; h01 = 0.0; h10 = 0.0;
+          } else {
+            const double ca = cs[ka], cb = cs[kb];
+            const double n00 = cb * m00 - sb * m01, n01 = sb * m00 + cb * m01;
+            const double n10 = cb * m10 - sb * m11, n11 = sb * m10 + cb * m11;
+            h00 = ca * n00 - sa * n10; h10 = sa * n00 + ca * n10;
+            h01 = ca * n01 - sa * n11; h11 = sa * n01 + ca * n11;
+          }
+        }
+      for (int64_t k = 0; k < np; ++k) {
+        if (sn[k] == 0.0) continue;
+        for (int64_t r = 0; r < d; ++r) {
+          double& vp = V[pa[k] * pe + r];
+          double& vq = V[qa[k] * pe + r];
+          const double x = vp, y = vq;
+          vp = cs[k] * x - sn[k] * y;
+          vq = sn[k] * x + cs[k] * y;
+        }
+      }
+    }
+    if (rot == 0) {
+      for (int64_t i = 0; i < d; ++i) {
+        w[i] = H[i * pe + i];
+        for (int64_t j = 0; j < d; ++j) Vt[i * ldv + j] = V[i * pe + j];
+      }
+      return sweep;
+    }
+  }
+  fail(CCZ_ENOCONV, "Jacobi did not converge in %d sweeps (d=%lld)", max_sweeps, (long long)d);
+}
+
 void row_dots(ccz_ctx*, int64_t rows, int64_t cols, const double* A, int64_t lda, const double* B, int64_t ldb,
               double* out) {
   for (int64_t i = 0; i < rows; ++i) {

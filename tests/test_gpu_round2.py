@@ -356,7 +356,7 @@ def test_factor_loadings_on_device_tensors_and_gcca_padding():
 # ---------------------------------------------------------------------------------------------
 # big-d building blocks: recursive Cholesky / TRSM (d >= 6144), split-K and big-tile GEMM shapes
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("d", [2048, 6144, 8192])
+@pytest.mark.parametrize("d", [1500, 2048, 4500, 6144, 8192])
 def test_potrf_and_trsm_large(H, d):
     import torch
 
@@ -376,6 +376,30 @@ def test_potrf_and_trsm_large(H, d):
         H.check(H.lib.ccz_trsm_right_lower(H.raw, trans, r, d, C.c_void_p(L.data_ptr()), d, C.c_void_p(X.data_ptr()), d))
         back = X @ (L.T if trans else L)
         assert float((back - B).abs().max() / B.abs().max()) < 1e-9, (d, trans)
+
+
+def test_syevj_two_sided_rayleigh_ritz_spectra(H):
+    """The two-sided Jacobi kernel (d <= 96) on the matrices the Rayleigh-Ritz steps actually produce: a cluster of 64
+    eigenvalues 1e-5 apart above a noise floor, an exactly diagonal matrix, a zero matrix, and non-finite input."""
+    rng = np.random.default_rng(7)
+    d = 80
+    q, _ = np.linalg.qr(rng.standard_normal((d, d)))
+    lam = np.concatenate([1.0 - 1e-5 * np.arange(64), 0.05 * rng.random(16)])
+    cases = [(q * lam) @ q.T, np.diag(lam), np.zeros((d, d))]
+    for A in cases:
+        Ad, wd, Vd = H.to_device(A), H.alloc(d * 8), H.alloc(d * d * 8)
+        sw = C.c_int(0)
+        H.check(H.lib.ccz_syevj(H.raw, C.c_void_p(Ad.ptr), d, C.c_void_p(wd.ptr), C.c_void_p(Vd.ptr), C.byref(sw)))
+        w, V = H.to_host(wd, (d,)), H.to_host(Vd, (d, d))
+        np.testing.assert_allclose(w, np.linalg.eigvalsh(A)[::-1], atol=5e-15 * max(1.0, np.abs(A).max()) * d)
+        np.testing.assert_allclose(V @ V.T, np.eye(d), atol=1e-13)
+        np.testing.assert_allclose(V @ A @ V.T, np.diag(w), atol=1e-13)
+        assert 1 <= sw.value <= 20
+    bad = cases[0].copy()
+    bad[3, 5] = bad[5, 3] = np.nan
+    Ad, wd, Vd = H.to_device(bad), H.alloc(d * 8), H.alloc(d * d * 8)
+    with pytest.raises(ValueError, match="non-finite"):
+        H.check(H.lib.ccz_syevj(H.raw, C.c_void_p(Ad.ptr), d, C.c_void_p(wd.ptr), C.c_void_p(Vd.ptr), None))
 
 
 @pytest.mark.parametrize("tA,tB,M,N,K", [
