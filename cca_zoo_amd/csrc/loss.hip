@@ -162,7 +162,21 @@ void fused_core(ccz_ctx* c, const double* mom, int64_t n, const int64_t* dims, i
   }
   // Only the blocks that are not trivially known are formed: A_aa = I is never computed, Gamma's diagonal blocks come
   // straight from  Gamma_aa = -sum_{b != a} A_ab Gamma_ba  ( = 2/(n-1) ((A M)_aa - M_aa) ).
+  // The four product stages below are dependent launches of at most a few hundred 64 x 64 tiles with K = d: on
+  // their own they leave most of the chip idle for ~40 us each.  From d = 256 on the K range of every tile is cut
+  // into four slices on separate workgroups that accumulate atomically into zeroed destinations (split-K).
+  int64_t dmin = dims[0];
+  for (int a = 1; a < m; ++a) dmin = std::min(dmin, dims[a]);
+  static const int split_env = [] { const char* e = getenv("CCZ_LOSS_SPLITK"); return e ? atoi(e) : 4; }();
+  const int ks = (dmin >= 256 && split_env > 1) ? split_env : 1;
+  if (ks > 1) {
+    for (int a = 0; a < m; ++a) zero(c, Sinv[a], size_t(dims[a]) * dims[a] * 8);
+    zero(c, Am, size_t(D) * D * 8);
+    if (want_grad) zero(c, gamma_dev, size_t(D) * D * 8);
+  }
   auto launch = [&](std::vector<MultiGemmArgs>& v) {
+    if (ks > 1)
+      for (auto& g : v) { g.ksplit = ks; g.beta = 1.0; }       // destinations are zero (or hold the earlier terms of a sum)
     for (size_t i0 = 0; i0 < v.size(); i0 += 8) gemm_f64_multi(c, int(std::min<size_t>(8, v.size() - i0)), v.data() + i0);
   };
   std::vector<MultiGemmArgs> pr;

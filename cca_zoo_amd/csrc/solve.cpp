@@ -314,14 +314,16 @@ void topk_symmetric(ccz_ctx* c, const SymOp& op, int k, std::vector<double>& the
 }
 
 // top-k eigenpairs of a dense symmetric S (p x p): rows-form output Vt (k x p).
+// lower_hint: a PROVEN lower bound of the spectrum if the caller has one (the filter damps [lower, cut]: the generic
+// bound -||S||_inf is often 10-100x too pessimistic, and the filter degree grows like 1 / sqrt(gap / interval)).
 void eig_topk_dense(ccz_ctx* c, const double* S, int64_t p, int k, std::vector<double>& lam,
-                    double* Vt, int64_t ldvt) {
+                    double* Vt, int64_t ldvt, double lower_hint = -HUGE_VAL) {
   k = int(std::min<int64_t>(k, p));
   bool direct = p <= kDirectMax || int64_t(k) * 3 >= p;
   if (!direct) {
     SymOp op;
     op.p = p;
-    op.lower = -norm_inf(c, p, p, S, p);
+    op.lower = std::isfinite(lower_hint) ? lower_hint : -norm_inf(c, p, p, S, p);
     op.apply = [c, S, p](const double* X, int64_t ldx, int64_t b, double* Y, int64_t ldy) {
       gemm(c, false, false, p, b, p, 1.0, S, p, X, ldx, 0.0, Y, ldy);
     };
@@ -673,7 +675,12 @@ static void mcca_solve_impl(ccz_ctx* c, const double* mom, int64_t n, const int6
   const int kk = int(std::min<int64_t>(k, D));
   std::vector<double> lam;
   DBuf Yt(c, int64_t(kk) * D);
-  eig_topk_dense(c, S, D, kk, lam, Yt, D);
+  // S = L^-1 C L^-T - blockdiag(L_i^-1 C_ii L_i^-T): the first term is positive semi-definite, and with
+  // R_i = (1 - c_i) C_ii + (c_i + shift) I the eigenvalues of block i of the second are mu / ((1 - c_i) mu + c_i + shift)
+  // < 1 / (1 - c_i) for the eigenvalues mu >= 0 of C_ii.  So S >= -max_i 1 / (1 - c_i)  (c_i = 1: no such bound).
+  double lower = 0.0;
+  for (int i = 0; i < m; ++i) lower = std::max(lower, cc[i] < 1.0 ? 1.0 / (1.0 - cc[i]) : HUGE_VAL);
+  eig_topk_dense(c, S, D, kk, lam, Yt, D, std::isfinite(lower) ? -(1.0 + 1e-6) * lower : -HUGE_VAL);
   S.reset();
   // v_i = sqrt(m) L_i^-T y_i   (normalisation v'(B/m)v = 1 of LAPACK sygvx on (A/m, B/m))
   int64_t wofs = 0;
@@ -741,7 +748,9 @@ static void gcca_solve_impl(ccz_ctx* c, const double* mom, int64_t n, const int6
   const int kk = int(std::min<int64_t>({int64_t(k), D, n}));
   std::vector<double> lam;
   DBuf Ut(c, int64_t(kk) * D);
-  eig_topk_dense(c, K, D, kk, lam, Ut, D);
+  // K = F' Gx F with F = blockdiag(sqrt(mu_i) L_i^-T) and Gx a second-moment matrix: positive semi-definite up to
+  // round-off (a few ulp of its norm).  The generic bound -||K||_inf would triple the width of the damped interval.
+  eig_topk_dense(c, K, D, kk, lam, Ut, D, -1e-9 * norm_inf(c, D, D, K, D));
   K.reset();
   for (int i = 0; i < kk; ++i)
     if (!(lam[i] > 0.0)) fail(CCZ_ENOCONV, "GCCA eigenvalue %d is not positive (%g); fewer than k shared directions", i, lam[i]);
