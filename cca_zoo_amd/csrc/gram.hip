@@ -82,6 +82,25 @@ __device__ __forceinline__ WorkItem locate_work(unsigned bid, int ntiles, int pe
     return it;
   }
   const unsigned x = bid & 7u, m = bid >> 3;
+  if (per_xcd < 0) {
+    // chunk-per-XCD order: XCD x works through row chunks x, x + 8, ... and walks the WHOLE tile list for each, so
+    // the 32 workgroups it runs at any time are 32 consecutive tiles of one chunk -- a 4 x 8 supertile that shares 12
+    // panels through that XCD's L2.  Odd local chunks walk the list backwards: the list's ragged tail (528 tiles =
+    // 16.5 rounds of 32) meets the tail of the next chunk and the two half rounds fill the XCD together.
+    // XCD x enters its (cyclic) sequence x * rot items in, rot a multiple of 32: at any moment the eight XCDs are on
+    // different supertiles (no two flush the same tile of G or stream the same columns at the same time)
+    const unsigned total = unsigned(ksplit >> 3) * unsigned(ntiles);
+    const unsigned rot = (total >> 8) << 5;
+    unsigned mm = m + x * rot;
+    if (mm >= total) mm -= total;
+    const unsigned lc = mm / unsigned(ntiles);
+    unsigned t = mm - lc * unsigned(ntiles);
+    if (lc & 1u) t = unsigned(ntiles) - 1u - t;
+    it.tile = int(t);
+    it.chunk = int64_t(lc) * 8 + x;
+    it.valid = it.chunk < ksplit;
+    return it;
+  }
   it.chunk = m / unsigned(per_xcd);
   it.tile = int(x) * per_xcd + int(m % unsigned(per_xcd));
   it.valid = it.chunk < ksplit && it.tile < ntiles;
@@ -856,7 +875,33 @@ bool launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
   // of an off-diagonal one (k_gram_f32_fifo skips their redundant quadrant work), so they are dealt round-robin
   // to the slices and the off-diagonal tiles fill each slice up to `per` in supertile order (the last slice takes
   // what is left).  The table stays dense: the plain order of small grids uses the same list.
-  {
+  // CCZ_GRAM_MAP=1 (default): chunk-per-XCD order (locate_work, per_xcd < 0).  The list is arranged so that rounds of
+  // 32 consecutive tiles have uniform cost and shared panels: first the complete 4 x 8 supertiles (no diagonal tiles:
+  // 12 panels per 32 tiles), then all diagonal tiles together (they cost ~65% of a full tile -- mixed into other
+  // rounds they would stagger the XCD's workgroups for good), then the off-diagonal rest of the ragged supertiles.
+  static const int map_mode = [] { const char* e = getenv("CCZ_GRAM_MAP"); return e ? atoi(e) : 1; }();
+  if (map_mode == 1) {
+    std::vector<GramTile> full, dg, rest;
+    size_t pos = 0;
+    for (int I = 0; I < np; I += 4)
+      for (int J = (I / 8) * 8; J < np; J += 8) {
+        size_t cnt = 0;
+        bool has_diag = false;
+        for (int i = I; i < std::min(np, I + 4); ++i)
+          for (int j = std::max(i, J); j < std::min(np, J + 8); ++j) { ++cnt; has_diag = has_diag || i == j; }
+        for (size_t q = 0; q < cnt; ++q) {
+          const GramTile& tl = tiles[pos + q];
+          if (cnt == 32 && !has_diag) full.push_back(tl);
+          else (tl.diag ? dg : rest).push_back(tl);
+        }
+        pos += cnt;
+      }
+    if (pos != tiles.size()) fail(CCZ_EHIP, "gram: tile ordering lost tiles (internal error)");
+    tiles.clear();
+    tiles.insert(tiles.end(), full.begin(), full.end());
+    tiles.insert(tiles.end(), dg.begin(), dg.end());
+    tiles.insert(tiles.end(), rest.begin(), rest.end());
+  } else {
     std::vector<GramTile> dg, off, balanced;
     for (const GramTile& tl : tiles) (tl.diag ? dg : off).push_back(tl);
     const size_t per = (tiles.size() + 7) / 8;
@@ -903,10 +948,13 @@ bool launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
     int64_t best_k = kmin;
     for (int64_t ks = kmin; ks <= kmax; ++ks) {
       const int64_t rows = ((n + ks - 1) / ks + BK - 1) / BK * BK;
-      const int64_t rounds = int64_t(ntiles) * ks >= 16 * int64_t(ncu)
-                                 ? (int64_t((ntiles + 7) / 8) * ks + ncu / 8 - 1) / (ncu / 8)   // per-XCD slice
-                                 : (int64_t(ntiles) * ks + ncu - 1) / ncu;
-      const double cost = double(rounds) * double(rows + 320);
+      const bool big = int64_t(ntiles) * ks >= 16 * int64_t(ncu);
+      int64_t rounds;
+      double penalty = 1.0;
+      if (big && map_mode == 1 && ks % 8 == 0) rounds = ((ks / 8) * int64_t(ntiles) + ncu / 8 - 1) / (ncu / 8);   // chunk-per-XCD
+      else if (big) { rounds = (int64_t((ntiles + 7) / 8) * ks + ncu / 8 - 1) / (ncu / 8); if (map_mode == 1) penalty = 1.03; }   // per-XCD slice
+      else rounds = (int64_t(ntiles) * ks + ncu - 1) / ncu;
+      const double cost = penalty * double(rounds) * double(rows + 320);
       if (cost < best) { best = cost; best_k = ks; }
     }
     rows_per_wg = ((n + best_k - 1) / best_k + BK - 1) / BK * BK;
@@ -914,8 +962,9 @@ bool launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
   const int64_t ksplit = (n + rows_per_wg - 1) / rows_per_wg;
   // XCD-aware slicing needs many workgroups per XCD to stay balanced; small grids keep the plain order
   const bool sliced = int64_t(ntiles) * ksplit >= 16 * int64_t(ncu);
-  const int per_xcd = sliced ? (ntiles + 7) / 8 : 0;
-  const int64_t nblocks = sliced ? int64_t(8) * per_xcd * ksplit : int64_t(ntiles) * ksplit;
+  const bool xchunks = sliced && map_mode == 1 && ksplit % 8 == 0;
+  const int per_xcd = xchunks ? -1 : (sliced ? (ntiles + 7) / 8 : 0);
+  const int64_t nblocks = xchunks ? int64_t(ntiles) * ksplit : (sliced ? int64_t(8) * per_xcd * ksplit : int64_t(ntiles) * ksplit);
   if (nblocks > 0x7fffffffLL) fail(CCZ_EUNSUP, "gram: grid too large");
   const size_t lds_bytes = size_t(2) * 2 * BK * tile * sizeof(T);  // 64 KiB either way
 
