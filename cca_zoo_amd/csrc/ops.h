@@ -150,7 +150,8 @@ double norm_inf(ccz_ctx* c, int64_t rows, int64_t cols, const double* A, int64_t
 // used; throws ENOCONV beyond max_sweeps.
 int jacobi_rows(ccz_ctx* c, int64_t p, int64_t q, double* W, int64_t ldw, double* Q, int64_t qc,
                 int64_t ldq, int max_sweeps);
-// Two-sided Jacobi EVD of a small symmetric A (d x d, d <= syev_small_max(c); only read, symmetrised on load):
+// Two-sided Jacobi EVD of a small symmetric A (d x d, d <= syev_small_max(c) -- 160 on the HIP backend; only read,
+// symmetrised on load):
 // w_dev[i] = eigenvalue i (unsorted), row i of Vrows (d x d, ld ldv) = its eigenvector.  Needs no definiteness and no
 // shift.  Returns sweeps; throws EINVAL on non-finite input, ENOCONV beyond max_sweeps.  syev_small_max: largest
 // supported d (0: the backend has no such kernel).

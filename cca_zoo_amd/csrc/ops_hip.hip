@@ -1784,32 +1784,296 @@ __global__ __launch_bounds__(1024) void k_syev_small_wide(int d, const double* _
   syev_small_body<3, 5>(jac_smem, d, A, lda, w, Vt, ldv, tol, max_sweeps, status);      // 80 < d <= 96
 }
 
+// ---------------------------------------------------------------------------
+// The same eigen-solve split in two (default; d <= 160): the fused kernel above moves 306 KB through the LDS of ONE
+// CU per round (H and V', each read + written, plus the rotation parameters) and is bound by exactly that.
+//   k_syev_packed   one workgroup: H only, stored as its packed lower triangle (the mirrored 2 x 2 blocks are the same
+//                   numbers: half the blocks, a quarter of the LDS bytes per round; 103 KB hold d = 160, which the
+//                   square layout could not), every round's (c, s) pairs are logged to global memory;
+//   k_jacobi_replay d / 16 workgroups: each replays the whole log on its own 16 columns of V' = I (columns of V' are
+//                   independent), one barrier per round, parameters of the next round prefetched.
+// ---------------------------------------------------------------------------
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence over ALL address spaces:
+// with a global store in flight (the rotation log) every wave would wait for its acknowledgement (~1 us) at every
+// barrier of the round loop.  The log is consumed by a later kernel, so only this wave's LDS operations must have
+// completed before the barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ int tri_off(int i, int j) {
+  const int hi = max(i, j), lo = min(i, j);
+  return ((hi * (hi + 1)) >> 1) + lo;
+}
+__device__ __forceinline__ void tri_decode(int e, int& i, int& j) {   // e = i (i + 1) / 2 + j, j <= i
+  i = int((sqrtf(8.0f * float(e) + 1.0f) - 1.0f) * 0.5f);
+  while (i * (i + 1) / 2 > e) --i;
+  while ((i + 1) * (i + 2) / 2 <= e) ++i;
+  j = e - i * (i + 1) / 2;
+}
+
+template <int NB_>
+__device__ __forceinline__ void syev_packed_body(char* smem, int d, const double* __restrict__ A, int64_t lda, double* __restrict__ w,
+                                                 jac_cs* __restrict__ log, double tol, int max_sweeps, int* __restrict__ status) {
+  const int pe = (d + 1) & ~1, m1 = pe - 1, np = pe >> 1;
+  const int nH = pe * (pe + 1) / 2, nHp = (nH + 1) & ~1;
+  double* Hs = reinterpret_cast<double*>(smem);
+  double* red = Hs + nHp;
+  int* rot = reinterpret_cast<int*>(red + 16);
+  jac_cs* csn = reinterpret_cast<jac_cs*>(red + 18);       // [2][np]
+  const int tid = threadIdx.x, nt = blockDim.x;
+  double mx = 0.0;
+  for (int e = tid; e < nH; e += nt) {
+    int i, j;
+    tri_decode(e, i, j);
+    double h = 0.0;
+    if (i < d) {                                           // j <= i
+      h = 0.5 * (A[int64_t(i) * lda + j] + A[int64_t(j) * lda + i]);
+      const double a = fabs(h);
+      mx = (a <= 1.79769313486231570e308) ? fmax(mx, a) : __builtin_inf();
+    }
+    Hs[e] = h;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  if (tid < 2) rot[tid] = 0;
+  __syncthreads();
+  double hmax = 0.0;
+  for (int i = 0; i < (nt + 63) >> 6; ++i) hmax = fmax(hmax, red[i]);
+  if (!(hmax < __builtin_inf())) {
+    if (tid == 0) { status[0] = -2; status[1] = 0; }
+    return;
+  }
+  if (hmax == 0.0) {
+    for (int i = tid; i < d; i += nt) w[i] = 0.0;
+    if (tid == 0) { status[0] = 1; status[1] = 0; }
+    return;
+  }
+  const double thr = tol * hmax, ih = 1.0 / hmax;
+  const int nblk = np * (np + 1) / 2;
+  int bka[NB_], bkb[NB_];
+  bool bon[NB_];
+#pragma unroll
+  for (int j = 0; j < NB_; ++j) {
+    const int b = tid + j * nt;
+    bon[j] = b < nblk;
+    bka[j] = 0; bkb[j] = 0;
+    if (bon[j]) tri_decode(b, bka[j], bkb[j]);            // ka >= kb
+  }
+  auto params = [&](int round, int buf, int sweep_parity, int glog) {   // lanes < np of wave 0
+    const int k = tid;
+    int a, b;
+    pair_of(round, k, m1, a, b);
+    const double hpq = Hs[tri_off(a, b)], hqq = Hs[tri_off(b, b)], hpp = Hs[tri_off(a, a)];
+    jac_cs r = {1.0, 0.0};
+    if (fabs(hpq) > thr) {
+      const double al = 0.5 * (hqq - hpp) * ih, hq = hpq * ih;
+      const double x = fma(al, al, hq * hq);
+      const double rr = x * rsq_nr(x);
+      const double t = (al >= 0.0 ? hq : -hq) * rcp_nr(fabs(al) + rr);
+      r.x = rsq_nr3(fma(t, t, 1.0));
+      r.y = t * r.x;
+      atomicAdd(rot + sweep_parity, 1);
+    }
+    csn[buf * np + k] = r;
+    log[int64_t(glog) * np + k] = r;
+  };
+  if (tid < np) params(0, 0, 1, 0);
+  __syncthreads();
+  int sweep = 0, g = 0;
+  bool done = false;
+  while (sweep < max_sweeps && !done) {
+    ++sweep;
+    const int par = sweep & 1;
+    if (tid == 0) rot[par ^ 1] = 0;
+    for (int round = 0; round < m1; ++round, ++g) {
+      const jac_cs* cur = csn + (g & 1) * np;
+      {
+        int o[NB_][4];
+        double m[NB_][4];
+        jac_cs ra[NB_], rb[NB_];
+#pragma unroll
+        for (int j = 0; j < NB_; ++j) {
+          int p1, q1, p2, q2;
+          pair_of(round, bka[j], m1, p1, q1);
+          pair_of(round, bkb[j], m1, p2, q2);
+          o[j][0] = tri_off(p1, p2);
+          o[j][1] = tri_off(p1, q2);
+          o[j][2] = tri_off(q1, p2);
+          o[j][3] = tri_off(q1, q2);
+          ra[j] = cur[bka[j]];
+          rb[j] = cur[bkb[j]];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) m[j][e] = Hs[o[j][e]];
+        }
+#pragma unroll
+        for (int j = 0; j < NB_; ++j) {
+          const double ca = ra[j].x, sa = ra[j].y, cb = rb[j].x, sb = rb[j].y;
+          const double n00 = cb * m[j][0] - sb * m[j][1], n01 = sb * m[j][0] + cb * m[j][1];
+          const double n10 = cb * m[j][2] - sb * m[j][3], n11 = sb * m[j][2] + cb * m[j][3];
+          double o00 = ca * n00 - sa * n10, o10 = sa * n00 + ca * n10;
+          double o01 = ca * n01 - sa * n11, o11 = sa * n01 + ca * n11;
+          if (bka[j] == bkb[j] && sa != 0.0) { o01 = 0.0; o10 = 0.0; }   // the rotated pair itself (one storage cell)
+          if (bon[j]) { Hs[o[j][0]] = o00; Hs[o[j][1]] = o01; Hs[o[j][2]] = o10; Hs[o[j][3]] = o11; }
+        }
+      }
+      lds_barrier();
+      if (tid < np) {
+        const bool last = round + 1 == m1;
+        params(last ? 0 : round + 1, (g & 1) ^ 1, last ? (par ^ 1) : par, g + 1);
+      }
+      lds_barrier();
+    }
+    done = (rot[par] == 0);
+    lds_barrier();
+  }
+  __syncthreads();
+  for (int i = tid; i < d; i += nt) w[i] = Hs[tri_off(i, i)];
+  if (tid == 0) { status[0] = done ? sweep : -1; status[1] = g; }
+}
+
+__global__ __launch_bounds__(1024) void k_syev_packed1(int d, const double* __restrict__ A, int64_t lda, double* __restrict__ w,
+                                                       jac_cs* __restrict__ log, double tol, int max_sweeps, int* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) char jac_smem[];
+  syev_packed_body<1>(jac_smem, d, A, lda, w, log, tol, max_sweeps, status);            // d <= 88 (990 blocks)
+}
+__global__ __launch_bounds__(1024) void k_syev_packed2(int d, const double* __restrict__ A, int64_t lda, double* __restrict__ w,
+                                                       jac_cs* __restrict__ log, double tol, int max_sweeps, int* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) char jac_smem[];
+  syev_packed_body<2>(jac_smem, d, A, lda, w, log, tol, max_sweeps, status);            // d <= 126
+}
+__global__ __launch_bounds__(1024) void k_syev_packed4(int d, const double* __restrict__ A, int64_t lda, double* __restrict__ w,
+                                                       jac_cs* __restrict__ log, double tol, int max_sweeps, int* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) char jac_smem[];
+  syev_packed_body<4>(jac_smem, d, A, lda, w, log, tol, max_sweeps, status);            // d <= 160 (3240 blocks)
+}
+
+constexpr int JR_COLS = 16, JR_SLOTS = 16, JR_MAXK = 5;      // 256 threads: 16 columns x 16 pair slots, np <= 80
+constexpr int JR_CHUNK = 16;                                  // rounds of parameters staged through LDS at a time
+__global__ __launch_bounds__(256) void k_jacobi_replay(int d, const jac_cs* __restrict__ log, int rounds, double* __restrict__ Vt,
+                                                       int64_t ldv) {
+  __shared__ double Vs[160 * (JR_COLS + 1)];
+  __shared__ jac_cs Ps[2][JR_CHUNK * 80];                     // two chunks of (c, s): one in use, one being filled
+  const int pe = (d + 1) & ~1, m1 = pe - 1, np = pe >> 1;
+  const int tid = threadIdx.x, col = tid & (JR_COLS - 1), slot = tid >> 4;
+  const int col0 = blockIdx.x * JR_COLS;
+  for (int e = tid; e < pe * JR_COLS; e += 256) {
+    const int r = e >> 4, cc = e & 15;
+    Vs[r * (JR_COLS + 1) + cc] = (r == col0 + cc && r < d) ? 1.0 : 0.0;
+  }
+  // the log is one contiguous array of rounds * np entries: a chunk is JR_CHUNK * np consecutive entries (<= 1280: 5 per thread)
+  const int per_chunk = JR_CHUNK * np;
+  const int64_t total = int64_t(rounds) * np;
+  jac_cs stage[JR_MAXK];
+  auto fetch = [&](int chunk) {
+#pragma unroll
+    for (int j = 0; j < JR_MAXK; ++j) {
+      const int e = tid + 256 * j;
+      const int64_t gidx = int64_t(chunk) * per_chunk + e;
+      stage[j] = (e < per_chunk && gidx < total) ? log[gidx] : jac_cs{1.0, 0.0};
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < JR_MAXK; ++j) {
+      const int e = tid + 256 * j;
+      if (e < per_chunk) Ps[buf][e] = stage[j];
+    }
+  };
+  const int nchunks = (rounds + JR_CHUNK - 1) / JR_CHUNK;
+  if (nchunks > 0) { fetch(0); stash(0); }
+  __syncthreads();
+  int round = 0;
+  for (int ch = 0; ch < nchunks; ++ch) {
+    if (ch + 1 < nchunks) fetch(ch + 1);                       // global latency hides behind this chunk's rounds
+    const jac_cs* P = Ps[ch & 1];
+    const int r_end = min(JR_CHUNK, rounds - ch * JR_CHUNK);
+    for (int rr = 0; rr < r_end; ++rr) {
+      int op[JR_MAXK], oq[JR_MAXK];
+      double x[JR_MAXK], y[JR_MAXK];
+      jac_cs cs[JR_MAXK];
+#pragma unroll
+      for (int j = 0; j < JR_MAXK; ++j) {
+        const int k = min(slot + JR_SLOTS * j, np - 1);
+        int p, q;
+        pair_of(round, k, m1, p, q);
+        op[j] = p * (JR_COLS + 1) + col;
+        oq[j] = q * (JR_COLS + 1) + col;
+        cs[j] = P[rr * np + k];
+        x[j] = Vs[op[j]];
+        y[j] = Vs[oq[j]];
+      }
+#pragma unroll
+      for (int j = 0; j < JR_MAXK; ++j)
+        if (slot + JR_SLOTS * j < np) {
+          Vs[op[j]] = cs[j].x * x[j] - cs[j].y * y[j];
+          Vs[oq[j]] = cs[j].y * x[j] + cs[j].x * y[j];
+        }
+      lds_barrier();
+      if (++round == m1) round = 0;
+    }
+    if (ch + 1 < nchunks) stash((ch + 1) & 1);                 // nobody reads that buffer during this chunk
+    __syncthreads();
+  }
+  if (col0 + col < d)
+    for (int r = slot; r < d; r += JR_SLOTS) Vt[int64_t(r) * ldv + col0 + col] = Vs[r * (JR_COLS + 1) + col];
+}
+
 static size_t syev_small_lds(int64_t d) {
   const int64_t pe = (d + 1) & ~int64_t(1), np = pe / 2, sd = pe | 1;
   return size_t(2 * pe * sd + 18 + 4 * np) * 8;          // H, V', 16 maxima, 2 counters (+ pad), 2 x np (c, s)
 }
 
-int syev_small_max(ccz_ctx*) {
-  static const int on = [] { const char* e = getenv("CCZ_SYEV_TWOSIDED"); return e ? atoi(e) : 1; }();
-  return on ? 96 : 0;
+static int syev_mode() {   // 0: one-sided rows (round 1), 1: fused two-sided LDS kernel (d <= 96), 2: packed H + replayed V' (d <= 160)
+  static const int m = [] { const char* e = getenv("CCZ_SYEV_TWOSIDED"); return e ? atoi(e) : 2; }();
+  return m;
 }
 
+int syev_small_max(ccz_ctx*) { return syev_mode() == 2 ? 160 : (syev_mode() == 1 ? 96 : 0); }
+
 int syev_small(ccz_ctx* c, const double* A, int64_t d, int64_t lda, double* w_dev, double* Vrows, int64_t ldv, int max_sweeps) {
-  if (d < 1 || d > 96) fail(CCZ_EINVAL, "syev_small: 1 <= d <= 96 required, got %lld", (long long)d);
+  const int dmax = syev_small_max(c);
+  if (d < 1 || d > dmax) fail(CCZ_EINVAL, "syev_small: 1 <= d <= %d required, got %lld", dmax, (long long)d);
   Impl* im = impl(c);
-  const size_t lds_need = syev_small_lds(d);
-  if (d <= 80) {
-    CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_syev_small), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_need)));
-    hipLaunchKernelGGL(k_syev_small, dim3(1), dim3(1024), lds_need, stream(c), int(d), A, lda, w_dev, Vrows, ldv,
-                       2.220446049250313e-16, max_sweeps, im->d_flag + 1);
-  } else {
-    CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_syev_small_wide), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_need)));
-    hipLaunchKernelGGL(k_syev_small_wide, dim3(1), dim3(1024), lds_need, stream(c), int(d), A, lda, w_dev, Vrows, ldv,
-                       2.220446049250313e-16, max_sweeps, im->d_flag + 1);
-  }
-  CCZ_LAUNCH_CHECK();
   int sw = 0;
-  d2h(c, &sw, im->d_flag + 1, sizeof(int));
+  if (syev_mode() == 2) {
+    const int64_t pe = (d + 1) & ~int64_t(1), m1 = pe - 1, np = pe / 2;
+    const int64_t nH = pe * (pe + 1) / 2, nblk = np * (np + 1) / 2;
+    const size_t lds_need = size_t(((nH + 1) & ~int64_t(1)) + 18 + 4 * np) * 8;
+    DBuf logb(c, (int64_t(max_sweeps) * m1 + 1) * np * 2);
+    jac_cs* log = reinterpret_cast<jac_cs*>(logb.get());
+    auto launch = [&](auto kern) {
+      CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_need)));
+      hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds_need, stream(c), int(d), A, lda, w_dev, log, 2.220446049250313e-16,
+                         max_sweeps, im->d_flag + 2);
+    };
+    if (nblk <= 1024) launch(&k_syev_packed1);
+    else if (nblk <= 2048) launch(&k_syev_packed2);
+    else launch(&k_syev_packed4);
+    CCZ_LAUNCH_CHECK();
+    int st[2] = {0, 0};
+    d2h(c, st, im->d_flag + 2, sizeof(st));
+    sw = st[0];
+    if (sw >= 1 && Vrows) {
+      // the last sweep of a converged run rotated nothing: the log's first (sweeps - 1) * m1 rounds are all of V
+      const int rounds = int((sw - 1) * m1);
+      hipLaunchKernelGGL(k_jacobi_replay, dim3((unsigned)((d + JR_COLS - 1) / JR_COLS)), dim3(256), 0, stream(c), int(d), log, rounds,
+                         Vrows, ldv);
+      CCZ_LAUNCH_CHECK();     // (the log goes back to the handle's pool: reuse is ordered behind this launch on the same stream)
+    }
+  } else {
+    const size_t lds_need = syev_small_lds(d);
+    if (d <= 80) {
+      CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_syev_small), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_need)));
+      hipLaunchKernelGGL(k_syev_small, dim3(1), dim3(1024), lds_need, stream(c), int(d), A, lda, w_dev, Vrows, ldv,
+                         2.220446049250313e-16, max_sweeps, im->d_flag + 1);
+    } else {
+      CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_syev_small_wide), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_need)));
+      hipLaunchKernelGGL(k_syev_small_wide, dim3(1), dim3(1024), lds_need, stream(c), int(d), A, lda, w_dev, Vrows, ldv,
+                         2.220446049250313e-16, max_sweeps, im->d_flag + 1);
+    }
+    CCZ_LAUNCH_CHECK();
+    d2h(c, &sw, im->d_flag + 1, sizeof(int));
+  }
   if (sw == -2) fail(CCZ_EINVAL, "syev: matrix has non-finite entries");
   if (sw < 0) fail(CCZ_ENOCONV, "Jacobi did not converge in %d sweeps (d=%lld)", max_sweeps, (long long)d);
   return sw;

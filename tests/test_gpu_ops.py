@@ -94,7 +94,7 @@ def test_potrf_reports_not_spd(H):
         call(H, "ccz_potrf_lower", vp(Ad), 70, 70)
 
 
-@pytest.mark.parametrize("d", [2, 3, 12, 65, 79, 80, 96, 97, 150])
+@pytest.mark.parametrize("d", [2, 3, 12, 65, 79, 80, 89, 96, 97, 127, 150, 159, 160, 161, 200])
 def test_syevj(H, d):
     rng = np.random.default_rng(d)
     if d == 12:   # +/- eigenvalue pairs
