@@ -1609,6 +1609,24 @@ __device__ __forceinline__ void pair_of(int round, int k, int m1, int& a, int& b
   b = round - k; if (b < 0) b += m1;
 }
 
+// (c, s) of the rotation that annihilates h_pq, from the pair's three entries scaled by 1 / max|H|.
+// A dependent fp64 VALU operation costs 32 cycles on gfx950 (measured: tools/probes/clock_probe.hip), and this chain is
+// the serial part of every round, so it is written for depth, not for operation count:
+//   u = |al| / r,  r = sqrt(al^2 + h^2),  al = (h_qq - h_pp) / 2:   c = sqrt((1 + u) / 2),  s = sgn(al) h / (2 r c)
+// with two reciprocal square roots (1 / r and 1 / c) -- 18 dependent operations instead of the 31 of
+// t = h / (|al| + r), c = 1 / sqrt(1 + t^2), s = t c.  c^2 + s^2 = (1 + u)/2 + (1 - u)/2 holds to rounding.
+__device__ __forceinline__ jac_cs jac_rotation(double hpp, double hqq, double hpq, double ih) {
+  const double al = 0.5 * (hqq - hpp) * ih, hq = hpq * ih;
+  const double x = fma(al, al, hq * hq);
+  const double y = rsq_nr(x);                              // 1 / r
+  const double c2 = fma(0.5 * fabs(al), y, 0.5);           // c^2 = (1 + |al| / r) / 2  in [1/2, 1]
+  const double z = rsq_nr3(c2);                            // 1 / c
+  jac_cs r;
+  r.x = c2 * z;
+  r.y = (al >= 0.0 ? 0.5 : -0.5) * hq * y * z;
+  return r;
+}
+
 template <int NB_, int NV_>   // H blocks / V' items per thread (compile-time: the slot arrays must stay in registers)
 __device__ __forceinline__ void syev_small_body(char* smem, int d, const double* __restrict__ A, int64_t lda, double* __restrict__ w,
                                                 double* __restrict__ Vt, int64_t ldv, double tol, int max_sweeps,
@@ -1682,12 +1700,7 @@ __device__ __forceinline__ void syev_small_body(char* smem, int d, const double*
     const double hpq = Hs[a * sd + b], hqq = Hs[b * sd + b], hpp = Hs[a * sd + a];
     jac_cs r = {1.0, 0.0};
     if (fabs(hpq) > thr) {
-      const double al = 0.5 * (hqq - hpp) * ih, hq = hpq * ih;          // scaled: no under/overflow
-      const double x = fma(al, al, hq * hq);
-      const double rr = x * rsq_nr(x);
-      const double t = (al >= 0.0 ? hq : -hq) * rcp_nr(fabs(al) + rr);
-      r.x = rsq_nr3(fma(t, t, 1.0));
-      r.y = t * r.x;
+      r = jac_rotation(hpp, hqq, hpq, ih);
       atomicAdd(rot + sweep_parity, 1);
     }
     csn[buf * np + k] = r;
@@ -1866,12 +1879,7 @@ __device__ __forceinline__ void syev_packed_body(char* smem, int d, const double
     const double hpq = Hs[tri_off(a, b)], hqq = Hs[tri_off(b, b)], hpp = Hs[tri_off(a, a)];
     jac_cs r = {1.0, 0.0};
     if (fabs(hpq) > thr) {
-      const double al = 0.5 * (hqq - hpp) * ih, hq = hpq * ih;
-      const double x = fma(al, al, hq * hq);
-      const double rr = x * rsq_nr(x);
-      const double t = (al >= 0.0 ? hq : -hq) * rcp_nr(fabs(al) + rr);
-      r.x = rsq_nr3(fma(t, t, 1.0));
-      r.y = t * r.x;
+      r = jac_rotation(hpp, hqq, hpq, ih);
       atomicAdd(rot + sweep_parity, 1);
     }
     csn[buf * np + k] = r;
