@@ -113,6 +113,12 @@ void potrf_lower_batched_aux(ccz_ctx* c, int count, double* const* A, const int6
                              double* const* aux);
 void trsm_right_lower_aux(ccz_ctx* c, bool trans, int64_t r, int64_t d, const double* L, int64_t ldl, double* X,
                           int64_t ldx, const double* aux);
+// The same solve for `count` independent problems with FEW rows each (the back-projections of the k wanted
+// directions, r_b = k): their dependent steps advance together in batched launches.  aux[b] as above (a backend may
+// fall back to a loop over trsm_right_lower_aux when one is null or the shapes do not suit it).
+void trsm_right_lower_aux_multi(ccz_ctx* c, int count, bool trans, const int64_t* r, const int64_t* d,
+                                const double* const* L, const int64_t* ldl, double* const* X, const int64_t* ldx,
+                                const double* const* aux);
 // out (cols x rows) = in (rows x cols)'
 void transpose(ccz_ctx* c, int64_t rows, int64_t cols, const double* in, int64_t ldi, double* out,
                int64_t ldo);

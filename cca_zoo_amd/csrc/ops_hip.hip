@@ -1394,6 +1394,58 @@ void trsm_right_lower(ccz_ctx* c, bool trans, int64_t r, int64_t d, const double
   else trsm_right_lower_iter(c, trans, r, d, L, ldl, X, ldx);
 }
 
+// Few-row solves of several problems together (back-projection of the k wanted directions through every view's
+// factor).  One problem alone is 2 dependent launches per super-block, each a 64-row product that cannot fill the chip
+// (31 us apiece, 16 per 4096-column factor); here every step is two batched split-K launches for ALL problems:
+//   stage 1:  Y_b[:, J] += X_b[:, J] inv(L_b,JJ)^(T)           (Y zeroed once; result accumulates out of place)
+//   stage 2:  X_b[:, rest] -= Y_b[:, J] L_b[., .]^(T)            (the not yet solved columns)
+void trsm_right_lower_aux_multi(ccz_ctx* c, int count, bool trans, const int64_t* r, const int64_t* d, const double* const* L,
+                                const int64_t* ldl, double* const* X, const int64_t* ldx, const double* const* aux) {
+  bool batched = !solver_legacy() && count >= 1 && count <= 8;
+  for (int b = 0; b < count && batched; ++b) batched = aux && aux[b] && d[b] > 1024 && r[b] >= 1 && r[b] <= 256;
+  if (!batched) {
+    for (int b = 0; b < count; ++b) trsm_right_lower_aux(c, trans, r[b], d[b], L[b], ldl[b], X[b], ldx[b], aux ? aux[b] : nullptr);
+    return;
+  }
+  int64_t total = 0, offs[8], nsb[8], max_nsb = 0;
+  for (int b = 0; b < count; ++b) {
+    offs[b] = total;
+    total += r[b] * d[b];
+    nsb[b] = (d[b] + SB - 1) / SB;
+    max_nsb = std::max(max_nsb, nsb[b]);
+  }
+  DBuf Y(c, total);
+  zero(c, Y, size_t(total) * 8);
+  for (int64_t st = 0; st < max_nsb; ++st) {
+    MultiGemmArgs s1[8], s2[8];
+    int n1 = 0, n2 = 0;
+    for (int b = 0; b < count; ++b) {
+      if (st >= nsb[b]) continue;
+      const int64_t J = trans ? st : nsb[b] - 1 - st;
+      const int64_t j0 = J * SB, w = std::min(SB, d[b] - j0);
+      double* Yb = Y.get() + offs[b];
+      MultiGemmArgs& a = s1[n1++];
+      a = MultiGemmArgs{};
+      a.A = X[b] + j0; a.lda = ldx[b]; a.tA = false;
+      a.B = aux[b] + J * SB * SB; a.ldb = SB; a.tB = trans;
+      a.C = Yb + j0; a.ldc = d[b]; a.Ct = nullptr; a.ldct = 0;
+      a.M = r[b]; a.N = w; a.K = w; a.alpha = 1.0; a.beta = 1.0; a.lower_only = false; a.ksplit = 4;
+      const int64_t rest = trans ? d[b] - j0 - w : j0;
+      if (rest <= 0) continue;
+      MultiGemmArgs& u = s2[n2++];
+      u = MultiGemmArgs{};
+      u.A = Yb + j0; u.lda = d[b]; u.tA = false;
+      if (trans) { u.B = L[b] + (j0 + w) * ldl[b] + j0; u.tB = true; u.C = X[b] + j0 + w; }      // X[:, below] -= Y_J L[below, J]'
+      else { u.B = L[b] + j0 * ldl[b]; u.tB = false; u.C = X[b]; }                                  // X[:, :j0]  -= Y_J L[J, :j0]
+      u.ldb = ldl[b]; u.ldc = ldx[b]; u.Ct = nullptr; u.ldct = 0;
+      u.M = r[b]; u.N = rest; u.K = w; u.alpha = -1.0; u.beta = 1.0; u.lower_only = false; u.ksplit = 4;
+    }
+    if (n1 > 0) gemm_f64_multi(c, n1, s1);
+    if (n2 > 0) gemm_f64_multi(c, n2, s2);
+  }
+  for (int b = 0; b < count; ++b) copy2d(c, r[b], d[b], Y.get() + offs[b], d[b], X[b], ldx[b]);
+}
+
 // ===========================================================================
 // one-sided Jacobi on rows: one workgroup per row pair, one launch per tournament round
 // ===========================================================================

@@ -440,6 +440,26 @@ struct Whitener {
   }
 };
 
+// Ut_i (k x r_i, ld ldu_i) <- Ut_i F_i'  for several whiteners at once, in place (Cholesky whiteners: r_i = d_i; the
+// dependent super-block steps of all views share their launches).  Eigen-floored whiteners have an explicit F of
+// another shape and go one by one into out_i.
+void back_project_rows_multi(ccz_ctx* c, const std::vector<const Whitener*>& F, int64_t k, const std::vector<double*>& Ut,
+                             const std::vector<int64_t>& ldu) {
+  std::vector<int64_t> rr, dd, ll, lx;
+  std::vector<const double*> Lp, Ap;
+  std::vector<double*> Xp;
+  for (size_t i = 0; i < F.size(); ++i) {
+    if (!F[i]->chol) fail(CCZ_EINVAL, "back_project_rows_multi: Cholesky whiteners only");
+    rr.push_back(k); dd.push_back(F[i]->d); ll.push_back(F[i]->d); lx.push_back(ldu[i]);
+    Lp.push_back(F[i]->L.get()); Ap.push_back(F[i]->aux.get()); Xp.push_back(Ut[i]);
+  }
+  for (size_t b0 = 0; b0 < F.size(); b0 += 8) {
+    const int cnt = int(std::min<size_t>(8, F.size() - b0));
+    trsm_right_lower_aux_multi(c, cnt, false, rr.data() + b0, dd.data() + b0, Lp.data() + b0, ll.data() + b0, Xp.data() + b0,
+                               lx.data() + b0, Ap.data() + b0);
+  }
+}
+
 // R_i (d_i x d_i, consumed) -> Whiteners; the Cholesky panel chains of all blocks run batched.
 // allow_floor: a block whose Cholesky fails falls back to the eigen-floored explicit factor
 // (rCCA c = 0 on rank-deficient data); otherwise ENOTSPD.
@@ -616,11 +636,17 @@ static void rcca_solve_impl(ccz_ctx* c, const double* mom, int64_t n, const int6
   DBuf Ut(c, int64_t(kk) * r1), Vt(c, int64_t(kk) * r2);
   svd_topk_dense(c, Tt, r1, r2, kk, sv, Ut, Vt);
 
-  DBuf W1t(c, int64_t(kk) * d1), W2t(c, int64_t(kk) * d2);
-  F1.back_project_rows(c, kk, Ut, r1, W1t, d1);
-  F2.back_project_rows(c, kk, Vt, r2, W2t, d2);
-  rows_to_host_cols(c, W1t, kk, d1, d1, 1.0, W_host);
-  rows_to_host_cols(c, W2t, kk, d2, d2, 1.0, W_host + d1 * kk);
+  if (F1.chol && F2.chol) {          // r_i = d_i: in place, both views' dependent steps in shared launches
+    back_project_rows_multi(c, {&F1, &F2}, kk, {Ut.get(), Vt.get()}, {r1, r2});
+    rows_to_host_cols(c, Ut, kk, d1, d1, 1.0, W_host);
+    rows_to_host_cols(c, Vt, kk, d2, d2, 1.0, W_host + d1 * kk);
+  } else {
+    DBuf W1t(c, int64_t(kk) * d1), W2t(c, int64_t(kk) * d2);
+    F1.back_project_rows(c, kk, Ut, r1, W1t, d1);
+    F2.back_project_rows(c, kk, Vt, r2, W2t, d2);
+    rows_to_host_cols(c, W1t, kk, d1, d1, 1.0, W_host);
+    rows_to_host_cols(c, W2t, kk, d2, d2, 1.0, W_host + d1 * kk);
+  }
   means_out(c, s, D, n, ctr, means_host);
   if (vals_host) std::copy(sv.begin(), sv.begin() + kk, vals_host);
   if (k_out) *k_out = kk;
@@ -684,8 +710,14 @@ static void mcca_solve_impl(ccz_ctx* c, const double* mom, int64_t n, const int6
   S.reset();
   // v_i = sqrt(m) L_i^-T y_i   (normalisation v'(B/m)v = 1 of LAPACK sygvx on (A/m, B/m))
   int64_t wofs = 0;
+  {
+    std::vector<const Whitener*> Fp;
+    std::vector<double*> Yp;
+    std::vector<int64_t> ldy;
+    for (int i = 0; i < m; ++i) { Fp.push_back(&F[i]); Yp.push_back(Yt.get() + off[i]); ldy.push_back(D); }
+    back_project_rows_multi(c, Fp, kk, Yp, ldy);       // make_whiteners(allow_floor = false): all Cholesky
+  }
   for (int i = 0; i < m; ++i) {
-    F[i].back_project_rows(c, kk, Yt.get() + off[i], D, Yt.get() + off[i], D);
     rows_to_host_cols(c, Yt.get() + off[i], kk, dims[i], D, std::sqrt(double(m)), W_host + wofs);
     wofs += dims[i] * kk;
   }

@@ -217,6 +217,12 @@ void trsm_right_lower_aux(ccz_ctx* c, bool trans, int64_t r, int64_t d, const do
   trsm_right_lower(c, trans, r, d, L, ldl, X, ldx);
 }
 
+void trsm_right_lower_aux_multi(ccz_ctx* c, int count, bool trans, const int64_t* r, const int64_t* d,
+                                const double* const* L, const int64_t* ldl, double* const* X, const int64_t* ldx,
+                                const double* const*) {
+  for (int b = 0; b < count; ++b) trsm_right_lower(c, trans, r[b], d[b], L[b], ldl[b], X[b], ldx[b]);
+}
+
 // Two-sided Jacobi in the device kernel's own formulation (k_syev_small, ops_hip.hip): round-robin tournament,
 // all rotation parameters of a round from the current H, then every 2 x 2 block R_a' M R_b and the rows of V'.
 int syev_small_max(ccz_ctx*) { return 160; }

@@ -378,6 +378,21 @@ def test_potrf_and_trsm_large(H, d):
         assert float((back - B).abs().max() / B.abs().max()) < 1e-9, (d, trans)
 
 
+@pytest.mark.parametrize("d,bad", [(2048, 1500), (4500, 4499), (4096, 3)])
+def test_potrf_large_reports_the_first_bad_pivot(H, d, bad):
+    """The super-blocked factorization with look-ahead on a second stream must still name the first non-positive pivot
+    (its pivot flags are read once, at the end) and leave the handle usable."""
+    import torch
+
+    A = torch.eye(d, dtype=torch.float64, device="cuda") * 2.0
+    A[bad, bad] = -1.0
+    with pytest.raises(np.linalg.LinAlgError, match=f"pivot {bad}"):
+        H.check(H.lib.ccz_potrf_lower(H.raw, C.c_void_p(A.data_ptr()), d, d))
+    B = torch.eye(d, dtype=torch.float64, device="cuda") * 4.0
+    H.check(H.lib.ccz_potrf_lower(H.raw, C.c_void_p(B.data_ptr()), d, d))
+    assert float((torch.diagonal(B) - 2.0).abs().max()) == 0.0
+
+
 def test_syevj_two_sided_rayleigh_ritz_spectra(H):
     """The two-sided Jacobi kernel (d <= 96) on the matrices the Rayleigh-Ritz steps actually produce: a cluster of 64
     eigenvalues 1e-5 apart above a noise floor, an exactly diagonal matrix, a zero matrix, and non-finite input."""
