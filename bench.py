@@ -550,12 +550,19 @@ def main():
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
-    # RCCL writes its version banner to the C stdout buffer, which would otherwise be flushed at exit AFTER the
-    # result: flush C stdio first so that the JSON is the last line on stdout
+    # RCCL writes its version banner into the C stdout buffer (it would be flushed at exit, AFTER the result).  The
+    # contract is ONE JSON line on rank 0's stdout: drain the C buffer with fd 1 pointed at stderr, then print.
+    sys.stdout.flush()
     try:
         import ctypes
 
-        ctypes.CDLL(None).fflush(None)
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            ctypes.CDLL(None).fflush(None)
+        finally:
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
     except Exception:
         pass
     if line is not None:
