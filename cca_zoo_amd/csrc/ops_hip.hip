@@ -1648,12 +1648,6 @@ __device__ __forceinline__ double rsq_nr3(double x) {      // the cosine: c^2 + 
   double y = rsq_nr(x);
   return y * fma(-0.5 * x * y, y, 1.5);
 }
-__device__ __forceinline__ double rcp_nr(double x) {
-  double y = __builtin_amdgcn_rcp(x);
-  y = y * fma(-x, y, 2.0);
-  y = y * fma(-x, y, 2.0);
-  return y;
-}
 typedef double jac_cs __attribute__((ext_vector_type(2)));   // (cosine, sine) of one rotation
 __device__ __forceinline__ void pair_of(int round, int k, int m1, int& a, int& b) {
   if (k == 0) { a = m1; b = round; return; }

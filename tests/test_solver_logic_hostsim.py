@@ -208,6 +208,32 @@ def test_syevj_indefinite_with_plus_minus_pairs(H):
     assert 1 <= sw.value <= 30
 
 
+@pytest.mark.parametrize("d", [2, 3, 79, 80, 159, 160, 161])
+def test_syevj_two_sided_sizes_and_the_one_sided_path_beyond(H, d):
+    """The Rayleigh-Ritz eigen-solve: two-sided tournament Jacobi up to d = 160 (odd sizes pad a zero row / column),
+    the one-sided row Jacobi beyond -- both behind ccz_syevj; the host double runs the device kernel's formulation."""
+    rng = np.random.default_rng(d)
+    A = rng.standard_normal((d, d))
+    A = A + A.T
+    A0 = A.copy()
+    w, V = np.zeros(d), np.zeros((d, d))
+    sw = C.c_int(0)
+    _call(H, "ccz_syevj", _p(A), d, _p(w), _p(V), C.byref(sw))
+    scale = np.abs(A0).sum(1).max()
+    np.testing.assert_allclose(w, np.linalg.eigvalsh(A0)[::-1], atol=1e-13 * scale)
+    np.testing.assert_allclose(V @ A0 @ V.T, np.diag(w), atol=1e-12 * scale)
+    np.testing.assert_allclose(V @ V.T, np.eye(d), atol=1e-12)
+    assert 1 <= sw.value <= 30
+
+
+def test_syevj_rejects_non_finite_input(H):
+    A = np.eye(40)
+    A[3, 7] = A[7, 3] = np.inf
+    w, V = np.zeros(40), np.zeros((40, 40))
+    with pytest.raises(ValueError, match="non-finite"):
+        _call(H, "ccz_syevj", _p(A), 40, _p(w), _p(V), None)
+
+
 @pytest.mark.parametrize("shape", [(9, 14), (14, 9), (6, 6)])
 def test_gesvj(H, shape):
     rng = np.random.default_rng(1)
