@@ -1407,6 +1407,7 @@ void trsm_right_lower_aux_multi(ccz_ctx* c, int count, bool trans, const int64_t
     for (int b = 0; b < count; ++b) trsm_right_lower_aux(c, trans, r[b], d[b], L[b], ldl[b], X[b], ldx[b], aux ? aux[b] : nullptr);
     return;
   }
+  static const int bp_split = [] { const char* e = getenv("CCZ_BACKPROJ_SPLIT"); return e ? atoi(e) : 4; }();
   int64_t total = 0, offs[8], nsb[8], max_nsb = 0;
   for (int b = 0; b < count; ++b) {
     offs[b] = total;
@@ -1429,7 +1430,7 @@ void trsm_right_lower_aux_multi(ccz_ctx* c, int count, bool trans, const int64_t
       a.A = X[b] + j0; a.lda = ldx[b]; a.tA = false;
       a.B = aux[b] + J * SB * SB; a.ldb = SB; a.tB = trans;
       a.C = Yb + j0; a.ldc = d[b]; a.Ct = nullptr; a.ldct = 0;
-      a.M = r[b]; a.N = w; a.K = w; a.alpha = 1.0; a.beta = 1.0; a.lower_only = false; a.ksplit = 4;
+      a.M = r[b]; a.N = w; a.K = w; a.alpha = 1.0; a.beta = 1.0; a.lower_only = false; a.ksplit = bp_split;
       const int64_t rest = trans ? d[b] - j0 - w : j0;
       if (rest <= 0) continue;
       MultiGemmArgs& u = s2[n2++];
@@ -1438,7 +1439,7 @@ void trsm_right_lower_aux_multi(ccz_ctx* c, int count, bool trans, const int64_t
       if (trans) { u.B = L[b] + (j0 + w) * ldl[b] + j0; u.tB = true; u.C = X[b] + j0 + w; }      // X[:, below] -= Y_J L[below, J]'
       else { u.B = L[b] + j0 * ldl[b]; u.tB = false; u.C = X[b]; }                                  // X[:, :j0]  -= Y_J L[J, :j0]
       u.ldb = ldl[b]; u.ldc = ldx[b]; u.Ct = nullptr; u.ldct = 0;
-      u.M = r[b]; u.N = rest; u.K = w; u.alpha = -1.0; u.beta = 1.0; u.lower_only = false; u.ksplit = 4;
+      u.M = r[b]; u.N = rest; u.K = w; u.alpha = -1.0; u.beta = 1.0; u.lower_only = false; u.ksplit = bp_split;
     }
     if (n1 > 0) gemm_f64_multi(c, n1, s1);
     if (n2 > 0) gemm_f64_multi(c, n2, s2);
