@@ -171,6 +171,140 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64_big(int64_t M, int64_t N, i
     }
 }
 
+// ---------------------------------------------------------------------------
+// 64 x 128 tile variant for grids that the 128 x 128 tile cannot fill.  The super-block products of the triangular
+// solves and Cholesky panels are M x 512 x 512: at M = 4096 that is 128 tiles on 256 CUs, and a tile's 128 x 128 x 512
+// block is 55 us of fp64 MFMA time on its CU whatever the rest of the chip does.  Halving the tile height doubles
+// the workgroups (one per CU) and halves each one's MFMA time; the four waves sit side by side (64 rows x 32 columns
+// each: 4 x 2 MFMA tiles, all waves read the same A fragment rows).
+// ---------------------------------------------------------------------------
+constexpr int HM = 64;         // tile rows
+constexpr int HSA = HM + 2;    // LDS row stride of the A image
+
+template <bool KMAJOR, int W>   // 16 (k) x W (m) block, W = 64 or 128; same two layouts as Stager
+struct StagerW {
+  static constexpr int NI = W / 32;          // 16-byte loads per thread
+  static constexpr int TPR = W / 2;          // k-major: threads per k-row
+  static constexpr int RPP = 256 / TPR;      // k-major: k-rows per pass
+  v2f64 r[NI];
+  __device__ __forceinline__ void load(const double* __restrict__ P, int64_t ld, int64_t m0, int64_t mlim, int64_t k0, int tid) {
+    if (KMAJOR) {
+      const int64_t m = m0 + 2 * (tid % TPR);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const double* p = P + (k0 + tid / TPR + RPP * i) * ld;
+        if (m + 1 < mlim) {
+          r[i] = *reinterpret_cast<const v2f64*>(p + m);
+        } else {
+          r[i][0] = m < mlim ? p[m] : 0.0;
+          r[i][1] = 0.0;
+        }
+      }
+    } else {
+      const int kq = tid & 7;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int64_t m = std::min<int64_t>(m0 + (tid >> 3) + 32 * i, mlim - 1);
+        r[i] = *reinterpret_cast<const v2f64*>(P + m * ld + k0 + 2 * kq);
+      }
+    }
+  }
+  __device__ __forceinline__ void store(double* dst, int stride, int tid) const {
+    if (KMAJOR) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) *reinterpret_cast<v2f64*>(dst + (tid / TPR + RPP * i) * stride + 2 * (tid % TPR)) = r[i];
+    } else {
+      const int kq = tid & 7;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int m = (tid >> 3) + 32 * i;
+        dst[(2 * kq) * stride + m] = r[i][0];
+        dst[(2 * kq + 1) * stride + m] = r[i][1];
+      }
+    }
+  }
+};
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void k_gemm_f64_half(int64_t M, int64_t N, int64_t K, double alpha,
+                                                          const double* __restrict__ A, int64_t lda,
+                                                          const double* __restrict__ B, int64_t ldb, double beta,
+                                                          double* __restrict__ C, int64_t ldc) {
+  extern __shared__ __attribute__((aligned(16))) char smem_h[];
+  double* lds = reinterpret_cast<double*>(smem_h);   // [2 buffers][A: 16 x HSA | B: 16 x DS]
+  constexpr int BUF = DK * (HSA + DS);
+  const int64_t m0 = int64_t(blockIdx.y) * HM, n0 = int64_t(blockIdx.x) * DT;
+  const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6;     // wave wc: columns [32 wc, 32 wc + 32)
+  v4f64 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
+  StagerW<TA, HM> sa;
+  StagerW<!TB, DT> sb;
+  const int64_t nkb = K / DK;
+  sa.load(A, lda, m0, M, 0, tid);
+  sb.load(B, ldb, n0, N, 0, tid);
+  sa.store(lds, HSA, tid);
+  sb.store(lds + DK * HSA, DS, tid);
+  __syncthreads();
+  for (int64_t kb = 0; kb < nkb; ++kb) {
+    const int cur = int(kb & 1);
+    if (kb + 1 < nkb) {
+      sa.load(A, lda, m0, M, (kb + 1) * DK, tid);
+      sb.load(B, ldb, n0, N, (kb + 1) * DK, tid);
+    }
+    const double* as = lds + cur * BUF;
+    const double* bs = as + DK * HSA;
+#pragma unroll
+    for (int kk = 0; kk < DK / 4; ++kk) {
+      const int krow = 4 * kk + (lane >> 4);
+      const double* ap = as + krow * HSA + 4 * (lane & 15);
+      const double* bp = bs + krow * DS + wc * 32 + 2 * (lane & 15);
+      const v2f64 a01 = *reinterpret_cast<const v2f64*>(ap), a23 = *reinterpret_cast<const v2f64*>(ap + 2);
+      const v2f64 b01 = *reinterpret_cast<const v2f64*>(bp);
+      const double a4[4] = {a01[0], a01[1], a23[0], a23[1]};
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti) {
+        acc[ti][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[ti], b01[0], acc[ti][0], 0, 0, 0);
+        acc[ti][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[ti], b01[1], acc[ti][1], 0, 0, 0);
+      }
+    }
+    if (kb + 1 < nkb) {
+      double* nx = lds + (cur ^ 1) * BUF;
+      sa.store(nx, HSA, tid);
+      sb.store(nx + DK * HSA, DS, tid);
+    }
+    __syncthreads();
+  }
+  // C/D layout of the 16 x 16 tile: col (B side) = lane & 15, row (A side) = (lane >> 4) + 4 * reg; tile ti owns the rows
+  // == ti mod 4, tile tj the columns == tj mod 2 of the wave's 32
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t m = m0 + 4 * ((lane >> 4) + 4 * r) + ti;
+      if (m >= M) continue;
+      const int64_t nb = n0 + wc * 32 + 2 * (lane & 15);
+      double* cp = C + m * ldc + nb;
+      if (nb + 1 < N) {
+        v2f64 v = {alpha * acc[ti][0][r], alpha * acc[ti][1][r]};
+        if (beta != 0.0) {
+          const v2f64 c01 = *reinterpret_cast<const v2f64*>(cp);
+          v[0] += beta * c01[0];
+          v[1] += beta * c01[1];
+        }
+        *reinterpret_cast<v2f64*>(cp) = v;
+      } else if (nb < N) {
+        double v = alpha * acc[ti][0][r];
+        if (beta != 0.0) v += beta * cp[0];
+        cp[0] = v;
+      }
+    }
+}
+
 static int64_t env_ll(const char* name, int64_t dflt) {
   const char* e = getenv(name);
   return e ? atoll(e) : dflt;
@@ -210,6 +344,25 @@ void gemm_f64_big(ccz_ctx* c, bool tA, bool tB, int64_t M, int64_t N, int64_t K,
   if (!lower_only && tm * tn < 2 * int64_t(ncu) && K >= 2048) {
     splits = int(std::min<int64_t>({int64_t(16), (4 * ncu) / (tm * tn), K / 512}));
     if (splits < 2) splits = 1;
+  }
+  static const int64_t half_on = env_ll("CCZ_GEMM_HALF_TILE", 1);
+  if (half_on && splits == 1 && !lower_only && tm * tn < int64_t(ncu) && M > HM) {
+    const size_t lds_h = size_t(2) * DK * (HSA + DS) * 8;    // 49 KiB
+    dim3 gridh((unsigned)tn, (unsigned)((M + HM - 1) / HM), 1);
+#define CCZ_LAUNCH_HALF(TA_, TB_)                                                                                     \
+  do {                                                                                                                \
+    CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_f64_half<TA_, TB_>),                            \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_h)));                             \
+    hipLaunchKernelGGL((k_gemm_f64_half<TA_, TB_>), gridh, dim3(256), lds_h, st, M, N, K, alpha, A, lda, B, ldb, beta, \
+                       C, ldc);                                                                                       \
+  } while (0)
+    if (!tA && !tB) CCZ_LAUNCH_HALF(false, false);
+    else if (tA && !tB) CCZ_LAUNCH_HALF(true, false);
+    else if (!tA && tB) CCZ_LAUNCH_HALF(false, true);
+    else CCZ_LAUNCH_HALF(true, true);
+#undef CCZ_LAUNCH_HALF
+    CCZ_LAUNCH_CHECK();
+    return;
   }
   int64_t kps = K;
   if (splits > 1) {
