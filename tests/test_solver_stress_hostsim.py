@@ -86,3 +86,52 @@ def test_rcca_chebyshev_route(H, d1, d2, k):
     np.testing.assert_allclose(vals, vr[:k], rtol=1e-9, atol=1e-11)
     for w, r in zip(W, Wr):
         assert col_rel_err(w, r) < 1e-6
+
+
+@pytest.mark.parametrize("dims,k,c", [
+    ([120, 100, 90], 6, [0.95, 0.0, 0.5]),      # ridge close to 1: the proven lower bound -1 / (1 - c) is loose but valid
+    ([150, 130], 5, [0.0, 0.0]),                # two views, c = 0: spectrum in [-1, 1] with exact +/- pairs
+    ([80, 70, 60, 50], 8, [1.0, 0.2, 0.2, 0.2]),  # c = 1 on one view: no closed-form bound, falls back to -||S||_inf
+])
+def test_mcca_gcca_chebyshev_route_with_spectrum_bounds(H, dims, k, c):
+    """D > 192 and 3k < D: MCCA / GCCA go through the Chebyshev-filtered subspace iteration, whose damped interval now
+    starts at a PROVEN lower bound of the spectrum (MCCA: -max 1/(1-c_i); GCCA: the Gram form is PSD) instead of
+    -||S||_inf.  A bound that was not a bound would damp wanted directions: compare with the dense oracle."""
+    rng = np.random.default_rng(sum(dims) + k)
+    n = 1200
+    views = _data(rng, n, dims, latent=k + 2, noise=1.0)
+    G, s, _ = gf.moments(views)
+    mom = pack_moments(G, s)
+    W, _, vals = H.mcca_solve(mom, n, dims, c, 1e-6, True, k)
+    Wr, _, vr = gf.mcca_from_moments(G, s, n, dims, k, c=c, eps=1e-6, center=True)
+    np.testing.assert_allclose(vals, vr[:k], rtol=1e-9, atol=1e-11)
+    if _subspace_gap_ok(vr, k):
+        for w, r in zip(W, Wr):
+            assert col_rel_err(w, r) < 1e-6, ("mcca", dims, c)
+    cg = [min(ci, 0.9) for ci in c]
+    W, _, vals = H.gcca_solve(mom, n, dims, cg, [1.0] * len(dims), 1e-6, True, k)
+    Wr, _, vr = gf.gcca_from_moments(G, s, n, dims, k, c=cg, view_weights=[1.0] * len(dims), eps=1e-6, center=True)
+    np.testing.assert_allclose(vals, vr[:k], rtol=1e-8, atol=1e-10)
+    if _subspace_gap_ok(vr, k):
+        for w, r in zip(W, Wr):
+            assert col_rel_err(w, r) < 1e-6, ("gcca", dims, cg)
+
+
+def test_mcca_whitened_operator_lower_bound_is_a_bound():
+    """The inequality behind the MCCA hint, checked numerically: eigenvalues of L^-1 (C - blockdiag C) L^-T are
+    >= -max_i 1 / (1 - c_i) for R_i = (1 - c_i) C_ii + c_i I = L_i L_i'."""
+    rng = np.random.default_rng(5)
+    dims = [7, 5, 9]
+    X = rng.standard_normal((40, sum(dims))) @ rng.standard_normal((sum(dims), sum(dims)))
+    C = np.cov(X, rowvar=False)
+    off = np.cumsum([0] + dims)
+    for c in ([0.0, 0.0, 0.0], [0.3, 0.9, 0.0], [0.99, 0.5, 0.1]):
+        Li = np.zeros_like(C)
+        A = C.copy()
+        for i in range(3):
+            b = slice(off[i], off[i + 1])
+            R = (1 - c[i]) * C[b, b] + c[i] * np.eye(dims[i])
+            Li[b, b] = np.linalg.inv(np.linalg.cholesky(R))
+            A[b, b] = 0.0
+        lam = np.linalg.eigvalsh(Li @ A @ Li.T)
+        assert lam.min() >= -max(1.0 / (1.0 - ci) for ci in c) - 1e-10
