@@ -34,6 +34,9 @@ constexpr int LMAXV = 8;
 struct PrepArgs {
   int64_t off[LMAXV + 1];
   double* work[LMAXV];     // per-view copy of the diagonal block (consumed by the factorization)
+  double* zero_v[LMAXV];   // optional per-view d_a x d_a buffers to clear (split-K destinations), same indexing as work
+  double* zero_a;          // optional D x D buffers to clear
+  double* zero_b;
   int m;
 };
 
@@ -52,11 +55,15 @@ __global__ void k_loss_prep(const double* __restrict__ G, const double* __restri
     v = (v - s[i] * s[j] * inv_n) * inv_nm1;
     if (i == j) { v += eps; mean[i] = s[i] * inv_n; }
     Ce[e] = v;
+    if (pa.zero_a) pa.zero_a[e] = 0.0;
+    if (pa.zero_b) pa.zero_b[e] = 0.0;
     int a = 0;
     while (a + 1 < pa.m && i >= pa.off[a + 1]) ++a;
     if (j >= pa.off[a] && j < pa.off[a + 1]) {
       const int64_t da = pa.off[a + 1] - pa.off[a];
-      pa.work[a][(i - pa.off[a]) * da + (j - pa.off[a])] = v;
+      const int64_t q = (i - pa.off[a]) * da + (j - pa.off[a]);
+      pa.work[a][q] = v;
+      if (pa.zero_v[a]) pa.zero_v[a][q] = 0.0;
     }
   }
 }
@@ -151,6 +158,16 @@ void fused_core(ccz_ctx* c, const double* mom, int64_t n, const int64_t* dims, i
     T[a] = DBuf(c, nblk * 4096);
     pa.work[a] = work[a].get();
   }
+  // (split-K destinations of the product stages below are cleared by the same pass -- see there)
+  int64_t dmin = dims[0];
+  for (int a = 1; a < m; ++a) dmin = std::min(dmin, dims[a]);
+  static const int split_env = [] { const char* e = getenv("CCZ_LOSS_SPLITK"); return e ? atoi(e) : 4; }();
+  const int ks = (dmin >= 256 && split_env > 1) ? split_env : 1;
+  if (ks > 1) {
+    for (int a = 0; a < m; ++a) pa.zero_v[a] = Sinv[a].get();
+    pa.zero_a = Am.get();
+    pa.zero_b = want_grad ? gamma_dev : nullptr;
+  }
   hipLaunchKernelGGL(k_loss_prep, dim3((unsigned)std::min<int64_t>((D * D + 255) / 256, 4096)), dim3(256), 0, st, mom, mom + D * D, D,
                      1.0 / double(n), inv, eps, Ce.get(), mean_dev, pa, acc_dev, want_grad ? bias_dev : nullptr);
   CCZ_LAUNCH_CHECK();
@@ -165,15 +182,7 @@ void fused_core(ccz_ctx* c, const double* mom, int64_t n, const int64_t* dims, i
   // The four product stages below are dependent launches of at most a few hundred 64 x 64 tiles with K = d: on
   // their own they leave most of the chip idle for ~40 us each.  From d = 256 on the K range of every tile is cut
   // into four slices on separate workgroups that accumulate atomically into zeroed destinations (split-K).
-  int64_t dmin = dims[0];
-  for (int a = 1; a < m; ++a) dmin = std::min(dmin, dims[a]);
-  static const int split_env = [] { const char* e = getenv("CCZ_LOSS_SPLITK"); return e ? atoi(e) : 4; }();
-  const int ks = (dmin >= 256 && split_env > 1) ? split_env : 1;
-  if (ks > 1) {
-    for (int a = 0; a < m; ++a) zero(c, Sinv[a], size_t(dims[a]) * dims[a] * 8);
-    zero(c, Am, size_t(D) * D * 8);
-    if (want_grad) zero(c, gamma_dev, size_t(D) * D * 8);
-  }
+  // (ks, and the clearing of Sinv / Am / Gamma: in k_loss_prep above -- three fills fewer per call)
   auto launch = [&](std::vector<MultiGemmArgs>& v) {
     if (ks > 1)
       for (auto& g : v) { g.ksplit = ks; g.beta = 1.0; }       // destinations are zero (or hold the earlier terms of a sum)
