@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--with-sharded-dcca", action="store_true",
                     help="N > 1 only: also time CCALoss fwd+bwd on the batch sharded over the ranks (extra collectives "
                          "after the timed fits; off by default so that nothing can delay the headline result)")
+    ap.add_argument("--cpu-mcca", action="store_true",
+                    help="also time the reference-structured MCCA (BASELINE configs[2]: 4 x 2048, k=64) on a bounded sample: ~1 min of CPU")
     ap.add_argument("--cpu-sample-rows", type=int, default=16384, help="rows of the CPU comparator's sample (>= 4 d keeps it in the tall regime)")
     return ap.parse_args()
 
@@ -196,6 +198,45 @@ def cpu_baseline(n_full, d, k, sample_rows):
         "extrapolated_full_s": full, "extrapolation": f"measured_s * {n_full}/{sample_rows} (O(n d^2) thin SVD)",
         "blas_threads": threads, "sched_affinity": affinity, "cgroup_cpu_quota": quota, "logical_cpus": os.cpu_count(),
     }
+
+
+def cpu_mcca_baseline(n_full=1_000_000, d=2048, m=4, k=64, sample_rows=8192):
+    """``oracle.reference_form.mcca_weights`` (PCA per view, np.cov of the projections, eps-floor, scipy eigh subset:
+    cca_zoo/linear/_mcca.py:99-197) on ``sample_rows`` = 4 d rows of BASELINE configs[2]-shaped data.  The part that
+    grows with n (the m thin SVDs and the covariance: O(n D^2)) is timed on its own so that the extrapolation to the
+    full n only scales THAT part; the D^3 eigen-solve does not grow."""
+    import numpy as np
+
+    from oracle import reference_form as rf
+
+    affinity, quota = host_cores()
+    cores = int(min(affinity, quota)) if quota else affinity
+    views = [v.astype(np.float32) for v in rf.joint_data(m, sample_rows, k, [d] * m, 1.0, 0)]
+    try:
+        from threadpoolctl import threadpool_limits
+
+        limiter = threadpool_limits(limits=max(cores, 1))
+    except Exception:
+        limiter = None
+    try:
+        t0 = time.perf_counter()
+        vs, _ = rf.center_views(views, True)
+        fits = [rf._pca_full(v) for v in vs]
+        rf._between_view_cov([f[2] for f in fits])
+        t_data = time.perf_counter() - t0
+        del fits, vs
+        t0 = time.perf_counter()
+        rf.mcca_weights(views, k, c=0.0)
+        t_all = time.perf_counter() - t0
+    finally:
+        if limiter is not None:
+            limiter.restore_original_limits()
+    t_fixed = max(t_all - t_data, 0.0)
+    full = t_fixed + t_data * (n_full / sample_rows)
+    return {"metric": f"CPU MCCA fit (reference structure), {m} x {d}, k={k}", "sample_rows": sample_rows, "cores": max(cores, 1),
+            "measured_s": t_all, "data_dependent_s": t_data, "eigen_solve_s": t_fixed,
+            "extrapolated_full_s": full, "extrapolation": f"eigen_solve_s + data_dependent_s * {n_full}/{sample_rows}",
+            "value": 1.0 / full, "unit": "fit/s (extrapolated)"}
 
 
 def cpu_loss_baseline(batch=8192, d=512):
@@ -544,6 +585,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(a.n, a.d, a.k, a.cpu_sample_rows)
             if not a.no_extras:
                 out["cpu_baseline"]["dcca_loss_configs3"] = cpu_loss_baseline()
+            if a.cpu_mcca:
+                out["cpu_baseline"]["mcca_configs2"] = cpu_mcca_baseline()
         line = json.dumps(out)
     else:
         line = None
