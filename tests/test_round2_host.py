@@ -257,3 +257,19 @@ def test_grid_search_generic_route_refuses_row_shards(monkeypatch):
     views = _data(9, 60, (5, 4), 2)
     with pytest.raises(NotImplementedError, match="row_sharded"):
         GridSearchCV(rCCA(latent_dimensions=1), {"c": [0.1]}, cv=3, scoring="r2")._fit_generic(views)
+
+
+def test_bench_cpu_comparators_run_on_small_shapes():
+    """bench.py's CPU legs (the oracle timed as the baseline) on toy sizes: they must run and return finite, positive,
+    self-consistent fields -- the full-size runs take tens of seconds and only happen inside bench.py."""
+    import bench
+
+    r = bench.cpu_mcca_baseline(n_full=10_000, d=24, m=3, k=4, sample_rows=200)
+    assert r["measured_s"] > 0 and r["data_dependent_s"] > 0 and r["eigen_solve_s"] >= 0
+    assert abs(r["extrapolated_full_s"] - (r["eigen_solve_s"] + r["data_dependent_s"] * 10_000 / 200)) < 1e-9
+    assert abs(r["value"] * r["extrapolated_full_s"] - 1.0) < 1e-12
+    b = bench.cpu_baseline(5_000, 16, 3, 128)
+    assert b["kind"] == "port" and b["sample_rows"] == 128 and b["measured_s"] > 0
+    assert abs(b["extrapolated_full_s"] - b["measured_s"] * 5_000 / 128) < 1e-9
+    t, src = bench.gram_traffic("f32", 8192, 1000)
+    assert src is not None and "gram_traffic" in src and t > 1000 * 8192 * 4      # more than the algorithmic bytes
