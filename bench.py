@@ -47,37 +47,30 @@ def parse():
     ap.add_argument("--with-sharded-dcca", action="store_true",
                     help="N > 1 only: also time CCALoss fwd+bwd on the batch sharded over the ranks (extra collectives "
                          "after the timed fits; off by default so that nothing can delay the headline result)")
-    ap.add_argument("--cpu-mcca", action="store_true",
-                    help="also time the reference-structured MCCA (BASELINE configs[2]: 4 x 2048, k=64) on a bounded sample: ~1 min of CPU")
-    ap.add_argument("--cpu-sample-rows", type=int, default=16384, help="rows of the CPU comparator's sample (>= 4 d keeps it in the tall regime)")
+    ap.add_argument("--no-cpu-mcca", action="store_true",
+                    help="skip the reference-structured MCCA / GCCA comparators (BASELINE configs[2] / [4] on bounded samples: ~1 min of CPU)")
+    ap.add_argument("--cpu-mcca", action="store_true", help="(kept for compatibility: the MCCA comparator is on by default)")
+    ap.add_argument("--cpu-sample-rows", type=int, default=0,
+                    help="rows of the rCCA CPU comparator's sample (0: chosen so that one run takes ~10 s and three runs are timed)")
+    ap.add_argument("--no-gates", action="store_true", help="skip the parity gates of the extras (the headline gate always runs)")
     return ap.parse_args()
 
 
 # ---------------------------------------------------------------------------------------------------------------
 # parity gate
 # ---------------------------------------------------------------------------------------------------------------
-def check_fit_properties(model, views, jd, seed, row0=0, sharded=False, n_check=2048):
-    """Is ``model`` (a c = 0 CCA / rCCA fitted on ``views``) a CCA solution of THESE views?
-
-    * generator: rows regenerated on the host (``oracle.rng``, the NumPy restatement) equal the device rows;
-    * K1: the device moments of the first ``n_check`` local rows agree with the float64 Gram of the regenerated rows;
-    * solution (all rows; global under ``sharded``): every canonical variate has unit variance (w'C w = 1), the
-      variates of a view are uncorrelated, the cross-view correlation matrix is diag(singular values), the training
-      score equals the singular values, and those are non-increasing in (0, 1].
-    Returns a dict with ``ok`` and the measured deviations."""
-    import contextlib
-
+def k1_spot_check(views, jd, seed, row0=0, n_check=2048):
+    """Generator + K1 on the first ``n_check`` local rows: the rows regenerated on the host by the NumPy restatement
+    (``oracle.rng``) equal the device rows, and the device moments of those rows agree with their float64 Gram."""
     import numpy as np
 
-    from cca_zoo_amd import _backend, row_sharded
+    from cca_zoo_amd import _backend, _dist
     from cca_zoo_amd._moments import compute_moments
     from oracle import rng as orng
 
     rep = {}
-    tol = 1e-3 if views[0].element_size() == 4 else 1e-5
     ndt = np.float32 if views[0].element_size() == 4 else np.float64
-    n_local = int(views[0].shape[0])
-    m_rows = min(n_check, n_local)
+    m_rows = min(n_check, int(views[0].shape[0]))
     host = orng.joint_data_rows(jd._weights, jd._snr_per_view, jd.latent_scales, seed=seed, row0=row0, rows=m_rows, dtype=ndt)
     # the device forms the signal z W' with an fp32 (fp64) GEMM, the restatement in float64 then rounds: a few ulp
     # of the LARGEST summands -- compare relative to the largest element
@@ -86,8 +79,6 @@ def check_fit_properties(model, views, jd, seed, row0=0, sharded=False, n_check=
     ok = rep["generator_rel_diff"] < (4e-6 if ndt == np.float32 else 1e-12)
     # K1 on the checked rows (never sharded: a local quantity)
     h = _backend.handle_for(views)
-    from cca_zoo_amd import _dist
-
     with _dist.unsharded():
         mom, keep, _, dims, _ = compute_moments([v[:m_rows] for v in views], h)
     D = int(sum(dims))
@@ -98,7 +89,29 @@ def check_fit_properties(model, views, jd, seed, row0=0, sharded=False, n_check=
     Gref = X.T @ X
     scale = np.sqrt(np.outer(np.diag(Gref), np.diag(Gref)))[iu]
     rep["k1_rel_err"] = float((np.abs(flat[:D * D].reshape(D, D)[iu] - Gref[iu]) / scale).max())
-    ok = ok and rep["k1_rel_err"] < (2e-5 if ndt == np.float32 else 1e-12)
+    rep["ok"] = bool(ok and rep["k1_rel_err"] < (2e-5 if ndt == np.float32 else 1e-12))
+    return rep
+
+
+def check_fit_properties(model, views, jd, seed, row0=0, sharded=False, n_check=2048):
+    """Is ``model`` (a c = 0 CCA / rCCA fitted on ``views``) a CCA solution of THESE views?
+
+    * generator + K1 (``k1_spot_check``) on the first ``n_check`` local rows;
+    * solution (all rows; global under ``sharded``): every canonical variate has unit variance (w'C w = 1), the
+      variates of a view are uncorrelated, the cross-view correlation matrix is diag(singular values), the training
+      score equals the singular values, and those are non-increasing in (0, 1].
+    Returns a dict with ``ok`` and the measured deviations."""
+    import contextlib
+
+    import numpy as np
+
+    from cca_zoo_amd import _backend, row_sharded
+    from cca_zoo_amd._moments import compute_moments
+
+    rep = k1_spot_check(views, jd, seed, row0, n_check)
+    ok = rep.pop("ok")
+    tol = 1e-3 if views[0].element_size() == 4 else 1e-5
+    h = _backend.handle_for(views)
     # the solution on all rows
     ctx = row_sharded() if sharded else contextlib.nullcontext()
     with ctx:
@@ -121,6 +134,52 @@ def check_fit_properties(model, views, jd, seed, row0=0, sharded=False, n_check=
     rep["singular_values"] = [float(sv[0]), float(sv[-1])]
     ok = ok and rep["unit_variance_dev"] < 3 * tol and within < 3 * tol and rep["cross_view_dev"] < 3 * tol
     ok = ok and rep["score_vs_singular_values"] < 3 * tol and bool(np.all(np.diff(sv) <= 1e-9)) and 0.0 < sv[-1] and sv[0] <= 1.0 + 1e-9
+    rep["ok"] = bool(ok)
+    return rep
+
+
+def solution_gate(model, views, est, c, jd=None, seed=None, inertia=True):
+    """Parity gate of an extra configuration: (1) generator + K1 spot check on regenerated rows, (2) the fitted model is
+    THE top-k solution of the symmetric-definite pencil the reference's estimator defines (``oracle.certificates``:
+    eigen-residual, B-orthonormality, exactly k pencil eigenvalues above lambda_k by inertia) -- on the moments of the
+    timed views themselves.  ``est``: "rcca" | "mcca" | "gcca"."""
+    import numpy as np
+
+    from cca_zoo_amd import _backend
+    from cca_zoo_amd._moments import compute_moments
+    from oracle import certificates as ct
+
+    f32 = views[0].element_size() == 4
+    tol = 1e-3 if f32 else 1e-7
+    rep = {"tol": tol}
+    ok = True
+    if jd is not None:
+        spot = k1_spot_check(views, jd, seed, 0, 2048 if sum(int(v.shape[1]) for v in views) <= 8192 else 1024)
+        ok = spot.pop("ok")
+        rep.update(spot)
+    h = _backend.handle_for(views)
+    mom, keep, n, dims, _ = compute_moments(views, h)
+    D = int(sum(dims))
+    h.moments_symmetrize(mom, D)
+    flat = h.to_host(mom, (D * D + D,))
+    del keep
+    G, sm = flat[:D * D].reshape(D, D), flat[D * D:]
+    cs = [float(c)] * len(dims)
+    if est == "rcca":
+        A, B = ct.rcca_pencil(G, sm, n, dims, cs)
+        V, lam = np.vstack(model.weights_).astype(np.float64) / np.sqrt(2.0), np.asarray(model.singular_values_, dtype=np.float64)
+    elif est == "mcca":
+        A, B = ct.mcca_pencil(G, sm, n, dims, cs)
+        V, lam = np.vstack(model.weights_).astype(np.float64) / np.sqrt(len(dims)), np.asarray(model.eigenvalues_, dtype=np.float64)
+    else:
+        lam = np.asarray(model.eigenvalues_, dtype=np.float64)
+        A, B, V = ct.gcca_pencil(G, sm, n, dims, cs, model.weights_, lam)
+    del flat, G
+    r = ct.pencil_certificate(A, B, V, lam, delta=1e-4 if f32 else 1e-6, inertia=inertia)
+    rep.update({"pencil_residual": r["residual"], "pencil_orthonormality": r["orthonormality"], "k": r["k"],
+                "pencil_eigenvalues_above_lambda_k": r.get("n_above", "not counted")})
+    ok = ok and r["residual"] < tol and r["orthonormality"] < tol and (not inertia or r["n_above"] == r["k"])
+    ok = ok and bool(np.all(np.diff(lam) <= 1e-9 * max(1.0, abs(lam[0]))))
     rep["ok"] = bool(ok)
     return rep
 
@@ -148,27 +207,18 @@ def host_cores():
     return n, quota
 
 
-def cpu_baseline(n_full, d, k, sample_rows):
+def cpu_baseline(n_full, d, k, sample_rows=0, target_s=10.0):
     """``oracle.reference_form.rcca_weights`` -- the reference's structure (thin SVD of each centred n x d view,
-    cca_zoo/linear/_rcca.py:92-100) -- on ``sample_rows`` >= 4 d rows of the same kind of data (the tall regime the
-    full problem is in), median of up to three runs; ``value`` is the linear-in-n extrapolation of the measured time
-    (the thin SVD is O(n d^2)), reported next to the measurement itself."""
+    cca_zoo/linear/_rcca.py:92-100) -- on a bounded sample of the same kind of data, THREE runs, median reported.
+    The sample's row count is chosen from a short pilot run (n = d / 2 rows) so that one run takes about
+    ``target_s`` seconds (rows >= d: the tall side of the thin SVD, where its cost is O(n d^2) like the full
+    problem's); ``value`` is the linear-in-n extrapolation of the measured median, reported next to the measurement."""
     import numpy as np
 
     from oracle import reference_form as rf
 
     affinity, quota = host_cores()
-    threads = None
-    try:
-        from threadpoolctl import threadpool_info
-
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:
-        pass
     cores = int(min(affinity, quota)) if quota else affinity
-    views = rf.joint_data(2, sample_rows, k, [d, d], 1.0, 0)
-    views = [v.astype(np.float32) for v in views]
-    times = []
     # one BLAS thread per usable core: the default (one per LOGICAL cpu of the box, 256) oversubscribes a 16-cpu quota
     # so badly that the same SVD takes 5x longer
     try:
@@ -177,30 +227,40 @@ def cpu_baseline(n_full, d, k, sample_rows):
         limiter = threadpool_limits(limits=max(cores, 1))
     except Exception:
         limiter = None
+    pilot_s = None
     try:
+        if sample_rows <= 0:
+            rows_p = max(d // 2, 256)
+            vp = [v.astype(np.float32) for v in rf.joint_data(2, rows_p, k, [d, d], 1.0, 1)]
+            t0 = time.perf_counter()
+            rf.rcca_weights(vp, k, c=0.0)
+            pilot_s = time.perf_counter() - t0
+            del vp
+            # O(n d^2): rows for ~target_s, kept in [d, 4 d] and a multiple of 1024
+            sample_rows = int(min(4 * d, max(d, rows_p * target_s / max(pilot_s, 1e-3))) // 1024 * 1024) or d
+        views = [v.astype(np.float32) for v in rf.joint_data(2, sample_rows, k, [d, d], 1.0, 0)]
+        times = []
         for _ in range(3):
             t0 = time.perf_counter()
             rf.rcca_weights(views, k, c=0.0)
             times.append(time.perf_counter() - t0)
-            if times[0] > 12.0:        # bounded: a single run already took its share of the bench's wall-clock
-                break
     finally:
         if limiter is not None:
             limiter.restore_original_limits()
-    threads = max(cores, 1) if limiter is not None else threads
     med = float(np.median(times))
     full = med * (n_full / sample_rows)
     return {
         "value": 1.0 / full, "unit": "fit/s (extrapolated linearly in n from the measured sample)", "cores": max(cores, 1), "kind": "port",
         "sample": (f"oracle.reference_form.rcca_weights (thin SVD per view, as cca_zoo/linear/_rcca.py:92-100) on "
-                   f"{sample_rows} rows (>= 4 d) of 2x{d} fp32 JointData, k={k}"),
-        "measured_s": med, "runs_s": [round(t, 3) for t in times], "sample_rows": sample_rows,
+                   f"{sample_rows} rows (= {sample_rows / d:.2g} d) of 2x{d} fp32 JointData, k={k}; median of 3 runs"),
+        "measured_s": med, "runs_s": [round(t, 3) for t in times], "sample_rows": sample_rows, "pilot_run_s": pilot_s,
         "extrapolated_full_s": full, "extrapolation": f"measured_s * {n_full}/{sample_rows} (O(n d^2) thin SVD)",
-        "blas_threads": threads, "sched_affinity": affinity, "cgroup_cpu_quota": quota, "logical_cpus": os.cpu_count(),
+        "blas_threads": max(cores, 1) if limiter is not None else None, "sched_affinity": affinity, "cgroup_cpu_quota": quota,
+        "logical_cpus": os.cpu_count(),
     }
 
 
-def cpu_mcca_baseline(n_full=1_000_000, d=2048, m=4, k=64, sample_rows=8192):
+def cpu_mcca_baseline(n_full=1_000_000, d=2048, m=4, k=64, sample_rows=4096):
     """``oracle.reference_form.mcca_weights`` (PCA per view, np.cov of the projections, eps-floor, scipy eigh subset:
     cca_zoo/linear/_mcca.py:99-197) on ``sample_rows`` = 4 d rows of BASELINE configs[2]-shaped data.  The part that
     grows with n (the m thin SVDs and the covariance: O(n D^2)) is timed on its own so that the extrapolation to the
@@ -239,6 +299,38 @@ def cpu_mcca_baseline(n_full=1_000_000, d=2048, m=4, k=64, sample_rows=8192):
             "value": 1.0 / full, "unit": "fit/s (extrapolated)"}
 
 
+def cpu_gcca_baseline(n_rows=2048, dims=(2048, 2048, 4096), k=128, n_full=2_000_000, full_dims=(4096, 4096, 8192)):
+    """``oracle.reference_form.gcca_weights`` -- the reference's n x n formulation (cca_zoo/linear/_gcca.py:80-110:
+    Q = sum_i X_i R_i^-1 X_i', top-k eigenvectors, pinv) -- at the largest size a ~20 s CPU budget allows: BASELINE
+    configs[4]'s three views at HALF width and n = 2048 rows.  The formulation is O(n^2 d + n^3) in time and n^2 in
+    memory: at the config's n = 2e6 the n x n matrix alone would be 32 TB, so there is no extrapolation -- the
+    reference cannot run configs[4]; the measured sample is context only."""
+    import numpy as np
+
+    from oracle import reference_form as rf
+
+    affinity, quota = host_cores()
+    cores = int(min(affinity, quota)) if quota else affinity
+    views = rf.joint_data(len(dims), n_rows, k, list(dims), 1.0, 0)
+    try:
+        from threadpoolctl import threadpool_limits
+
+        limiter = threadpool_limits(limits=max(cores, 1))
+    except Exception:
+        limiter = None
+    try:
+        t0 = time.perf_counter()
+        rf.gcca_weights(views, k, c=0.1)
+        dt = time.perf_counter() - t0
+    finally:
+        if limiter is not None:
+            limiter.restore_original_limits()
+    return {"metric": f"CPU GCCA fit (reference n x n structure), n={n_rows}, d={list(dims)}, k={k}, float64", "cores": max(cores, 1),
+            "measured_s": dt, "extrapolated_full_s": None,
+            "note": (f"configs[4] itself (n={n_full}, d={list(full_dims)}) is out of reach of the n x n formulation "
+                     f"({8.0 * n_full * n_full / 1e12:.0f} TB for Q); no extrapolation is given")}
+
+
 def cpu_loss_baseline(batch=8192, d=512):
     """The reference's own CCALoss (oracle.losses.cca_loss_autograd: torch eigh + autograd, deep/objectives.py:61-102)
     forward + backward on the host, BASELINE configs[3] shape, median of three."""
@@ -265,12 +357,59 @@ def cpu_loss_baseline(batch=8192, d=512):
 # ---------------------------------------------------------------------------------------------------------------
 # extras (N = 1): the other BASELINE configurations and the second half of the metric
 # ---------------------------------------------------------------------------------------------------------------
-def dcca_extra(steps=20, warmup=3, batch=8192, d=512, label="BASELINE configs[3]"):
-    """CCALoss forward + backward (ccz_cca_loss through the autograd Function), fp32 embeddings resident in HBM."""
+def loss_parity_gate(z1, z2, eps, loss, tol=1e-3, n_rows_check=2048):
+    """Value and gradients of a timed CCALoss evaluation against the float64 closed form (oracle.losses).  Small batches:
+    the closed form on the whole batch on the host.  Large ones (the metric shape): float64 moments of the SAME batch
+    formed chunk by chunk on the device with torch (the comparator, not the product), the closed form evaluated on the
+    host from those moments, the gradient compared on ``n_rows_check`` rows spread over the batch."""
     import numpy as np
     import torch
 
-    from cca_zoo_amd.deep.objectives import CCALoss
+    from oracle import losses as ol
+
+    n, d1, d2 = int(z1.shape[0]), int(z1.shape[1]), int(z2.shape[1])
+    rep = {"tol": tol}
+    if n * (d1 + d2) <= 8192 * 2048:
+        l, g1, g2 = ol.cca_loss_closed_form(z1.detach().cpu().numpy(), z2.detach().cpu().numpy(), eps)
+        rep["comparator"] = "oracle.losses.cca_loss_closed_form on the whole batch (host, float64)"
+        e1 = float(np.linalg.norm(z1.grad.cpu().numpy() - g1) / np.linalg.norm(g1))
+        e2 = float(np.linalg.norm(z2.grad.cpu().numpy() - g2) / np.linalg.norm(g2))
+    else:
+        D = d1 + d2
+        G = torch.zeros(D, D, dtype=torch.float64, device=z1.device)
+        sm = torch.zeros(D, dtype=torch.float64, device=z1.device)
+        step = max(1, (1 << 28) // D)
+        with torch.no_grad():
+            for r0 in range(0, n, step):
+                blk = torch.cat([z1[r0:r0 + step], z2[r0:r0 + step]], dim=1).double()
+                G += blk.T @ blk
+                sm += blk.sum(0)
+                del blk
+        l, Gamma, mean = ol.cca_loss_from_moments(G.cpu().numpy(), sm.cpu().numpy(), n, d1, d2, eps)
+        del G
+        rows = torch.arange(0, n, max(1, n // n_rows_check), device=z1.device)[:n_rows_check]
+        with torch.no_grad():
+            Z = torch.cat([z1[rows], z2[rows]], dim=1).double().cpu().numpy()
+        gr = (Z - mean) @ Gamma
+        rep["comparator"] = (f"oracle.losses.cca_loss_from_moments on float64 moments of the same batch; gradient on {len(rows)} rows")
+        e1 = float(np.linalg.norm(z1.grad[rows].double().cpu().numpy() - gr[:, :d1]) / np.linalg.norm(gr[:, :d1]))
+        e2 = float(np.linalg.norm(z2.grad[rows].double().cpu().numpy() - gr[:, d1:]) / np.linalg.norm(gr[:, d1:]))
+    rep["loss"] = float(loss)
+    rep["loss_ref"] = float(l)
+    rep["loss_rel_err"] = abs(float(loss) - float(l)) / abs(float(l))
+    rep["grad_rel_err"] = [e1, e2]
+    rep["ok"] = bool(rep["loss_rel_err"] <= tol and e1 < tol and e2 < tol and np.isfinite(float(loss)))
+    return rep
+
+
+def dcca_extra(steps=20, warmup=3, batch=8192, d=512, label="BASELINE configs[3]", gate=True):
+    """CCALoss forward + backward (ccz_pair_loss through the autograd Function), fp32 embeddings resident in HBM.
+    Steps are enqueued back to back and the device is drained ONCE (the objective never synchronises the host): the
+    reported time is wall-clock per step of that queue; ``ms_sync_each`` is the same loop with a host wait per step."""
+    import numpy as np
+    import torch
+
+    from cca_zoo_amd.deep.objectives import CCALoss, check_async_errors
 
     torch.manual_seed(0)
     z1 = torch.randn(batch, d, device="cuda", requires_grad=True)
@@ -289,14 +428,84 @@ def dcca_extra(steps=20, warmup=3, batch=8192, d=512, label="BASELINE configs[3]
         obj([z1, z2]).backward()
         torch.cuda.synchronize()
         ts.append(time.perf_counter() - t0)
-    dt = float(np.median(ts))
+    dt_sync = float(np.median(ts))
+    # back-to-back: the way a training loop issues it
+    reps = max(3, steps)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        z1.grad = None
+        z2.grad = None
+        loss = obj([z1, z2])
+        loss.backward()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    check_async_errors()
     # forward Gram n D (D + 1) with D = 2 d, backward (n x 2d) @ (2d x 2d)
     flops = float(batch) * (2 * d) * (2 * d + 1) + 2.0 * batch * (2 * d) * (2 * d)
-    return {"metric": f"DCCA CCALoss fwd+bwd/sec (batch {batch}, 2x{d}, fp32; {label})", "value": 1.0 / dt, "ms": dt * 1e3,
-            "ms_min": float(min(ts)) * 1e3, "tflops": flops / dt / 1e12, "flop": flops,
-            "roofline": {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": PEAK_TFLOPS["f32"], "unit": "TFLOP/s",
-                         "frac": flops / dt / 1e12 / PEAK_TFLOPS["f32"],
-                         "note": "algorithmic flops of the whole fwd+bwd (K1 + gradient GEMM) over its wall time"}}
+    out = {"metric": f"DCCA CCALoss fwd+bwd/sec (batch {batch}, 2x{d}, fp32; {label})", "value": 1.0 / dt, "ms": dt * 1e3,
+           "ms_sync_each": dt_sync * 1e3, "ms_min_sync_each": float(min(ts)) * 1e3, "tflops": flops / dt / 1e12, "flop": flops,
+           "roofline": {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": PEAK_TFLOPS["f32"], "unit": "TFLOP/s",
+                        "frac": flops / dt / 1e12 / PEAK_TFLOPS["f32"],
+                        "note": "algorithmic flops of the whole fwd+bwd (K1 + gradient GEMM) over its wall time"}}
+    if gate:
+        out["parity_gate"] = loss_parity_gate(z1, z2, 1e-6, loss.item())
+    return out
+
+
+def training_step_extra(batch=8192, d_in=784, hidden=1024, d_out=512, steps=30, warmup=5):
+    """One DCCA ``training_step`` (the reference: cca_zoo/deep/_base.py:78-104 -- encoders forward, the objective,
+    backward) with MLP encoders as in the reference's user guide (docs/user-guide/deep.md:225-232), timed (a) with
+    CCALoss, (b) with a trivial stand-in objective (the encoders alone), and (c) the objective alone on the same
+    embeddings.  If the objective drained the queue, (a) would exceed (b) + (c); with device-side stream hand-over it
+    does not."""
+    import torch
+    import torch.nn as nn
+
+    from cca_zoo_amd.deep.objectives import CCALoss
+
+    torch.manual_seed(0)
+
+    def mlp():
+        return nn.Sequential(nn.Linear(d_in, hidden), nn.ReLU(), nn.Linear(hidden, hidden), nn.ReLU(), nn.Linear(hidden, d_out)).cuda()
+
+    e1, e2 = mlp(), mlp()
+    x1 = torch.randn(batch, d_in, device="cuda")
+    x2 = torch.randn(batch, d_in, device="cuda") + 0.5 * x1
+    obj = CCALoss(eps=1e-6)
+    params = list(e1.parameters()) + list(e2.parameters())
+
+    def step(with_loss):
+        for p in params:
+            p.grad = None
+        z1, z2 = e1(x1), e2(x2)
+        loss = obj([z1, z2]) if with_loss else (z1.square().mean() - (z1[:, :d_out] * z2).mean())
+        loss.backward()
+
+    def timed(fn):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3
+
+    with_ms = timed(lambda: step(True))
+    without_ms = timed(lambda: step(False))
+    z1 = e1(x1).detach().requires_grad_(True)
+    z2 = e2(x2).detach().requires_grad_(True)
+
+    def loss_only():
+        z1.grad = None
+        z2.grad = None
+        obj([z1, z2]).backward()
+
+    alone_ms = timed(loss_only)
+    return {"metric": f"DCCA training_step (two MLP encoders {d_in}-{hidden}-{hidden}-{d_out}, batch {batch}, fp32): fwd + CCALoss + bwd",
+            "step_ms_with_loss": with_ms, "step_ms_encoders_only": without_ms, "loss_alone_ms": alone_ms,
+            "loss_increment_ms": with_ms - without_ms,
+            "note": "loss_increment ~ loss_alone means the objective adds its own kernel time and no queue drain"}
 
 
 def timed_fit(make_model, views, runs):
@@ -312,9 +521,11 @@ def timed_fit(make_model, views, runs):
     return float(np.median(ts[1:])), last
 
 
-def config_extras(info):
-    """BASELINE configs[1], [2] and [4] (the last at the largest n one GPU holds) and the metric shape in float64:
-    fit time, K1 rate, solve time.  Each configuration draws its own views and frees them."""
+def config_extras(info, gates=True):
+    """BASELINE configs[1], [2] and [4] (the last at the largest n one GPU holds), the metric shape in float64 and the
+    metric shape on data far from zero (mean = 10 sigma: the pilot-shifted K1): fit time, K1 rate, solve time -- each
+    behind its own parity gate (``solution_gate``); a configuration whose gate fails is reported as failed, without
+    numbers.  Each configuration draws its own views and frees them."""
     import numpy as np
     import torch
 
@@ -325,7 +536,7 @@ def config_extras(info):
     h = _backend.default_handle()
     out = {}
 
-    def run(tag, label, dims, n, k, tdt, make_model, runs=2):
+    def run(tag, label, dims, n, k, tdt, make_model, est, c, runs=2, offset=0.0):
         free, _ = torch.cuda.mem_get_info()
         need = n * sum(dims) * (4 if tdt == torch.float32 else 8)
         if need * 1.15 > free:
@@ -334,25 +545,41 @@ def config_extras(info):
         jd = JointData(n_views=len(dims), n_samples=1, latent_dimensions=k, n_features=list(dims), random_state=1,
                        latent_scales=list(np.linspace(2.0, 0.5, k)))
         views = jd.sample_device(device="cuda", dtype=tdt, n_samples=n, seed=DATA_SEED + 1)
+        if offset:
+            for v in views:                       # every feature sits `offset` standard deviations away from zero
+                v.add_(offset * float(v[:4096].std()))
         ms, model = timed_fit(make_model, views, runs)
         g_ms = h.moments_last_ms()[0]
         D = sum(dims)
         flop = float(n) * D * (D + 1)
         kind = "f32" if tdt == torch.float32 else "f64"
-        out[tag] = {"config": label, "fit_ms": ms, "fits_per_s": 1e3 / ms, "gram_ms": g_ms, "solve_ms": model.timings_["solve_ms"],
-                    "gram_tflops": flop / (g_ms * 1e-3) / 1e12, "gram_frac_of_peak": flop / (g_ms * 1e-3) / 1e12 / PEAK_TFLOPS[kind],
-                    "dtype": kind, "n": n, "score_top": float(np.asarray(model.score(views))[0])}
+        res = {"config": label, "fit_ms": ms, "fits_per_s": 1e3 / ms, "gram_ms": g_ms, "solve_ms": model.timings_["solve_ms"],
+               "gram_tflops": flop / (g_ms * 1e-3) / 1e12, "gram_frac_of_peak": flop / (g_ms * 1e-3) / 1e12 / PEAK_TFLOPS[kind],
+               "dtype": kind, "n": n, "pilot_shifted_k1": bool(h.moments_last_pilot()),
+               "score_top": float(np.asarray(model.score(views))[0])}
+        if gates:
+            try:
+                gate = solution_gate(model, views, est, c, jd=None if offset else jd, seed=DATA_SEED + 1, inertia=D <= 8192)
+            except Exception as e:                                            # a gate that cannot run does not pass
+                gate = {"ok": False, "error": f"{type(e).__name__}: {e}"}
+            if gate["ok"]:
+                res["parity_gate"] = gate
+            else:
+                res = {"config": label, "failed_parity_gate": gate}
+        out[tag] = res
         del views, model
         torch.cuda.empty_cache()
 
     run("c2_rcca", "configs[1]: rCCA n=100k, 2x1024, k=32, float32", (1024, 1024), 100_000, 32, torch.float32,
-        lambda: rCCA(latent_dimensions=32, c=0.1), runs=5)
+        lambda: rCCA(latent_dimensions=32, c=0.1), "rcca", 0.1, runs=5)
     run("c3_mcca", "configs[2]: MCCA 4x2048, n=1e6, k=64, float32 (one GPU holds all rows)", (2048,) * 4, 1_000_000, 64,
-        torch.float32, lambda: MCCA(latent_dimensions=64))
+        torch.float32, lambda: MCCA(latent_dimensions=64), "mcca", 0.0)
+    run("ns_offset", "metric shape on off-centre data (every column mean = 10 sigma): CCA n=1e6, 2x4096, k=64, float32",
+        (4096, 4096), 1_000_000, 64, torch.float32, lambda: CCA(latent_dimensions=64), "rcca", 0.0, offset=10.0)
     run("ns_f64", "metric shape in float64: CCA n=1e6, 2x4096, k=64", (4096, 4096), 1_000_000, 64, torch.float64,
-        lambda: CCA(latent_dimensions=64))
+        lambda: CCA(latent_dimensions=64), "rcca", 0.0)
     run("c5_gcca", "configs[4] at the largest n one GPU holds: GCCA d=[4096,4096,8192], n=1e6 (of 2e6), k=128, float64",
-        (4096, 4096, 8192), 1_000_000, 128, torch.float64, lambda: GCCA(latent_dimensions=128))
+        (4096, 4096, 8192), 1_000_000, 128, torch.float64, lambda: GCCA(latent_dimensions=128), "gcca", 0.0)
     return out
 
 
@@ -564,19 +791,31 @@ def main():
                 "metric": f"DCCA CCALoss fwd+bwd/sec (batch {a.n} sharded over {world} GPUs, 2x{a.d}, fp32)",
                 "value": 1.0 / sharded_loss_s, "ms": sharded_loss_s * 1e3}
         if world == 1 and not a.no_extras and views is not None:
+            gates = not a.no_gates
+
+            def gated(name, res):
+                """An extra whose parity gate failed is dropped (reported as failed, without numbers)."""
+                g = res.get("parity_gate")
+                if gates and g is not None and not g["ok"]:
+                    extra[name] = {"metric": res.get("metric"), "failed_parity_gate": g}
+                    return False
+                extra[name] = res
+                return True
+
             if not a.no_dcca:
-                extra["dcca_loss"] = dcca_extra()
+                gated("dcca_loss", dcca_extra(gate=gates))
+                extra["dcca_training_step"] = training_step_extra()
             extra["grid_search"] = grid_extra(views, a.k, ms_per_step)
             del views
             views = None
             torch.cuda.empty_cache()
             if not a.no_dcca and a.n * a.d * 4 * 4 < 200e9:   # z1, z2 and their gradients must fit in HBM
-                extra["dcca_loss_metric_shape"] = dcca_extra(steps=3, warmup=1, batch=a.n, d=a.d, label="metric shape")
+                gated("dcca_loss_metric_shape", dcca_extra(steps=3, warmup=1, batch=a.n, d=a.d, label="metric shape", gate=gates))
                 torch.cuda.empty_cache()
-            extra["configs"] = config_extras(info)
+            extra["configs"] = config_extras(info, gates=gates)
         if extra:
             out["extra"] = extra
-        if "dcca_loss_metric_shape" in extra:
+        if "value" in extra.get("dcca_loss_metric_shape", {}):
             # the second half of BASELINE's metric, first-class next to the fit rate
             out["dcca_loss_fwd_bwd_per_s"] = extra["dcca_loss_metric_shape"]["value"]
             out["dcca_loss_roofline"] = extra["dcca_loss_metric_shape"]["roofline"]
@@ -585,8 +824,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(a.n, a.d, a.k, a.cpu_sample_rows)
             if not a.no_extras:
                 out["cpu_baseline"]["dcca_loss_configs3"] = cpu_loss_baseline()
-            if a.cpu_mcca:
+            if not a.no_cpu_mcca and not a.no_extras:
                 out["cpu_baseline"]["mcca_configs2"] = cpu_mcca_baseline()
+                out["cpu_baseline"]["gcca_configs4"] = cpu_gcca_baseline()
         line = json.dumps(out)
     else:
         line = None

@@ -58,6 +58,9 @@ SIGNATURES = {
     "ccz_last_error": (C.c_char_p, [_vp]),
     "ccz_set_stream": (_int, [_vp, _vp]),
     "ccz_sync": (_int, [_vp]),
+    "ccz_stream_acquire": (_int, [_vp, _vp]),
+    "ccz_stream_release": (_int, [_vp, _vp]),
+    "ccz_loss_status": (_int, [_vp, _int, _pint, _pint]),
     "ccz_device_info": (_int, [_vp, C.POINTER(DevInfo)]),
     "ccz_dev_alloc": (_int, [_vp, C.POINTER(_vp), C.c_size_t]),
     "ccz_dev_free": (_int, [_vp, _vp]),
@@ -65,6 +68,7 @@ SIGNATURES = {
     "ccz_memcpy_d2h": (_int, [_vp, _vp, _vp, C.c_size_t]),
     "ccz_memset0": (_int, [_vp, _vp, C.c_size_t]),
     "ccz_moments": (_int, [_vp, _int, C.POINTER(View), _int, _i64, _int, _vp, _int]),
+    "ccz_moments_opts": (_int, [_vp, _int, C.POINTER(View), _int, _i64, _int, _vp, _int, _int, _int]),
     "ccz_moments_symmetrize": (_int, [_vp, _vp, _i64]),
     "ccz_moments_pack": (_int, [_vp, _vp, _i64, _vp]),
     "ccz_moments_unpack": (_int, [_vp, _vp, _i64, _vp]),
@@ -85,6 +89,7 @@ SIGNATURES = {
     "ccz_moments_subset": (_int, [_vp, _vp, _i64, _i64, _i64, _vp]),
     "ccz_gemm_f64": (_int, [_vp, _int, _int, _i64, _i64, _i64, _dbl, _vp, _i64, _vp, _i64, _dbl, _vp, _i64]),
     "ccz_cca_loss": (_int, [_vp, _int, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _dbl, _vp, _vp, _vp, _i64, _i64]),
+    "ccz_pair_loss": (_int, [_vp, _int, C.POINTER(View), _int, _i64, _dbl, _vp, C.POINTER(_vp), _pi64]),
     "ccz_cca_loss_moments": (_int, [_vp, _vp, _i64, _i64, _i64, _dbl, C.POINTER(_dbl), _vp, _vp]),
     "ccz_pair_loss_moments": (_int, [_vp, _vp, _i64, _pi64, _int, _dbl, C.POINTER(_dbl), _vp, _vp]),
     "ccz_cholinv": (_int, [_vp, _int, C.POINTER(_vp), _pi64, C.POINTER(_vp), C.POINTER(_vp)]),
@@ -197,6 +202,21 @@ class Handle:
     def sync(self):
         self.check(self.lib.ccz_sync(self._h))
 
+    def acquire(self, stream_ptr):
+        """The handle's stream waits (on the device) for ``stream_ptr``'s work so far; the host does not block."""
+        self.check(self.lib.ccz_stream_acquire(self._h, C.c_void_p(int(stream_ptr) or None)))
+
+    def release(self, stream_ptr):
+        """``stream_ptr`` waits (on the device) for the handle's work so far; the host does not block."""
+        self.check(self.lib.ccz_stream_release(self._h, C.c_void_p(int(stream_ptr) or None)))
+
+    def loss_status(self, synchronise=False):
+        """(view, pivot) of a factorization failure recorded by an earlier ``ccz_cca_loss`` call, or ``None``;
+        clears the record."""
+        v, p = C.c_int(0), C.c_int(0)
+        self.check(self.lib.ccz_loss_status(self._h, 1 if synchronise else 0, C.byref(v), C.byref(p)))
+        return (v.value - 1, p.value) if v.value else None
+
     def device_info(self):
         info = DevInfo()
         self.check(self.lib.ccz_device_info(self._h, C.byref(info)))
@@ -233,8 +253,10 @@ class Handle:
         return out
 
     # -- K1 ---------------------------------------------------------------------------
-    def moments(self, views, n_rows, dtype, on_device, moments_ptr, accumulate=False):
-        """views: list of (ptr_or_ndarray, cols, ld)."""
+    def moments(self, views, n_rows, dtype, on_device, moments_ptr, accumulate=False, pilot=None, timed=True):
+        """views: list of (ptr_or_ndarray, cols, ld).  ``pilot`` (None: automatic, False: never, True: always shift
+        fp32 views) and ``timed=False`` select ``ccz_moments_opts`` -- with ``pilot=True, timed=False`` the call only
+        enqueues work."""
         arr = (View * len(views))()
         keep = []
         for i, (data, cols, ld) in enumerate(views):
@@ -244,8 +266,13 @@ class Handle:
             else:
                 arr[i].data = int(data)
             arr[i].cols, arr[i].ld = int(cols), int(ld)
-        self.check(self.lib.ccz_moments(self._h, int(dtype), arr, len(views), int(n_rows),
-                                        1 if on_device else 0, _ptr(moments_ptr), 1 if accumulate else 0))
+        if pilot is None and timed:
+            self.check(self.lib.ccz_moments(self._h, int(dtype), arr, len(views), int(n_rows),
+                                            1 if on_device else 0, _ptr(moments_ptr), 1 if accumulate else 0))
+        else:
+            mode = 1 if pilot is None else (2 if pilot else 0)
+            self.check(self.lib.ccz_moments_opts(self._h, int(dtype), arr, len(views), int(n_rows), 1 if on_device else 0,
+                                                 _ptr(moments_ptr), 1 if accumulate else 0, mode, 1 if timed else 0))
 
     def moments_symmetrize(self, moments_ptr, D):
         self.check(self.lib.ccz_moments_symmetrize(self._h, _ptr(moments_ptr), int(D)))

@@ -224,9 +224,11 @@ def _device_project(v, mean, w):
     out = torch.empty((v.shape[0], k), dtype=v.dtype, device=v.device)
     md = torch.as_tensor(np.asarray(mean, dtype=np.float64), device=v.device)
     wd = torch.as_tensor(np.ascontiguousarray(w, dtype=np.float64), device=v.device)
-    torch.cuda.current_stream(v.device).synchronize()
+    sp = int(torch.cuda.current_stream(v.device).cuda_stream)
+    h.acquire(sp)                                          # device-side hand-over: the host never waits here
     h.check(h.lib.ccz_transform(h.raw, _backend.F32 if v.element_size() == 4 else _backend.F64,
                                 C.c_void_p(v.data_ptr()), v.shape[0], v.shape[1], v.stride(0),
                                 C.c_void_p(md.data_ptr()), C.c_void_p(wd.data_ptr()), k,
                                 C.c_void_p(out.data_ptr()), out.stride(0)))
+    h.release(sp)
     return out

@@ -8,6 +8,7 @@ moments (upper-triangular tiles of G, column sums) and -- inside ``row_sharded()
 
 from __future__ import annotations
 
+import threading
 import time
 
 import numpy as np
@@ -16,8 +17,21 @@ from cca_zoo_amd import _backend, _dist
 from cca_zoo_amd._utils._validation import is_device_tensor
 
 
-#: wall-clock of the pieces of the last ``compute_moments`` call on this process (bench.py reports them)
-LAST = {"moments_ms": 0.0, "allreduce_ms": 0.0}
+class _Last(threading.local):
+    """Per-THREAD record (a handle is single-threaded; concurrent fits on different handles keep their own numbers)."""
+
+    def __init__(self):
+        self.values = {"moments_ms": 0.0, "allreduce_ms": 0.0}
+
+    def __getitem__(self, key):
+        return self.values[key]
+
+    def __setitem__(self, key, value):
+        self.values[key] = value
+
+
+#: wall-clock of the pieces of the last ``compute_moments`` call on this thread (bench.py reports them)
+LAST = _Last()
 
 
 def _common_float(views):
@@ -62,11 +76,12 @@ def compute_moments(views, handle=None):
 
         tdt = torch.float32 if kind == "f32" else torch.float64
         for v in views:
-            if v.dtype != tdt or v.stride(1) != 1:
+            if v.dtype != tdt or v.stride(1) != 1 or v.stride(0) < v.shape[1]:     # (expanded / overlapping rows: ld >= d)
                 v = v.to(tdt).contiguous()
             keep.append(v)
             descr.append((v.data_ptr(), v.shape[1], v.stride(0)))
-        torch.cuda.current_stream(views[0].device).synchronize()
+        stream_ptr = int(torch.cuda.current_stream(views[0].device).cuda_stream)
+        h.acquire(stream_ptr)                              # libccz's stream follows torch's on the device; no host wait
     else:
         ndt = np.float32 if kind == "f32" else np.float64
         for v in views:
@@ -85,7 +100,10 @@ def compute_moments(views, handle=None):
         npk = D * (D + 1) // 2 + D
         packed = torch.empty(npk + 1, dtype=torch.float64, device=mom_t.device)
         h.moments_pack(mom_ptr, D, packed.data_ptr())
-        h.sync()
+        if on_device:
+            h.release(stream_ptr)                        # the collective's stream follows libccz's on the device
+        else:
+            h.sync()
         packed[npk:].fill_(float(n))                     # the row count rides in the tail slot of the same buffer
         t_ar = time.perf_counter()
         n_total = _dist.allreduce_moments(packed, _dist.active_group())     # in place; its .item() is the sync

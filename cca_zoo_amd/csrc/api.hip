@@ -14,10 +14,13 @@ namespace ccz {
 // loss.hip
 void cca_loss_impl(ccz_ctx* c, int dtype, const void* z1, const void* z2, int64_t n, int64_t d1, int64_t d2, int64_t ld1,
                    int64_t ld2, double eps, void* loss_dev, void* g1, void* g2, int64_t ldg1, int64_t ldg2);
+void pair_loss_impl(ccz_ctx* c, int dtype, const ccz_view* z, int m, int64_t n, double eps, void* loss_dev, void* const* g,
+                    const int64_t* ldg);
 void cca_loss_moments_impl(ccz_ctx* c, const double* mom, int64_t n, int64_t d1, int64_t d2, double eps, double* loss_host,
                            double* gamma_dev, double* mean_dev);
 void pair_loss_moments_impl(ccz_ctx* c, const double* mom, int64_t n, const int64_t* dims, int m, double eps,
                             double* loss_host, double* gamma_dev, double* mean_dev);
+void loss_status_take(ccz_ctx* c, bool synchronise, int* view, int* pivot);
 void randn_fill_impl(ccz_ctx* c, int dtype, void* out, int64_t rows, int64_t cols, int64_t ld, uint64_t seed,
                      int64_t row0, int64_t row_stride, double scale, bool accumulate);
 }  // namespace ccz
@@ -49,7 +52,7 @@ static void transform_impl(ccz_ctx* c, int dtype, const void* X, int64_t n, int6
   DBuf bias(c, k);
   if (mean) gemm(c, false, false, 1, k, d, 1.0, mean, d, W, k, 0.0, bias, k);
   gemm_mixed(c, dtype, n, k, d, 1.0, X, ld, W, k, 0.0, out, ldo, mean ? bias.get() : nullptr);
-  sync(c);
+  // enqueue-only: `out` is ready in stream order (ccz_sync / ccz_stream_release / ccz_memcpy_d2h for a host consumer)
 }
 
 }  // namespace ccz
@@ -93,6 +96,7 @@ int ccz_destroy(ccz_handle h) {
     for (auto& g : im->graphs) (void)hipGraphExecDestroy(g.exec);
     if (im->own_stream) (void)hipStreamDestroy(im->own_stream);
     for (auto& b : im->pool) (void)hipFree(b.p);
+    for (auto& t : im->tile_tabs) if (t.dev) (void)hipFree(t.dev);
     for (int i = 0; i < 4; ++i) (void)hipEventDestroy(im->ev[i]);
     for (int i = 0; i < 4; ++i) if (im->pipe_ev[i]) (void)hipEventDestroy(im->pipe_ev[i]);
     for (int i = 0; i < 2; ++i) if (im->pin_buf[i]) (void)hipHostFree(im->pin_buf[i]);
@@ -103,6 +107,8 @@ int ccz_destroy(ccz_handle h) {
     if (im->copy_stream) (void)hipStreamDestroy(im->copy_stream);
     for (int i = 0; i < 2; ++i) if (im->aux_ev[i]) (void)hipEventDestroy(im->aux_ev[i]);
     if (im->aux_stream) (void)hipStreamDestroy(im->aux_stream);
+    for (int i = 0; i < 2; ++i) if (im->xs_ev[i]) (void)hipEventDestroy(im->xs_ev[i]);
+    if (im->loss_status) (void)hipHostFree(im->loss_status);
     (void)hipFree(im->d_flag);
     (void)hipFree(im->d_small);
     delete im;
@@ -121,6 +127,31 @@ int ccz_set_stream(ccz_handle h, void* s) {
 }
 
 int ccz_sync(ccz_handle h) { CCZ_GUARD(h, sync(h)) }
+
+// Hand-over between a caller's stream and the handle's stream WITHOUT blocking the host.  The handle's own stream is
+// a blocking stream: it is already ordered with the legacy null stream (PyTorch's default stream) in both directions,
+// so nothing is enqueued for ext == NULL; any other stream is joined through an event.
+static void stream_join(ccz_ctx* c, hipStream_t from, hipStream_t to, int slot) {
+  if (from == to) return;
+  Impl* im = impl(c);
+  const bool own_blocking = stream(c) == im->own_stream;
+  if (own_blocking && (from == nullptr || to == nullptr)) return;       // legacy null-stream ordering
+  if (!im->xs_ev[slot]) CCZ_HIP(hipEventCreateWithFlags(&im->xs_ev[slot], hipEventDisableTiming));
+  CCZ_HIP(hipEventRecord(im->xs_ev[slot], from));
+  CCZ_HIP(hipStreamWaitEvent(to, im->xs_ev[slot], 0));
+}
+
+int ccz_stream_acquire(ccz_handle h, void* ext) {
+  CCZ_GUARD(h, stream_join(h, static_cast<hipStream_t>(ext), stream(h), 0))
+}
+
+int ccz_stream_release(ccz_handle h, void* ext) {
+  CCZ_GUARD(h, stream_join(h, stream(h), static_cast<hipStream_t>(ext), 1))
+}
+
+int ccz_loss_status(ccz_handle h, int synchronise, int* view, int* pivot) {
+  CCZ_GUARD(h, ccz::loss_status_take(h, synchronise != 0, view, pivot))
+}
 
 int ccz_device_info(ccz_handle h, ccz_devinfo* out) {
   CCZ_GUARD(h, {
@@ -166,6 +197,14 @@ int ccz_moments(ccz_handle h, int dtype, const ccz_view* views, int n_views, int
   })
 }
 
+int ccz_moments_opts(ccz_handle h, int dtype, const ccz_view* views, int n_views, int64_t n_rows, int views_on_device,
+                     double* moments_dev, int accumulate, int pilot_mode, int timed) {
+  CCZ_GUARD(h, {
+    if (pilot_mode < 0 || pilot_mode > 2) fail(CCZ_EINVAL, "moments: pilot_mode must be 0 (never), 1 (automatic) or 2 (always)");
+    moments_impl(h, dtype, views, n_views, n_rows, views_on_device != 0, moments_dev, accumulate != 0, pilot_mode, timed != 0);
+  })
+}
+
 int ccz_moments_symmetrize(ccz_handle h, double* moments_dev, int64_t D) {
   CCZ_GUARD(h, {
     if (!moments_dev || D < 1) fail(CCZ_EINVAL, "bad argument");
@@ -208,6 +247,11 @@ int ccz_cca_loss(ccz_handle h, int dtype, const void* z1_dev, const void* z2_dev
   CCZ_GUARD(h, {
     cca_loss_impl(h, dtype, z1_dev, z2_dev, n, d1, d2, ld1, ld2, eps, loss_dev, g1_dev, g2_dev, ldg1, ldg2);
   })
+}
+
+int ccz_pair_loss(ccz_handle h, int dtype, const ccz_view* z_dev, int n_views, int64_t n, double eps, void* loss_dev,
+                  void* const* g_dev, const int64_t* ldg) {
+  CCZ_GUARD(h, ccz::pair_loss_impl(h, dtype, z_dev, n_views, n, eps, loss_dev, g_dev, ldg));
 }
 
 int ccz_cca_loss_moments(ccz_handle h, const double* moments_dev, int64_t n_rows, int64_t d1, int64_t d2, double eps,

@@ -473,8 +473,7 @@ void gemm_f32_big(ccz_ctx* c, int64_t M, int64_t N, int64_t K, double alpha, con
     hipLaunchKernelGGL(k_gemm_f32_nn_tall, dim3((unsigned)((M + BT - 1) / BT)), dim3(256), lds_bytes, st, M, N, K, float(alpha),
                        A, lda, B32, float(beta), C, ldc, bias32);
     CCZ_LAUNCH_CHECK();
-    CCZ_HIP(hipStreamSynchronize(st));   // B32 is pooled scratch
-    dev_free(c, B32);
+    dev_free(c, B32);                    // pooled scratch is recycled in stream order: no host wait
     return;
   }
   float* B32 = static_cast<float*>(dev_alloc(c, size_t(K) * N * 4 + (bias_row ? size_t(N) * 4 : 0)));
@@ -503,8 +502,7 @@ void gemm_f32_big(ccz_ctx* c, int64_t M, int64_t N, int64_t K, double alpha, con
                        N, float(beta), C, ldc, bias32);
   }
   CCZ_LAUNCH_CHECK();
-  CCZ_HIP(hipStreamSynchronize(st));   // B32 is pooled scratch
-  dev_free(c, B32);
+  dev_free(c, B32);                      // pooled scratch is recycled in stream order: no host wait
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -41,7 +41,7 @@ struct Impl {
   hipStream_t copy_stream = nullptr;
   hipEvent_t pipe_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // h2d done [2], compute done [2]
   // ring of pinned slots for small asynchronous host -> device copies (tile tables, descriptors)
-  static constexpr int kSmallSlots = 8;
+  static constexpr int kSmallSlots = 32;
   static constexpr size_t kSmallBytes = size_t(64) << 10;
   void* small_pin[kSmallSlots] = {};
   hipEvent_t small_ev[kSmallSlots] = {};
@@ -49,6 +49,15 @@ struct Impl {
   // second stream + events for the look-ahead of the super-blocked Cholesky (ops_hip.hip), created on first use
   hipStream_t aux_stream = nullptr;
   hipEvent_t aux_ev[2] = {nullptr, nullptr};
+  // device copies of recently used K1 tile tables (gram.hip): the table is a pure function of the views' pointers,
+  // widths and strides, so a training loop (same pooled staging buffer every step) never copies one again
+  struct TileTab { uint64_t hash; size_t bytes; void* dev; uint64_t tick; };
+  std::vector<TileTab> tile_tabs;
+  // sticky failure record of the stream-native loss (loss.hip): pinned + mapped host words written by the device
+  int* loss_status = nullptr;       // host view
+  int* loss_status_dev = nullptr;   // device view of the same words
+  // hand-over events between a caller's stream and the handle's stream (ccz_stream_acquire / ccz_stream_release)
+  hipEvent_t xs_ev[2] = {nullptr, nullptr};
 };
 
 inline Impl* impl(ccz_ctx* c) { return static_cast<Impl*>(c->impl); }

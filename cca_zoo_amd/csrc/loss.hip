@@ -17,8 +17,10 @@
 //   K1 (pilot-shifted for fp32) -> prep (Ce, mean, per-view copies) -> batched Cholesky + inverse (cholinv.hip,
 //   d/64 + 1 launches for all views together) -> 4 batched 64-tile GEMM launches (Sinv_a; A_ab; Gamma_ab;
 //   Gamma_aa = -sum_b A_ab Gamma_ba) -> loss reduction -> ONE sample-side GEMM (Z - mean) Gamma on the fp32 MFMA pipe.
-// The previous formulation (blocked potrf + two triangular solves against the identity + 14 GEMMs + a host round
-// trip for the loss value) was ~70 dependent launches and 3.1 ms at batch 8192, 2 x 512.
+// Views wider than 2048 columns (the metric shape, d = 4096) run the SAME formulas through the super-blocked
+// factorization, explicit triangular inverses and the 128-tile fp64 GEMM (pair_core, `narrow == false`); there the four
+// sample-side n x d x d products dominate.  Nothing on the narrow path is read back by the host: a non-positive pivot
+// makes the loss NaN and sets the handle's sticky status (ccz_loss_status), checked by the NEXT call.
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -88,9 +90,18 @@ __global__ void k_trace_sq(const double* __restrict__ A, int64_t D, PrepArgs pa,
   if (threadIdx.x == 0) unsafeAtomicAdd(acc, red[0] + red[1] + red[2] + red[3]);
 }
 
-// loss = -1/2 acc -> one element of dtype (and/or a double)
-__global__ void k_loss_finish(const double* __restrict__ acc, int dtype, void* __restrict__ out, double* __restrict__ out64) {
-  const double l = -0.5 * acc[0];
+// loss = -1/2 acc -> one element of dtype (and/or a double).  info (optional, m ints from the factorization): a failed
+// pivot turns the loss into NaN and is recorded in the handle's sticky status words (pinned host memory) -- the
+// stream-native replacement of a blocking read-back of the pivot flags after every call.
+__global__ void k_loss_finish(const double* __restrict__ acc, int dtype, void* __restrict__ out, double* __restrict__ out64,
+                              const int* __restrict__ info, int m, int* __restrict__ status) {
+  double l = -0.5 * acc[0];
+  for (int a = 0; a < m; ++a)
+    if (info[a] != 0x7fffffff) {
+      l = __builtin_nan("");
+      if (status && status[0] == 0) { status[1] = info[a] - 1; __threadfence_system(); status[0] = a + 1; }
+      break;
+    }
   if (out) { if (dtype == CCZ_F32) *static_cast<float*>(out) = float(l); else *static_cast<double*>(out) = l; }
   if (out64) *out64 = l;
 }
@@ -128,25 +139,32 @@ __global__ void k_neg_sum(const double* __restrict__ v, int64_t n, int dtype, vo
   }
 }
 
-constexpr int64_t kFusedMaxD = 2048;     // per-view width served by the fused (cholinv) core
+constexpr int64_t kFusedMaxD = 2048;     // per-view width served by the batched step kernels (cholinv.hip)
 
-bool fused_ok(const int64_t* dims, int m) {
-  if (m < 2 || m > LMAXV) return false;
+// true: every view goes through the batched Cholesky + inverse step kernels and the 64-tile batched products;
+// false (a view wider than kFusedMaxD -- the metric shape d = 4096 -- or CCZ_LOSS_FUSED=0): the SAME formulas on the
+// super-blocked factorization, explicit triangular inverses and the 128-tile fp64 GEMM
+bool narrow_ok(const int64_t* dims, int m) {
   for (int a = 0; a < m; ++a)
     if (dims[a] > kFusedMaxD) return false;
   static const int on = [] { const char* e = getenv("CCZ_LOSS_FUSED"); return e ? atoi(e) : 1; }();
   return on != 0;
 }
 
-// Gamma (D x D), mean (D) and the loss accumulator tr(A A) (one double, zeroed here) from the moments; info_dev: m ints.
-// Everything is enqueued on the handle's stream; nothing is read back.
-void fused_core(ccz_ctx* c, const double* mom, int64_t n, const int64_t* dims, int m, double eps, bool want_grad,
-                double* acc_dev, double* gamma_dev, double* mean_dev, int* info_dev, double* bias_dev = nullptr) {
+// Gamma (D x D), mean (D) and the loss accumulator tr(A A) (one double, zeroed here) from the moments, for ANY number
+// of views (<= LMAXV) of ANY width; info_dev: LMAXV ints (0x7fffffff = factorization succeeded).
+// Narrow views: everything is enqueued on the handle's stream and nothing is read back (the pivot flags stay on the
+// device).  Wide views: the super-blocked factorization reads its pivot flags on the host and throws CCZ_ENOTSPD
+// itself; info_dev is then set to "succeeded" for the caller's device-side check.
+void pair_core(ccz_ctx* c, const double* mom, int64_t n, const int64_t* dims, int m, double eps, bool want_grad,
+               double* acc_dev, double* gamma_dev, double* mean_dev, int* info_dev, double* bias_dev = nullptr) {
+  if (m < 2 || m > LMAXV) fail(CCZ_EUNSUP, "pairwise CCA loss: 2 .. %d views are supported, got %d", LMAXV, m);
   hipStream_t st = stream(c);
   std::vector<int64_t> off(m + 1, 0);
   for (int a = 0; a < m; ++a) off[a + 1] = off[a] + dims[a];
   const int64_t D = off[m];
   const double inv = 1.0 / double(n - 1);
+  const bool narrow = narrow_ok(dims, m);
   DBuf Ce(c, D * D), Am(c, D * D);
   std::vector<DBuf> work(m), Lf(m), X(m), T(m), Sinv(m);
   PrepArgs pa{};
@@ -154,15 +172,15 @@ void fused_core(ccz_ctx* c, const double* mom, int64_t n, const int64_t* dims, i
   for (int a = 0; a <= m; ++a) pa.off[a] = off[a];
   for (int a = 0; a < m; ++a) {
     const int64_t d = dims[a], nblk = (d + 63) / 64;
-    work[a] = DBuf(c, d * d); Lf[a] = DBuf(c, d * d); X[a] = DBuf(c, d * d); Sinv[a] = DBuf(c, d * d);
-    T[a] = DBuf(c, nblk * 4096);
+    work[a] = DBuf(c, d * d); X[a] = DBuf(c, d * d); Sinv[a] = DBuf(c, d * d);
+    if (narrow) { Lf[a] = DBuf(c, d * d); T[a] = DBuf(c, nblk * 4096); }
     pa.work[a] = work[a].get();
   }
   // (split-K destinations of the product stages below are cleared by the same pass -- see there)
   int64_t dmin = dims[0];
   for (int a = 1; a < m; ++a) dmin = std::min(dmin, dims[a]);
   static const int split_env = [] { const char* e = getenv("CCZ_LOSS_SPLITK"); return e ? atoi(e) : 4; }();
-  const int ks = (dmin >= 256 && split_env > 1) ? split_env : 1;
+  const int ks = (narrow && dmin >= 256 && split_env > 1) ? split_env : 1;
   if (ks > 1) {
     for (int a = 0; a < m; ++a) pa.zero_v[a] = Sinv[a].get();
     pa.zero_a = Am.get();
@@ -171,28 +189,51 @@ void fused_core(ccz_ctx* c, const double* mom, int64_t n, const int64_t* dims, i
   hipLaunchKernelGGL(k_loss_prep, dim3((unsigned)std::min<int64_t>((D * D + 255) / 256, 4096)), dim3(256), 0, st, mom, mom + D * D, D,
                      1.0 / double(n), inv, eps, Ce.get(), mean_dev, pa, acc_dev, want_grad ? bias_dev : nullptr);
   CCZ_LAUNCH_CHECK();
-  {
+  if (narrow) {
     std::vector<double*> Ap(m), Lp(m), Xp(m), Tp(m);
     std::vector<int64_t> ld(dims, dims + m);
     for (int a = 0; a < m; ++a) { Ap[a] = work[a].get(); Lp[a] = Lf[a].get(); Xp[a] = X[a].get(); Tp[a] = T[a].get(); }
     cholinv_batched(c, m, Ap.data(), ld.data(), ld.data(), Lp.data(), ld.data(), Xp.data(), ld.data(), Tp.data(), info_dev);
+  } else {
+    // factor in place (work[a] <- L_a), then X_a = I L_a^-1 by the super-blocked triangular solve
+    std::vector<double*> Ap(m);
+    std::vector<int64_t> ld(dims, dims + m);
+    std::vector<int> info(m, 0);
+    for (int a = 0; a < m; ++a) Ap[a] = work[a].get();
+    potrf_lower_batched(c, m, Ap.data(), ld.data(), ld.data(), info.data());
+    for (int a = 0; a < m; ++a)
+      if (info[a] != 0) fail(CCZ_ENOTSPD, "pairwise CCA loss: S_%d%d + eps I is not positive definite (pivot %d)", a + 1, a + 1, info[a] - 1);
+    int ok[LMAXV];
+    for (int a = 0; a < LMAXV; ++a) ok[a] = 0x7fffffff;
+    h2d_small(c, info_dev, ok, sizeof(ok));
+    for (int a = 0; a < m; ++a) {
+      fill2d(c, dims[a], dims[a], X[a], dims[a], 0.0);
+      add_diag(c, dims[a], X[a], dims[a], 1.0);
+      trsm_right_lower(c, false, dims[a], dims[a], work[a], dims[a], X[a], dims[a]);
+    }
   }
   // Only the blocks that are not trivially known are formed: A_aa = I is never computed, Gamma's diagonal blocks come
   // straight from  Gamma_aa = -sum_{b != a} A_ab Gamma_ba  ( = 2/(n-1) ((A M)_aa - M_aa) ).
-  // The four product stages below are dependent launches of at most a few hundred 64 x 64 tiles with K = d: on
-  // their own they leave most of the chip idle for ~40 us each.  From d = 256 on the K range of every tile is cut
-  // into four slices on separate workgroups that accumulate atomically into zeroed destinations (split-K).
-  // (ks, and the clearing of Sinv / Am / Gamma: in k_loss_prep above -- three fills fewer per call)
+  // Narrow views: the four product stages below are dependent launches of at most a few hundred 64 x 64 tiles with
+  // K = d: on their own they leave most of the chip idle for ~40 us each.  From d = 256 on the K range of every tile
+  // is cut into four slices on separate workgroups that accumulate atomically into zeroed destinations (split-K).
+  // (ks, and the clearing of Sinv / Am / Gamma: in k_loss_prep above -- three fills fewer per call.)
+  // Wide views: every product is a 128-tile fp64 GEMM of its own (d^3 work fills the chip).
   auto launch = [&](std::vector<MultiGemmArgs>& v) {
+    if (!narrow) {
+      for (auto& g : v)
+        gemm(c, g.tA, g.tB, g.M, g.N, g.K, g.alpha, g.A, g.lda, g.B, g.ldb, g.beta, g.C, g.ldc);
+      return;
+    }
     if (ks > 1)
       for (auto& g : v) { g.ksplit = ks; g.beta = 1.0; }       // destinations are zero (or hold the earlier terms of a sum)
     for (size_t i0 = 0; i0 < v.size(); i0 += 8) gemm_f64_multi(c, int(std::min<size_t>(8, v.size() - i0)), v.data() + i0);
   };
   std::vector<MultiGemmArgs> pr;
   // Sinv_a = X_a' X_a   (X lower triangular: the K loop starts at the diagonal; the blocks of X above it -- never
-  // written by cholinv -- are never read)
+  // written by cholinv -- are never read.  Wide: X was built from the identity, its upper part is exact zeros)
   for (int a = 0; a < m; ++a)
-    pr.push_back(MultiGemmArgs{X[a], X[a], Sinv[a], nullptr, dims[a], dims[a], dims[a], 0, dims[a], dims[a], dims[a], true, false, false, 1.0, 0.0, true});
+    pr.push_back(MultiGemmArgs{X[a], X[a], Sinv[a], nullptr, dims[a], dims[a], dims[a], 0, dims[a], dims[a], dims[a], true, false, false, 1.0, 0.0, narrow});
   launch(pr);
   // A_ab = Sinv_a Ce_ab   (a != b)
   pr.clear();
@@ -231,177 +272,138 @@ void fused_core(ccz_ctx* c, const double* mom, int64_t n, const int64_t* dims, i
 
 void check_info(ccz_ctx* c, const int* info_dev, int m, const char* what) {
   int got[LMAXV];
-  d2h(c, got, info_dev, size_t(m) * sizeof(int));      // the one synchronisation of the fused path
+  d2h(c, got, info_dev, size_t(m) * sizeof(int));      // synchronises: only the entries that return HOST values use it
   for (int a = 0; a < m; ++a)
     if (got[a] != 0x7fffffff) fail(CCZ_ENOTSPD, "%s: S_%d%d + eps I is not positive definite (pivot %d)", what, a + 1, a + 1, got[a] - 1);
 }
 
-// ---------------------------------------------------------------------------
-// wide blocks (d > 2048; the metric shape d = 4096): blocked factorizations + explicit triangular inverses, the
-// sample-side GEMMs dominate there (4 x n d^2 flops at 95 % of the fp32 MFMA peak).  Two views only.
-// ---------------------------------------------------------------------------
-struct LossCore {
-  DBuf G11s, G22s, G12, G12t, mu, rd;
+// pooled allocation of raw bytes that goes back to the pool on every exit path
+struct PoolPtr {
+  ccz_ctx* c;
+  void* p;
+  PoolPtr(ccz_ctx* c_, size_t bytes) : c(c_), p(bytes ? dev_alloc(c_, bytes) : nullptr) {}
+  ~PoolPtr() { if (p) dev_free(c, p); }
+  PoolPtr(const PoolPtr&) = delete;
+  PoolPtr& operator=(const PoolPtr&) = delete;
+  template <typename T> T* as() const { return static_cast<T*>(p); }
 };
-
-LossCore wide_core(ccz_ctx* c, const double* G, const double* s, int64_t n, int64_t d1, int64_t d2, double eps, bool want1, bool want2) {
-  const int64_t D = d1 + d2;
-  const double inv = 1.0 / double(n - 1);
-  LossCore out;
-  DBuf L1(c, d1 * d1), L2(c, d2 * d2), S12(c, d1 * d2);
-  cov_block(c, G, D, s, n, true, inv, 0, d1, 0, d1, L1, d1);
-  add_diag(c, d1, L1, d1, eps);
-  cov_block(c, G, D, s, n, true, inv, d1, d2, d1, d2, L2, d2);
-  add_diag(c, d2, L2, d2, eps);
-  cov_block(c, G, D, s, n, true, inv, 0, d1, d1, d2, S12, d2);
-  {
-    double* Lp[2] = {L1.get(), L2.get()};
-    const int64_t dd[2] = {d1, d2};
-    int info[2] = {0, 0};
-    potrf_lower_batched(c, 2, Lp, dd, dd, info);
-    if (info[0] != 0) fail(CCZ_ENOTSPD, "cca_loss: S11 + eps I is not positive definite");
-    if (info[1] != 0) fail(CCZ_ENOTSPD, "cca_loss: S22 + eps I is not positive definite");
-  }
-  auto tri_inverse = [&](const double* L, int64_t d) {
-    DBuf Li(c, d * d);
-    fill2d(c, d, d, Li, d, 0.0);
-    add_diag(c, d, Li, d, 1.0);
-    trsm_right_lower(c, false, d, d, L, d, Li, d);            // I L^-1
-    return Li;
-  };
-  DBuf Li1 = tri_inverse(L1, d1), Li2 = tri_inverse(L2, d2);
-  auto solve_left = [&](const double* Li, int64_t d, bool transM, const double* M, int64_t ldm, int64_t r, double alpha, double* o) {
-    DBuf t(c, d * r);
-    gemm(c, false, transM, d, r, d, 1.0, Li, d, M, ldm, 0.0, t, r);
-    gemm(c, true, false, d, r, d, alpha, Li, d, t, r, 0.0, o, r);
-  };
-  auto solve_right = [&](const double* Li, int64_t d, const double* M, int64_t ldm, int64_t r, double alpha, double* o) {
-    DBuf t(c, r * d);
-    gemm(c, false, true, r, d, d, 1.0, M, ldm, Li, d, 0.0, t, d);
-    gemm(c, false, false, r, d, d, alpha, t, d, Li, d, 0.0, o, d);
-  };
-  DBuf A(c, d1 * d2), Bmt(c, d1 * d2);
-  solve_left(Li1, d1, false, S12, d2, d2, 1.0, A);            // A   = S11^-1 S12           (d1 x d2)
-  solve_right(Li2, d2, S12, d2, d1, 1.0, Bmt);                // Bm' = S12 S22^-1           (d1 x d2)
-  out.rd = DBuf(c, d1);
-  row_dots(c, d1, d2, A, d2, Bmt, d2, out.rd);                // tr(A Bm) = sum A o Bm'   (summed on the device)
-  if (!want1 && !want2) return out;
-  out.G12 = DBuf(c, d1 * d2);
-  out.G12t = DBuf(c, d2 * d1);
-  solve_right(Li2, d2, A, d2, d1, -2.0, out.G12);
-  transpose(c, d1, d2, out.G12, d2, out.G12t, d1);
-  out.mu = DBuf(c, D);
-  d2d(c, out.mu, s, size_t(D) * 8);
-  axpby2d(c, 1, D, 1.0 / double(n), out.mu, D, 0.0, nullptr, 0);
-  if (want1) {
-    DBuf P(c, d1 * d1);
-    out.G11s = DBuf(c, d1 * d1);
-    gemm(c, false, true, d1, d1, d2, 1.0, A, d2, Bmt, d2, 0.0, P, d1);          // A Bm
-    solve_right(Li1, d1, P, d1, d1, 2.0, out.G11s);
-  }
-  if (want2) {
-    DBuf P(c, d2 * d2);
-    out.G22s = DBuf(c, d2 * d2);
-    gemm(c, true, false, d2, d2, d1, 1.0, Bmt, d2, A, d2, 0.0, P, d2);          // Bm A
-    solve_right(Li2, d2, P, d2, d2, 2.0, out.G22s);
-  }
-  return out;
-}
 
 }  // namespace
 
+// The sticky failure record of the stream-native loss (hip_common.h::Impl::loss_status): two ints in pinned host
+// memory that k_loss_finish writes when a factorization of the batch covariances met a non-positive pivot.
+// status[0] = 1 + view index (0: no failure since the last take), status[1] = pivot.
+void loss_status_take(ccz_ctx* c, bool synchronise, int* view, int* pivot) {
+  Impl* im = impl(c);
+  if (view) *view = 0;
+  if (pivot) *pivot = 0;
+  if (!im->loss_status) return;
+  if (synchronise) sync(c);
+  volatile int* st = im->loss_status;
+  const int v = st[0];
+  if (v != 0) {
+    if (view) *view = v;
+    if (pivot) *pivot = st[1];
+    st[0] = 0;
+    st[1] = 0;
+  }
+}
+
+static int* loss_status_dev(ccz_ctx* c) {
+  Impl* im = impl(c);
+  if (!im->loss_status) {
+    void* hp = nullptr;
+    if (hipHostMalloc(&hp, 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    std::memset(hp, 0, 64);
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(hp); return nullptr; }
+    im->loss_status = static_cast<int*>(hp);
+    im->loss_status_dev = static_cast<int*>(dp);
+  }
+  return im->loss_status_dev;
+}
+
+// Sum over all pairs a < b of the CCA loss of views a and b of ONE batch, and its gradient with respect to every view:
+// K1 on [z_1 .. z_m] -> pair_core -> loss -> sample-side products.  m = 2 is CCALoss (deep/objectives.py:61-102),
+// m > 2 MCCALoss (:138-153).  Everything is enqueued on the handle's stream; on the narrow path the host never waits.
+void pair_loss_impl(ccz_ctx* c, int dtype, const ccz_view* z, int m, int64_t n, double eps, void* loss_dev, void* const* g,
+                    const int64_t* ldg) {
+  if (dtype != CCZ_F32 && dtype != CCZ_F64) fail(CCZ_EUNSUP, "cca_loss: dtype must be CCZ_F32 or CCZ_F64");
+  if (!z || !loss_dev) fail(CCZ_EINVAL, "cca_loss: null argument");
+  if (m < 2 || m > LMAXV) fail(CCZ_EUNSUP, "cca_loss: 2 .. %d views are supported, got %d", LMAXV, m);
+  if (n < 2) fail(CCZ_EINVAL, "cca_loss: bad shape (at least 2 rows are required)");
+  int64_t dims[LMAXV], off[LMAXV + 1];
+  off[0] = 0;
+  bool want = false, all = g != nullptr;
+  for (int a = 0; a < m; ++a) {
+    if (!z[a].data || z[a].cols < 1 || z[a].ld < z[a].cols) fail(CCZ_EINVAL, "cca_loss: bad shape (view %d)", a);
+    dims[a] = z[a].cols;
+    off[a + 1] = off[a] + dims[a];
+    if (g && g[a]) {
+      if (!ldg || ldg[a] < dims[a]) fail(CCZ_EINVAL, "cca_loss: bad gradient stride (view %d)", a);
+      want = true;
+    } else {
+      all = false;
+    }
+  }
+  const int64_t D = off[m];
+  hipStream_t st = stream(c);
+  const bool narrow = narrow_ok(dims, m);
+
+  // two fp32 views whose widths suit the 256-column tiles of the FIFO GEMM are gathered into one n x D matrix: the
+  // gradient is then ONE product (Z - mean) Gamma whose column ranges land in g1 / g2
+  const size_t es = dtype == CCZ_F32 ? 4 : 8;
+  const bool fifo = m == 2 && narrow && dtype == CCZ_F32 && all &&
+                    gemm_f32_fifo_split_eligible(n, D, D, dims[0], g[0], ldg[0], g[1], ldg[1]);
+  PoolPtr zcat(c, fifo ? size_t(n) * D * es : 0);
+  ccz_view gathered{zcat.p, D, D};
+  if (fifo) {
+    for (int a = 0; a < 2; ++a)
+      CCZ_HIP(hipMemcpy2DAsync(zcat.as<char>() + size_t(off[a]) * es, size_t(D) * es, z[a].data, size_t(z[a].ld) * es, size_t(dims[a]) * es,
+                               size_t(n), hipMemcpyDeviceToDevice, st));
+  }
+  // Gamma and, as row D of the same buffer, the bias row mean' Gamma (the centring of the batch)
+  DBuf mom(c, D * D + D), gamma(c, want ? (D + 1) * D : 0), mean(c, D), acc(c, 1);
+  PoolPtr info(c, LMAXV * sizeof(int));
+  // narrow (a DCCA batch): embeddings (post-ReLU, un-normalised) routinely sit far from zero -- always take the
+  // pilot-shifted Gram for fp32: no host read-back, and at batch sizes the staged kernel costs the same as the FIFO
+  // one.  Wide (n ~ 1e6 rows x 8192): the automatic choice (one 2 D-double read-back) keeps centred data on the
+  // faster FIFO kernel.
+  moments_impl(c, dtype, fifo ? &gathered : z, fifo ? 1 : m, n, true, mom, false, dtype == CCZ_F32 ? (narrow ? 2 : 1) : 0, false);
+  pair_core(c, mom, n, dims, m, eps, want, acc, gamma, mean, info.as<int>(), want ? gamma.get() + D * D : nullptr);
+  hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(1), 0, st, acc.get(), dtype, loss_dev, static_cast<double*>(nullptr), info.as<int>(), m,
+                     loss_status_dev(c));
+  CCZ_LAUNCH_CHECK();
+  if (!want) return;
+  const double* bias = gamma.get() + D * D;
+  if (fifo) {
+    PoolPtr G32(c, size_t(D + 1) * D * 4);
+    hipLaunchKernelGGL(k_cvt_f32, dim3((unsigned)std::min<int64_t>(((D + 1) * D + 255) / 256, 2048)), dim3(256), 0, st, gamma.get(),
+                       (D + 1) * D, G32.as<float>());
+    CCZ_LAUNCH_CHECK();
+    gemm_f32_fifo_split(c, n, D, D, 1.0f, zcat.as<float>(), D, G32.as<float>(), G32.as<float>() + D * D, static_cast<float*>(g[0]), ldg[0],
+                        static_cast<float*>(g[1]), ldg[1], dims[0]);
+    return;
+  }
+  // dz_a = sum_b (z_b - mean_b) Gamma_ba : the own block first (it carries the bias row of ALL blocks), then the others
+  for (int a = 0; a < m; ++a) {
+    if (!g[a]) continue;
+    gemm_mixed(c, dtype, n, dims[a], dims[a], 1.0, z[a].data, z[a].ld, gamma.get() + off[a] * D + off[a], D, 0.0, g[a], ldg[a], bias + off[a]);
+    for (int b = 0; b < m; ++b)
+      if (b != a)
+        gemm_mixed(c, dtype, n, dims[a], dims[b], 1.0, z[b].data, z[b].ld, gamma.get() + off[b] * D + off[a], D, 1.0, g[a], ldg[a], nullptr);
+  }
+}
+
 void cca_loss_impl(ccz_ctx* c, int dtype, const void* z1, const void* z2, int64_t n, int64_t d1, int64_t d2, int64_t ld1,
                    int64_t ld2, double eps, void* loss_dev, void* g1, void* g2, int64_t ldg1, int64_t ldg2) {
-  if (dtype != CCZ_F32 && dtype != CCZ_F64) fail(CCZ_EUNSUP, "cca_loss: dtype must be CCZ_F32 or CCZ_F64");
   if (!z1 || !z2 || !loss_dev) fail(CCZ_EINVAL, "cca_loss: null argument");
   if (n < 2 || d1 < 1 || d2 < 1 || ld1 < d1 || ld2 < d2) fail(CCZ_EINVAL, "cca_loss: bad shape");
   if ((g1 && ldg1 < d1) || (g2 && ldg2 < d2)) fail(CCZ_EINVAL, "cca_loss: bad gradient stride");
-  const int64_t D = d1 + d2;
-  const double inv = 1.0 / double(n - 1);
-  const int64_t dims[2] = {d1, d2};
-  const bool want = g1 || g2;
-  hipStream_t st = stream(c);
-
-  if (fused_ok(dims, 2)) {
-    // fp32 batches whose widths suit the 256-column tiles of the FIFO GEMM are gathered into one n x D matrix: the
-    // gradient is then ONE product (Z - mean) Gamma whose column ranges land in g1 / g2
-    const size_t es = dtype == CCZ_F32 ? 4 : 8;
-    const bool fifo = dtype == CCZ_F32 && want && g1 && g2 &&
-                      gemm_f32_fifo_split_eligible(n, D, D, d1, g1, ldg1, g2, ldg2);
-    void* zcat = nullptr;
-    ccz_view views[2] = {{z1, d1, ld1}, {z2, d2, ld2}};
-    int nviews = 2;
-    if (fifo) {
-      zcat = dev_alloc(c, size_t(n) * D * es);
-      CCZ_HIP(hipMemcpy2DAsync(zcat, size_t(D) * es, z1, size_t(ld1) * es, size_t(d1) * es, size_t(n), hipMemcpyDeviceToDevice, st));
-      CCZ_HIP(hipMemcpy2DAsync(static_cast<char*>(zcat) + size_t(d1) * es, size_t(D) * es, z2, size_t(ld2) * es, size_t(d2) * es, size_t(n),
-                               hipMemcpyDeviceToDevice, st));
-      views[0] = ccz_view{zcat, D, D};                        // one n x D view: one column-sum launch, same tiles
-      nviews = 1;
-    }
-    // Gamma and, as row D of the same buffer, the bias row mean' Gamma (the centring of the batch)
-    DBuf mom(c, D * D + D), gamma(c, want ? (D + 1) * D : 0), mean(c, D), acc(c, 1);
-    int* info_dev = static_cast<int*>(dev_alloc(c, LMAXV * sizeof(int)));
-    // embeddings (post-ReLU, un-normalised) routinely sit far from zero: always take the pilot-shifted Gram for
-    // fp32 -- no host read-back, and at batch sizes the staged kernel costs the same as the FIFO one
-    moments_impl(c, dtype, views, nviews, n, true, mom, false, dtype == CCZ_F32 ? 2 : 0, false);
-    fused_core(c, mom, n, dims, 2, eps, want, acc, gamma, mean, info_dev, want ? gamma.get() + D * D : nullptr);
-    hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(1), 0, st, acc.get(), dtype, loss_dev, static_cast<double*>(nullptr));
-    CCZ_LAUNCH_CHECK();
-    if (want) {
-      double* bias = gamma.get() + D * D;
-      if (fifo) {
-        float* G32 = static_cast<float*>(dev_alloc(c, size_t(D + 1) * D * 4));
-        hipLaunchKernelGGL(k_cvt_f32, dim3((unsigned)std::min<int64_t>(((D + 1) * D + 255) / 256, 2048)), dim3(256), 0, st, gamma.get(),
-                           (D + 1) * D, G32);
-        CCZ_LAUNCH_CHECK();
-        gemm_f32_fifo_split(c, n, D, D, 1.0f, static_cast<const float*>(zcat), D, G32, G32 + D * D, static_cast<float*>(g1), ldg1,
-                            static_cast<float*>(g2), ldg2, d1);
-        dev_free(c, G32);
-      } else {
-        if (g1) {
-          gemm_mixed(c, dtype, n, d1, d1, 1.0, z1, ld1, gamma, D, 0.0, g1, ldg1, bias);
-          gemm_mixed(c, dtype, n, d1, d2, 1.0, z2, ld2, gamma.get() + d1 * D, D, 1.0, g1, ldg1, nullptr);
-        }
-        if (g2) {
-          gemm_mixed(c, dtype, n, d2, d2, 1.0, z2, ld2, gamma.get() + d1 * D + d1, D, 0.0, g2, ldg2, bias + d1);
-          gemm_mixed(c, dtype, n, d2, d1, 1.0, z1, ld1, gamma.get() + d1, D, 1.0, g2, ldg2, nullptr);
-        }
-      }
-    }
-    try {
-      check_info(c, info_dev, 2, "cca_loss");
-    } catch (...) {
-      dev_free(c, info_dev);
-      if (zcat) dev_free(c, zcat);
-      throw;
-    }
-    dev_free(c, info_dev);
-    if (zcat) dev_free(c, zcat);
-    return;
-  }
-
-  DBuf mom(c, D * D + D);
-  ccz_view views[2] = {{z1, d1, ld1}, {z2, d2, ld2}};
-  moments_impl(c, dtype, views, 2, n, true, mom, false, 1, false);
-  LossCore k = wide_core(c, mom, mom.get() + D * D, n, d1, d2, eps, g1 != nullptr, g2 != nullptr);
-  hipLaunchKernelGGL(k_neg_sum, dim3(1), dim3(256), 0, st, k.rd.get(), d1, dtype, loss_dev);
-  CCZ_LAUNCH_CHECK();
-  if (g1) {
-    DBuf bias(c, d1);
-    gemm(c, false, false, 1, d1, d1, 1.0, k.mu, D, k.G11s, d1, 0.0, bias, d1);
-    gemm(c, false, false, 1, d1, d2, 1.0, k.mu.get() + d1, D, k.G12t, d1, 1.0, bias, d1);
-    gemm_mixed(c, dtype, n, d1, d1, inv, z1, ld1, k.G11s, d1, 0.0, g1, ldg1, bias);
-    gemm_mixed(c, dtype, n, d1, d2, inv, z2, ld2, k.G12t, d1, 1.0, g1, ldg1, nullptr);
-  }
-  if (g2) {
-    DBuf bias(c, d2);
-    gemm(c, false, false, 1, d2, d2, 1.0, k.mu.get() + d1, D, k.G22s, d2, 0.0, bias, d2);
-    gemm(c, false, false, 1, d2, d1, 1.0, k.mu, D, k.G12, d2, 1.0, bias, d2);
-    gemm_mixed(c, dtype, n, d2, d2, inv, z2, ld2, k.G22s, d2, 0.0, g2, ldg2, bias);
-    gemm_mixed(c, dtype, n, d2, d1, inv, z1, ld1, k.G12, d2, 1.0, g2, ldg2, nullptr);
-  }
-  sync(c);
+  const ccz_view z[2] = {{z1, d1, ld1}, {z2, d2, ld2}};
+  void* const g[2] = {g1, g2};
+  const int64_t ldg[2] = {ldg1, ldg2};
+  pair_loss_impl(c, dtype, z, 2, n, eps, loss_dev, (g1 || g2) ? g : nullptr, ldg);
 }
 
 // Sum of the pairwise CCA losses of m views from the (all-reduced) batch moments: loss (host) and, if gamma_dev != NULL,
@@ -410,46 +412,21 @@ void pair_loss_moments_impl(ccz_ctx* c, const double* mom, int64_t n, const int6
                             double* loss_host, double* gamma_dev, double* mean_dev) {
   if (!mom || !dims || !loss_host) fail(CCZ_EINVAL, "pair_loss_moments: null argument");
   if (m < 2 || n < 2) fail(CCZ_EINVAL, "pair_loss_moments: at least 2 views and 2 rows are required");
+  if (m > LMAXV) fail(CCZ_EUNSUP, "pair_loss_moments: at most %d views", LMAXV);
   for (int a = 0; a < m; ++a)
     if (dims[a] < 1) fail(CCZ_EINVAL, "pair_loss_moments: view %d has no features", a);
   const bool want = gamma_dev != nullptr;
   if (want && !mean_dev) fail(CCZ_EINVAL, "pair_loss_moments: mean_dev is required with gamma_dev");
   int64_t D = 0;
   for (int a = 0; a < m; ++a) D += dims[a];
-  if (fused_ok(dims, m)) {
-    DBuf acc(c, 2), mean_tmp(c, want ? 0 : D);
-    int* info_dev = static_cast<int*>(dev_alloc(c, LMAXV * sizeof(int)));
-    fused_core(c, mom, n, dims, m, eps, want, acc, gamma_dev, want ? mean_dev : mean_tmp.get(), info_dev);
-    hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(1), 0, stream(c), acc.get(), CCZ_F64, static_cast<void*>(nullptr), acc.get() + 1);
-    CCZ_LAUNCH_CHECK();
-    try {
-      check_info(c, info_dev, m, "pair_loss_moments");
-    } catch (...) {
-      dev_free(c, info_dev);
-      throw;
-    }
-    dev_free(c, info_dev);
-    d2h(c, loss_host, acc.get() + 1, 8);
-    return;
-  }
-  if (m != 2) fail(CCZ_EUNSUP, "pair_loss_moments: views wider than %lld features are supported for 2 views only", (long long)kFusedMaxD);
-  const int64_t d1 = dims[0], d2 = dims[1];
-  LossCore k = wide_core(c, mom, mom + D * D, n, d1, d2, eps, want, want);
-  std::vector<double> rh(d1);
-  d2h(c, rh.data(), k.rd, size_t(d1) * 8);
-  double l = 0.0;
-  for (double v : rh) l -= v;
-  *loss_host = l;
-  if (want) {
-    const double inv = 1.0 / double(n - 1);
-    copy2d(c, d1, d1, k.G11s, d1, gamma_dev, D);
-    copy2d(c, d1, d2, k.G12, d2, gamma_dev + d1, D);
-    copy2d(c, d2, d1, k.G12t, d1, gamma_dev + d1 * D, D);
-    copy2d(c, d2, d2, k.G22s, d2, gamma_dev + d1 * D + d1, D);
-    axpby2d(c, D, D, inv, gamma_dev, D, 0.0, nullptr, 0);
-    d2d(c, mean_dev, k.mu, size_t(D) * 8);
-  }
-  sync(c);
+  DBuf acc(c, 2), mean_tmp(c, want ? 0 : D);
+  PoolPtr info(c, LMAXV * sizeof(int));
+  pair_core(c, mom, n, dims, m, eps, want, acc, gamma_dev, want ? mean_dev : mean_tmp.get(), info.as<int>());
+  hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(1), 0, stream(c), acc.get(), CCZ_F64, static_cast<void*>(nullptr), acc.get() + 1,
+                     static_cast<const int*>(nullptr), 0, static_cast<int*>(nullptr));
+  CCZ_LAUNCH_CHECK();
+  check_info(c, info.as<int>(), m, "pair_loss_moments");   // the loss goes back to the HOST here: this entry synchronises anyway
+  d2h(c, loss_host, acc.get() + 1, 8);
 }
 
 void cca_loss_moments_impl(ccz_ctx* c, const double* mom, int64_t n, int64_t d1, int64_t d2, double eps, double* loss_host,

@@ -171,6 +171,13 @@ void row_dots(ccz_ctx* c, int64_t rows, int64_t cols, const double* A, int64_t l
 void gather_rows(ccz_ctx* c, int64_t rows, int64_t cols, const double* in, int64_t ldi,
                  const int64_t* perm_host, const double* scale_host, double* out, int64_t ldo);
 
+// ---- measurement aid (CCZ_TRACE_PHASES=2) ------------------------------------------
+// trace_mark: note a phase boundary on the handle's stream WITHOUT synchronising (HIP backend: an event, a host
+// time stamp and a 20 us single-wave kernel that measures the shader clock); trace_flush: wait for the stream and
+// print, per phase, device time, host time and the shader clock at its end.  No-ops on the host backend.
+void trace_mark(ccz_ctx* c, const char* name);
+void trace_flush(ccz_ctx* c, const char* what);
+
 // ---- solver drivers (solve.cpp) used by other translation units -------------
 // full symmetric EVD of A (d x d, destroyed): w_host (d, descending), V rows = eigenvectors
 int syev_full(ccz_ctx* c, double* A, int64_t d, std::vector<double>& w_host, double* Vrows,

@@ -6,6 +6,9 @@
 // matrix pipe (v_mfma_f64_16x16x4_f64); Cholesky / triangular solves are
 // blocked around it; the Jacobi rotations run one workgroup per row pair.
 #include <algorithm>
+#include <chrono>
+#include <string>
+#include <vector>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -71,7 +74,16 @@ void h2d_small(ccz_ctx* c, void* dst, const void* src, size_t bytes) {
   if (!bytes) return;
   Impl* im = impl(c);
   if (bytes > Impl::kSmallBytes) { h2d(c, dst, src, bytes); return; }
-  const int i = im->small_next;
+  // next slot of the ring whose previous copy has drained (a deep queue -- many enqueue-only calls behind a long
+  // kernel -- must not make the host wait for the device: look for a free slot before blocking on the oldest one)
+  int i = im->small_next;
+  for (int t = 0; t < Impl::kSmallSlots; ++t) {
+    const int j = (im->small_next + t) % Impl::kSmallSlots;
+    if (!im->small_pin[j]) { i = j; break; }
+    const hipError_t q = hipEventQuery(im->small_ev[j]);
+    if (q == hipSuccess) { i = j; break; }
+    if (q != hipErrorNotReady) { (void)hipGetLastError(); }
+  }
   if (!im->small_pin[i]) {
     if (hipHostMalloc(&im->small_pin[i], Impl::kSmallBytes, hipHostMallocDefault) != hipSuccess ||
         hipEventCreateWithFlags(&im->small_ev[i], hipEventDisableTiming) != hipSuccess) {
@@ -81,7 +93,7 @@ void h2d_small(ccz_ctx* c, void* dst, const void* src, size_t bytes) {
       return;
     }
   } else {
-    CCZ_HIP(hipEventSynchronize(im->small_ev[i]));      // the copy that last used this slot has drained it
+    CCZ_HIP(hipEventSynchronize(im->small_ev[i]));      // (returns at once for a drained slot)
   }
   im->small_next = (i + 1) % Impl::kSmallSlots;
   std::memcpy(im->small_pin[i], src, bytes);
@@ -102,6 +114,56 @@ void zero(ccz_ctx* c, void* dst, size_t bytes) {
   CCZ_HIP(hipMemsetAsync(dst, 0, bytes, stream(c)));
 }
 void sync(ccz_ctx* c) { CCZ_HIP(hipStreamSynchronize(stream(c))); }
+
+// ---- phase tracing without synchronisation (ops.h: trace_mark / trace_flush) ----
+__global__ void k_clock_probe(long long* out) {
+  const long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
+  while (wall_clock64() - w0 < 2000) {}                     // 20 us of the constant 100 MHz counter
+  if (threadIdx.x == 0) { out[0] = __builtin_readcyclecounter() - c0; out[1] = wall_clock64() - w0; }
+}
+namespace {
+struct TraceMark { std::string name; hipEvent_t ev; double host_ms; };
+struct TraceState {
+  std::vector<TraceMark> marks;
+  std::vector<hipEvent_t> spare;
+  long long* probes = nullptr;      // 2 x 64 counters, device
+  std::chrono::steady_clock::time_point t0;
+};
+TraceState& trace_state() { static TraceState s; return s; }
+}  // namespace
+void trace_mark(ccz_ctx* c, const char* name) {
+  TraceState& ts = trace_state();
+  if (ts.marks.size() >= 64) return;
+  if (!ts.probes) CCZ_HIP(hipMalloc(reinterpret_cast<void**>(&ts.probes), 64 * 2 * sizeof(long long)));
+  if (ts.marks.empty()) ts.t0 = std::chrono::steady_clock::now();
+  hipEvent_t ev;
+  if (!ts.spare.empty()) { ev = ts.spare.back(); ts.spare.pop_back(); }
+  else CCZ_HIP(hipEventCreate(&ev));
+  hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, stream(c), ts.probes + 2 * ts.marks.size());
+  CCZ_HIP(hipEventRecord(ev, stream(c)));
+  const double hm = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts.t0).count();
+  ts.marks.push_back({name, ev, hm});
+}
+void trace_flush(ccz_ctx* c, const char* what) {
+  TraceState& ts = trace_state();
+  if (ts.marks.empty()) return;
+  CCZ_HIP(hipStreamSynchronize(stream(c)));
+  std::vector<long long> pr(ts.marks.size() * 2);
+  CCZ_HIP(hipMemcpy(pr.data(), ts.probes, pr.size() * sizeof(long long), hipMemcpyDeviceToHost));
+  std::string line;
+  char buf[160];
+  for (size_t i = 0; i < ts.marks.size(); ++i) {
+    float dev_ms = 0.f;
+    if (i > 0) (void)hipEventElapsedTime(&dev_ms, ts.marks[i - 1].ev, ts.marks[i].ev);
+    const double mhz = pr[2 * i + 1] > 0 ? double(pr[2 * i]) / (double(pr[2 * i + 1]) / 100.0) : 0.0;
+    snprintf(buf, sizeof(buf), " | %s dev %.2f host %.2f clk %.0f", ts.marks[i].name.c_str(), dev_ms,
+             ts.marks[i].host_ms - (i > 0 ? ts.marks[i - 1].host_ms : 0.0), mhz);
+    line += buf;
+  }
+  fprintf(stderr, "[ccz] %s phases (ms; each phase includes a 20 us probe)%s\n", what, line.c_str());
+  for (auto& m : ts.marks) ts.spare.push_back(m.ev);
+  ts.marks.clear();
+}
 void wave_kernels_init();
 void activate(ccz_ctx* c) {
   CCZ_HIP(hipSetDevice(c->device));

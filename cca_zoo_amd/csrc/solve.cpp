@@ -11,6 +11,7 @@
 // cited per driver; the dense NumPy statement of the same maths is
 // oracle/gram_form.py.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -590,6 +591,36 @@ void chol_solve_inplace(ccz_ctx* c, int64_t d, int64_t r, const double* L, int64
 // ===========================================================================
 // rCCA / CCA / PLS      reference: cca_zoo/linear/_rcca.py:69-101
 // ===========================================================================
+// CCZ_TRACE_PHASES=1: synchronise at the phase boundaries of the rCCA solve and print the wall time of each phase;
+// CCZ_TRACE_PHASES=2: no synchronisation -- events, host time stamps and shader-clock probes (ops.h::trace_mark).
+// (Measurement aids for the launch-bound chain; mode 1 changes the overlap between host and device.)
+struct PhaseTrace {
+  ccz_ctx* c;
+  int mode;
+  std::chrono::steady_clock::time_point t;
+  std::string line;
+  explicit PhaseTrace(ccz_ctx* c_) : c(c_) {
+    static const int env = [] { const char* e = getenv("CCZ_TRACE_PHASES"); return e ? atoi(e) : 0; }();
+    mode = env;
+    if (mode == 1) { sync(c); t = std::chrono::steady_clock::now(); }
+    if (mode == 2) trace_mark(c, "start");
+  }
+  void mark(const char* name) {
+    if (mode == 2) { trace_mark(c, name); return; }
+    if (mode != 1) return;
+    sync(c);
+    const auto now = std::chrono::steady_clock::now();
+    char buf[64];
+    snprintf(buf, sizeof(buf), " %s %.2f", name, std::chrono::duration<double, std::milli>(now - t).count());
+    line += buf;
+    t = now;
+  }
+  ~PhaseTrace() {
+    if (mode == 1) fprintf(stderr, "[ccz] rcca phases (ms):%s\n", line.c_str());
+    if (mode == 2) { try { trace_flush(c, "rcca"); } catch (...) {} }
+  }
+};
+
 static void rcca_solve_impl(ccz_ctx* c, const double* mom, int64_t n, const int64_t dims[2],
                             const double cc[2], int center, int k, double* W_host, double* means_host,
                             double* vals_host, int* k_out) {
@@ -604,6 +635,7 @@ static void rcca_solve_impl(ccz_ctx* c, const double* mom, int64_t n, const int6
   // reference: k = min(latent, rank1, rank2); ranks are at most min(n, d)
   int kk = int(std::min<int64_t>({int64_t(k), d1, d2, n}));
 
+  PhaseTrace pt(c);
   std::vector<DBuf> Rv(2);
   Rv[0] = DBuf(c, d1 * d1);
   Rv[1] = DBuf(c, d2 * d2);
@@ -613,8 +645,10 @@ static void rcca_solve_impl(ccz_ctx* c, const double* mom, int64_t n, const int6
   cov_block(c, G, D, s, n, ctr, (1.0 - cc[1]) * inv, d1, d2, d1, d2, Rv[1], d2);
   add_diag(c, d2, Rv[1], d2, cc[1]);
   cov_block(c, G, D, s, n, ctr, inv, 0, d1, d1, d2, M12, d2);
+  pt.mark("cov");
 
   std::vector<Whitener> Fv = make_whiteners(c, Rv, {d1, d2}, true);
+  pt.mark("factor");
   Whitener& F1 = Fv[0];
   Whitener& F2 = Fv[1];
   const int64_t r1 = F1.r, r2 = F2.r;
@@ -632,9 +666,11 @@ static void rcca_solve_impl(ccz_ctx* c, const double* mom, int64_t n, const int6
   if (F1.chol) { F1.right_apply(c, r2, Yt, d1, Yt, d1); Tt = std::move(Yt); }
   else { Tt = DBuf(c, r2 * r1); F1.right_apply(c, r2, Yt, d1, Tt, r1); Yt.reset(); }
 
+  pt.mark("whiten");
   std::vector<double> sv;
   DBuf Ut(c, int64_t(kk) * r1), Vt(c, int64_t(kk) * r2);
   svd_topk_dense(c, Tt, r1, r2, kk, sv, Ut, Vt);
+  pt.mark("topk");
 
   if (F1.chol && F2.chol) {          // r_i = d_i: in place, both views' dependent steps in shared launches
     back_project_rows_multi(c, {&F1, &F2}, kk, {Ut.get(), Vt.get()}, {r1, r2});
@@ -648,6 +684,7 @@ static void rcca_solve_impl(ccz_ctx* c, const double* mom, int64_t n, const int6
     rows_to_host_cols(c, W2t, kk, d2, d2, 1.0, W_host + d1 * kk);
   }
   means_out(c, s, D, n, ctr, means_host);
+  pt.mark("backproject");
   if (vals_host) std::copy(sv.begin(), sv.begin() + kk, vals_host);
   if (k_out) *k_out = kk;
 }

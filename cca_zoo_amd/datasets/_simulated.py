@@ -64,7 +64,7 @@ class JointData:
     def __call__(self) -> list[np.ndarray]:
         return self.sample()
 
-    def sample_device(self, device="cuda", dtype=None, n_samples=None, seed=None, row0=0, row_chunk=131072):
+    def sample_device(self, device="cuda", dtype=None, n_samples=None, seed=None, *, row0=0, row_chunk=131072):
         """Draw rows ``[row0, row0 + n_samples)`` of the views directly into HBM (torch CUDA tensors).
 
         Every element is a pure function of ``(seed, global row, column)`` (``ccz_randn_fill``: SplitMix64 +
@@ -96,7 +96,8 @@ class JointData:
         wts = [torch.as_tensor(np.ascontiguousarray((w * scales[None, :]).T), dtype=torch.float64, device=dev)
                for w in self._weights]                                    # k x d_v
         zbuf = torch.empty((min(n, row_chunk), k), dtype=dtype, device=dev)
-        torch.cuda.current_stream(dev).synchronize()
+        sp = int(torch.cuda.current_stream(dev).cuda_stream)
+        h.acquire(sp)                                      # every call below only enqueues work on libccz's stream
         for r0 in range(0, n, row_chunk):
             rows = min(n, r0 + row_chunk) - r0
             h.check(h.lib.ccz_randn_fill(h.raw, code, C.c_void_p(zbuf.data_ptr()), rows, k, k, zseed, int(row0) + r0,
@@ -109,5 +110,6 @@ class JointData:
                                             C.c_void_p(wt.data_ptr()), d, C.c_void_p(blk.data_ptr()), d))
                 h.check(h.lib.ccz_randn_fill(h.raw, code, C.c_void_p(blk.data_ptr()), rows, d, d,
                                              (base + 2 + v) & 0xFFFFFFFFFFFFFFFF, int(row0) + r0, d + (d & 1), sd, 1))
-        h.sync()
+        h.release(sp)
+        h.sync()                                           # one wait per draw: the views are complete when this returns
         return outs

@@ -53,14 +53,15 @@ class _BatchWhiten(nn.Module):
         self.num_batches_tracked.add_(1)
         n, d = int(x.shape[0]), int(x.shape[1])
         a = x.detach()
-        a = a if a.stride(1) == 1 else a.contiguous()
+        a = a if (a.stride(1) == 1 and a.stride(0) >= a.shape[1]) else a.contiguous()
         h = _backend.handle_for([x])
         mom = torch.empty(d * d + d, dtype=torch.float64, device=x.device)
-        torch.cuda.current_stream(x.device).synchronize()
+        sp = int(torch.cuda.current_stream(x.device).cuda_stream)
+        h.acquire(sp)                                      # enqueue-only: the stream hand-over happens on the device
         h.moments([(a.data_ptr(), d, a.stride(0))], n, _backend.F32 if a.dtype == torch.float32 else _backend.F64,
-                  True, mom.data_ptr())
+                  True, mom.data_ptr(), pilot=True, timed=False)
         h.moments_symmetrize(mom.data_ptr(), d)
-        h.sync()
+        h.release(sp)
         batch_cov = (mom[: d * d].reshape(d, d) / n).to(self.running_covar.dtype)
         with torch.no_grad():
             self.running_covar.mul_(1.0 - self.momentum).add_(batch_cov * self.momentum)

@@ -13,6 +13,13 @@ input gradients (row 9) as four MFMA GEMMs, instead of autograd through ``eigh``
 (which is NaN at repeated eigenvalues; the closed form is not).
 
 Inputs must be CUDA tensors: there is no CPU implementation in this package.
+
+Stream contract (the reference's ``training_step``: cca_zoo/deep/_base.py:78-104).  The loss is an
+ordinary node of the autograd graph: libccz's stream is joined to ``torch.cuda.current_stream()`` on the DEVICE before and
+after the call (``ccz_stream_acquire`` / ``ccz_stream_release``; nothing at all for the default stream, with which the
+handle's blocking stream is ordered implicitly).  ``CCALoss`` / ``MCCALoss`` never make the host wait: a failed
+factorization (possible only with eps <= 0 or non-finite inputs) turns the loss into NaN and is raised as ``LinAlgError``
+by the NEXT loss call on that device or by :func:`check_async_errors`.
 """
 
 from __future__ import annotations
@@ -23,6 +30,32 @@ import torch
 import torch.nn as nn
 
 from cca_zoo_amd import _backend
+
+
+def _stream_ptr(t: torch.Tensor) -> int:
+    return int(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _raise_pending(h, synchronise: bool = False) -> None:
+    st = h.loss_status(synchronise)
+    if st is not None:
+        import numpy as np
+
+        raise np.linalg.LinAlgError(
+            f"an earlier CCALoss / MCCALoss call on this device returned NaN: S_{st[0] + 1}{st[0] + 1} + eps I was not "
+            f"positive definite (pivot {st[1]}); eps must be > 0 and the representations finite")
+
+
+def check_async_errors(device=None) -> None:
+    """Drain libccz's stream on ``device`` (default: the current one) and raise ``LinAlgError`` if a loss evaluated since the
+    last check met a non-positive pivot (its value was NaN).  The losses themselves never wait for the device."""
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    _raise_pending(_backend.default_handle(dev if dev is not None else torch.cuda.current_device()), synchronise=True)
+
+
+def _view_of(t: torch.Tensor) -> torch.Tensor:
+    """Row-major with unit column stride and non-overlapping rows (else a contiguous copy)."""
+    return t if (t.stride(1) == 1 and t.stride(0) >= t.shape[1]) else t.contiguous()
 
 
 def _require_cuda(t: torch.Tensor, what: str) -> None:
@@ -56,14 +89,17 @@ class _ShardedCCALossFn(torch.autograd.Function):
         dev = zcat.device
         h = _backend.handle_for([zcat])
         mom = torch.empty(D * D + D, dtype=torch.float64, device=dev)
-        torch.cuda.current_stream(dev).synchronize()
-        h.moments([(zcat.data_ptr(), D, D)], n_local, _backend.F32 if dt == torch.float32 else _backend.F64, True, mom.data_ptr())
+        sp = _stream_ptr(zcat)
+        h.acquire(sp)
+        h.moments([(zcat.data_ptr(), D, D)], n_local, _backend.F32 if dt == torch.float32 else _backend.F64, True, mom.data_ptr(),
+                  pilot=True, timed=False)
         npk = D * (D + 1) // 2 + D
         packed = torch.empty(npk + 1, dtype=torch.float64, device=dev)
         h.moments_pack(mom.data_ptr(), D, packed.data_ptr())
-        h.sync()
+        h.release(sp)                                      # the collective (torch's stream) follows libccz's stream on the device
         packed[npk:].fill_(float(n_local))
         n_total = _dist.allreduce_moments(packed, _dist.active_group())
+        h.acquire(sp)
         h.moments_unpack(packed.data_ptr(), D, mom.data_ptr())
         need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         loss_h = C.c_double(0.0)
@@ -86,38 +122,44 @@ class _ShardedCCALossFn(torch.autograd.Function):
         return (grad_out * g1).to(ctx.dtypes[0]), (grad_out * g2).to(ctx.dtypes[1]), None
 
 
-class _CCALossFn(torch.autograd.Function):
+class _PairLossFn(torch.autograd.Function):
+    """Sum over all view pairs of the CCA loss of ONE batch (``ccz_pair_loss``; two views: ``CCALoss``): one K1 pass over
+    ``[z_1 .. z_m]``, one Cholesky + inverse per VIEW -- the reference re-centres every view and recomputes its
+    ``S_aa^-1/2`` once per PAIR (cca_zoo/deep/objectives.py:138-153) -- the loss written on the device and the gradient of
+    every view straight into its own tensor.  Enqueue-only: no host synchronisation, no concatenated copy."""
+
     @staticmethod
-    def forward(ctx, z1: torch.Tensor, z2: torch.Tensor, eps: float) -> torch.Tensor:
-        _require_cuda(z1, "CCALoss")
-        _require_cuda(z2, "CCALoss")
-        if z1.dtype != z2.dtype:
-            z2 = z2.to(z1.dtype)
-        if z1.dim() != 2 or z2.dim() != 2 or z1.shape[0] != z2.shape[0]:
-            raise ValueError("CCALoss expects two (batch, d_i) tensors with equal batch size")
-        a = z1 if (z1.stride(1) == 1 and z1.stride(0) >= z1.shape[1]) else z1.contiguous()
-        b = z2 if (z2.stride(1) == 1 and z2.stride(0) >= z2.shape[1]) else z2.contiguous()
-        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
-        loss = torch.empty((), dtype=a.dtype, device=a.device)
-        g1 = torch.empty_like(a, memory_format=torch.contiguous_format) if need else None
-        g2 = torch.empty_like(b, memory_format=torch.contiguous_format) if need else None
-        h = _backend.handle_for([a])
-        torch.cuda.current_stream(a.device).synchronize()
-        h.check(h.lib.ccz_cca_loss(
-            h.raw, _backend.F32 if a.dtype == torch.float32 else _backend.F64,
-            C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), a.shape[0], a.shape[1], b.shape[1],
-            a.stride(0), b.stride(0), float(eps), C.c_void_p(loss.data_ptr()),
-            C.c_void_p(g1.data_ptr()) if need else None, C.c_void_p(g2.data_ptr()) if need else None,
-            g1.stride(0) if need else 0, g2.stride(0) if need else 0))
-        h.sync()
+    def forward(ctx, eps: float, what: str, *zs: torch.Tensor) -> torch.Tensor:
+        for z in zs:
+            _require_cuda(z, what)
+            if z.dim() != 2 or z.shape[0] != zs[0].shape[0]:
+                raise ValueError(f"{what} expects (batch, d_i) tensors with equal batch size")
+        dt = zs[0].dtype
+        vs = [_view_of(z if z.dtype == dt else z.to(dt)) for z in zs]
+        m = len(vs)
+        h = _backend.handle_for(vs)
+        _raise_pending(h)
+        need = any(ctx.needs_input_grad[2:])
+        loss = torch.empty((), dtype=dt, device=vs[0].device)
+        grads = [torch.empty_like(v, memory_format=torch.contiguous_format) for v in vs] if need else None
+        views = (_backend.View * m)()
+        for i, v in enumerate(vs):
+            views[i].data, views[i].cols, views[i].ld = v.data_ptr(), int(v.shape[1]), int(v.stride(0))
+        gp = (C.c_void_p * m)(*[g.data_ptr() for g in grads]) if need else None
+        ldg = (C.c_int64 * m)(*[int(g.stride(0)) for g in grads]) if need else None
+        sp = _stream_ptr(vs[0])
+        h.acquire(sp)
+        h.check(h.lib.ccz_pair_loss(h.raw, _backend.F32 if dt == torch.float32 else _backend.F64, views, m, int(vs[0].shape[0]),
+                                    float(eps), C.c_void_p(loss.data_ptr()), gp, ldg))
+        h.release(sp)
         if need:
-            ctx.save_for_backward(g1, g2)
+            ctx.save_for_backward(*grads)
+            ctx.dtypes = [z.dtype for z in zs]
         return loss
 
     @staticmethod
     def backward(ctx, grad_out):
-        g1, g2 = ctx.saved_tensors
-        return grad_out * g1, grad_out * g2, None
+        return (None, None, *[(grad_out * g).to(t) for g, t in zip(ctx.saved_tensors, ctx.dtypes)])
 
 
 def _inv_sqrtm(A: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
@@ -126,10 +168,11 @@ def _inv_sqrtm(A: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
     h = _backend.handle_for([A])
     a64 = A.detach().to(torch.float64).contiguous()
     out = torch.empty_like(a64)
-    torch.cuda.current_stream(A.device).synchronize()
+    sp = _stream_ptr(A)
+    h.acquire(sp)
     h.check(h.lib.ccz_inv_sqrtm(h.raw, C.c_void_p(a64.data_ptr()), a64.shape[0], float(eps),
                                 C.c_void_p(out.data_ptr())))
-    h.sync()
+    h.release(sp)
     return out.to(A.dtype)
 
 
@@ -155,14 +198,15 @@ class CCALoss(nn.Module):
 
         if _dist.is_sharded():
             return _ShardedCCALossFn.apply(z1, z2, self.eps)
-        return _CCALossFn.apply(z1, z2, self.eps)
+        if z1.dim() != 2 or z2.dim() != 2 or z1.shape[0] != z2.shape[0]:
+            raise ValueError("CCALoss expects two (batch, d_i) tensors with equal batch size")
+        return _PairLossFn.apply(self.eps, "CCALoss", z1, z2)
 
 
-class _PairLossFn(torch.autograd.Function):
-    """Sum over all view pairs of the CCA loss from ONE pass over the stacked batch: K1 on ``[z_1 .. z_m]``, (inside
-    ``row_sharded()``) one all-reduce of the packed moments, ``ccz_pair_loss_moments`` -- one Cholesky + inverse per
-    VIEW, where the reference re-centres every view and recomputes its ``S_aa^-1/2`` once per PAIR
-    (cca_zoo/deep/objectives.py:138-153) -- and the gradient of every view as one ``ccz_transform`` GEMM
+class _ShardedPairLossFn(torch.autograd.Function):
+    """``MCCALoss`` of a batch whose rows are spread over the ranks of ``row_sharded()``: K1 on the local rows of
+    ``[z_1 .. z_m]``, one all-reduce of the packed moments, ``ccz_pair_loss_moments`` replicated (one Cholesky + inverse
+    per view) and the gradient of the GLOBAL loss with respect to the LOCAL rows as one ``ccz_transform`` GEMM
     ``(Z - mean) Gamma``."""
 
     @staticmethod
@@ -180,16 +224,19 @@ class _PairLossFn(torch.autograd.Function):
         dev = zcat.device
         h = _backend.handle_for([zcat])
         mom = torch.empty(D * D + D, dtype=torch.float64, device=dev)
-        torch.cuda.current_stream(dev).synchronize()
-        h.moments([(zcat.data_ptr(), D, D)], n_local, _backend.F32 if dt == torch.float32 else _backend.F64, True, mom.data_ptr())
+        sp = _stream_ptr(zcat)
+        h.acquire(sp)
+        h.moments([(zcat.data_ptr(), D, D)], n_local, _backend.F32 if dt == torch.float32 else _backend.F64, True, mom.data_ptr(),
+                  pilot=True, timed=False)
         n_total = n_local
         if _dist.is_sharded():
             npk = D * (D + 1) // 2 + D
             packed = torch.empty(npk + 1, dtype=torch.float64, device=dev)
             h.moments_pack(mom.data_ptr(), D, packed.data_ptr())
-            h.sync()
+            h.release(sp)
             packed[npk:].fill_(float(n_local))
             n_total = _dist.allreduce_moments(packed, _dist.active_group())
+            h.acquire(sp)
             h.moments_unpack(packed.data_ptr(), D, mom.data_ptr())
         need = any(ctx.needs_input_grad[1:])
         loss_h = C.c_double(0.0)
@@ -212,10 +259,6 @@ class _PairLossFn(torch.autograd.Function):
         return (None, *[(grad_out * g).to(t) for g, t in zip(grads, ctx.dtypes)])
 
 
-#: widest view the one-pass pairwise core serves (wider views: pair by pair through ``CCALoss``)
-_PAIR_CORE_MAX_WIDTH = 2048
-
-
 class MCCALoss(nn.Module):
     r"""Sum of pairwise :class:`CCALoss` over all view pairs ``i < j``.
 
@@ -223,16 +266,23 @@ class MCCALoss(nn.Module):
         eps: ridge passed to every pairwise loss (default 1e-5).
     """
 
+    #: views one fused pass serves (``ccz_pair_loss``); more fall back to the pair-by-pair sum
+    _MAX_FUSED_VIEWS = 8
+
     def __init__(self, eps: float = 1e-5) -> None:
         super().__init__()
         self.eps = eps
         self._cca_loss = CCALoss(eps=eps)
 
     def forward(self, representations: list[torch.Tensor]) -> torch.Tensor:
+        from cca_zoo_amd import _dist
+
         n_views = len(representations)
         total = torch.tensor(0.0, device=representations[0].device)      # fp32 accumulator, as the reference (:149)
-        if 2 <= n_views <= 8 and max(int(z.shape[1]) for z in representations) <= _PAIR_CORE_MAX_WIDTH:
-            return total + _PairLossFn.apply(self.eps, *representations)
+        if 2 <= n_views <= self._MAX_FUSED_VIEWS:
+            if _dist.is_sharded():
+                return total + _ShardedPairLossFn.apply(self.eps, *representations)
+            return total + _PairLossFn.apply(self.eps, "MCCALoss", *representations)
         for i in range(n_views):
             for j in range(i + 1, n_views):
                 total = total + self._cca_loss([representations[i], representations[j]])
@@ -242,14 +292,15 @@ class MCCALoss(nn.Module):
 def _project(x: torch.Tensor, mean64: torch.Tensor, w64: torch.Tensor) -> torch.Tensor:
     """``(x - mean) @ w`` through ``ccz_transform`` (x: n x d CUDA tensor, mean: d, w: d x k float64 CUDA)."""
     h = _backend.handle_for([x])
-    a = x if (x.stride(1) == 1 and x.stride(0) >= x.shape[1]) else x.contiguous()   # e.g. an expanded gradient
+    a = _view_of(x)                                        # e.g. an expanded gradient
     out = torch.empty((a.shape[0], w64.shape[1]), dtype=a.dtype, device=a.device)
-    torch.cuda.current_stream(a.device).synchronize()
+    sp = _stream_ptr(a)
+    h.acquire(sp)
     h.check(h.lib.ccz_transform(h.raw, _backend.F32 if a.dtype == torch.float32 else _backend.F64,
                                 C.c_void_p(a.data_ptr()), a.shape[0], a.shape[1], a.stride(0),
                                 C.c_void_p(mean64.data_ptr()), C.c_void_p(w64.data_ptr()), w64.shape[1],
                                 C.c_void_p(out.data_ptr()), out.stride(0)))
-    h.sync()
+    h.release(sp)
     return out
 
 
@@ -278,8 +329,9 @@ class _GCCALossFn(torch.autograd.Function):
         dev = zcat.device
         h = _backend.handle_for([zcat])
         mom = torch.empty(D * D + D, dtype=torch.float64, device=dev)
-        torch.cuda.current_stream(dev).synchronize()
-        h.moments([(zcat.data_ptr(), D, D)], n, _backend.F32 if dt == torch.float32 else _backend.F64, True, mom.data_ptr())
+        h.acquire(_stream_ptr(zcat))
+        h.moments([(zcat.data_ptr(), D, D)], n, _backend.F32 if dt == torch.float32 else _backend.F64, True, mom.data_ptr(),
+                  pilot=True, timed=False)
         # C, B = blockdiag(C_ii) + eps I, the top-k generalised eigenpairs and Gamma are all built on the device
         # from the moments (ccz_gcca_loss_moments); only the k eigenvalues (as the loss) come back to the host
         need = any(ctx.needs_input_grad[1:])

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CCZ_VERSION 110 /* 0.1.1 */
+#define CCZ_VERSION 120 /* 0.1.2 */
 
 #if defined(__GNUC__)
 #define CCZ_API __attribute__((visibility("default")))
@@ -70,6 +70,15 @@ CCZ_API const char* ccz_last_error(ccz_handle h);
 /* stream = hipStream_t as void* (torch: torch.cuda.current_stream().cuda_stream); NULL = default */
 CCZ_API int ccz_set_stream(ccz_handle h, void* stream);
 CCZ_API int ccz_sync(ccz_handle h);
+/* Stream-native use from a framework that owns its streams (the DCCA objective inside a training step,
+ * deep/_base.py:78-104: the loss is one autograd node between the encoders' forward and backward): instead of
+ * draining the caller's stream before a libccz call and libccz's stream after it,
+ *   ccz_stream_acquire(h, s):  the handle's stream waits (on the DEVICE) for everything enqueued on s so far;
+ *   ccz_stream_release(h, s):  s waits (on the device) for everything the handle has enqueued so far.
+ * Neither blocks the host.  s = hipStream_t as void*; NULL = the legacy default stream, with which the handle's own
+ * (blocking) stream is ordered implicitly -- then nothing is enqueued at all. */
+CCZ_API int ccz_stream_acquire(ccz_handle h, void* stream);
+CCZ_API int ccz_stream_release(ccz_handle h, void* stream);
 CCZ_API int ccz_device_info(ccz_handle h, ccz_devinfo* out);
 
 /* ---- raw device memory for callers that do not bring torch tensors ------- */
@@ -94,6 +103,12 @@ CCZ_API int ccz_memset0(ccz_handle h, void* dst_dev, size_t bytes);
  */
 CCZ_API int ccz_moments(ccz_handle h, int dtype, const ccz_view* views, int n_views, int64_t n_rows,
                 int views_on_device, double* moments_dev, int accumulate);
+/* ccz_moments with its two policies exposed: pilot_mode 0 = never shift, 1 = automatic (ccz_moments; one small
+ * read-back of the column sums decides), 2 = always shift fp32 views (no read-back); timed = 0 skips the HIP-event
+ * timing of ccz_moments_last_ms, whose read-out makes the host wait for K1 -- with (2, 0) or fp64 views the call only
+ * ENQUEUES work on the handle's stream (the stream-native losses use it that way). */
+CCZ_API int ccz_moments_opts(ccz_handle h, int dtype, const ccz_view* views, int n_views, int64_t n_rows,
+                int views_on_device, double* moments_dev, int accumulate, int pilot_mode, int timed);
 CCZ_API int ccz_moments_symmetrize(ccz_handle h, double* moments_dev, int64_t D);
 /* Packed form for the one collective of the sharded path: [ upper triangle of G, row-major,
  * D(D+1)/2 | colsum (D) ] -- half the bytes of the full buffer on the wire.  pack: moments -> packed;
@@ -185,6 +200,20 @@ CCZ_API int ccz_gemm_f64(ccz_handle h, int transA, int transB, int64_t M, int64_
 CCZ_API int ccz_cca_loss(ccz_handle h, int dtype, const void* z1_dev, const void* z2_dev, int64_t n,
                  int64_t d1, int64_t d2, int64_t ld1, int64_t ld2, double eps, void* loss_dev,
                  void* g1_dev, void* g2_dev, int64_t ldg1, int64_t ldg2);
+/* The sum over all view pairs a < b of that loss for n_views (2 .. 8) views of one batch, any widths -- MCCALoss,
+ * deep/objectives.py:138-153 (n_views = 2 IS ccz_cca_loss) -- and its gradient with respect to every view: ONE K1
+ * pass over [z_1 .. z_m], ONE Cholesky + inverse per VIEW (the reference re-centres every view and recomputes its
+ * S_aa^-1/2 once per PAIR).  z_dev: HOST array of n_views device views; g_dev: NULL (forward only) or a HOST array of
+ * n_views device pointers (entries may be NULL), ldg their leading dimensions; loss_dev: one element of `dtype`. */
+CCZ_API int ccz_pair_loss(ccz_handle h, int dtype, const ccz_view* z_dev, int n_views, int64_t n, double eps,
+                  void* loss_dev, void* const* g_dev, const int64_t* ldg);
+/* ccz_cca_loss / ccz_pair_loss never read the factorization's pivot flags back (no host synchronisation between the encoders' forward
+ * and backward).  If S_aa + eps I was not positive definite the loss written to loss_dev is NaN and the handle keeps a
+ * sticky record: *view = 1 + index of the failing view (0: none since the last query), *pivot = the failing pivot;
+ * querying clears it.  synchronise = 0 reads what has been recorded so far without waiting (a wrapper calls this
+ * before its NEXT loss call); synchronise = 1 drains the handle's stream first.  (The reference clamps eigenvalues at
+ * eps instead, deep/objectives.py:9-21, and cannot fail; with eps > 0 neither can this, short of NaN inputs.) */
+CCZ_API int ccz_loss_status(ccz_handle h, int synchronise, int* view, int* pivot);
 /* The same loss for a batch that is row-sharded over ranks: `moments_dev` holds the batch moments of
  * [z1 | z2] summed over all shards (ccz_moments per rank + one all-reduce), n_rows the total batch size.
  * Returns the loss (host) and, if gamma_dev != NULL, the (d1+d2) x (d1+d2) matrix Gamma and the batch mean
@@ -212,6 +241,8 @@ CCZ_API int ccz_gcca_loss_moments(ccz_handle h, const double* moments_dev, int64
 
 /* ---- transform / score -------------------------------
  * out (n x k, dtype) = (X - mean) W ; X,out device; mean (d), W (d x k) device float64.
+ * Enqueue-only on the handle's stream (no host synchronisation): follow with ccz_sync / ccz_stream_release /
+ * ccz_memcpy_d2h before another stream or the host reads `out`.
  * _base.py:108-123 */
 CCZ_API int ccz_transform(ccz_handle h, int dtype, const void* X_dev, int64_t n, int64_t d, int64_t ld,
                   const double* mean_dev, const double* W_dev, int64_t k, void* out_dev,

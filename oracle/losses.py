@@ -17,6 +17,7 @@ __all__ = [
     "cca_loss_autograd",
     "mcca_loss_autograd",
     "cca_loss_closed_form",
+    "cca_loss_from_moments",
     "mcca_loss_closed_form",
 ]
 
@@ -81,6 +82,35 @@ def cca_loss_closed_form(z1, z2, eps=1e-5):
     g1 -= g1.mean(axis=0)
     g2 -= g2.mean(axis=0)
     return loss, g1, g2
+
+
+def cca_loss_from_moments(G, s, n, d1, d2, eps=1e-5):
+    """The same closed form from the RAW second moments of the stacked batch ``[z1 | z2]`` -- ``G = Z'Z`` (D x D),
+    ``s = 1'Z`` (D), ``n`` rows -- for batches too large to hold in float64 on the host (the metric shape,
+    n = 1e6): returns ``(loss, Gamma, mean)`` with ``[dz1 | dz2] = (Z - 1 mean') Gamma`` for any subset of the rows.
+
+    ``Gamma = [[G11 + G11', G12], [G12', G22 + G22']] / (n - 1)`` in the notation of :func:`cca_loss_closed_form`
+    (cca_zoo/deep/objectives.py:61-102 + autograd); the column-centring of the gradients there is implied: columns of
+    ``Z - 1 mean'`` sum to zero."""
+    G = np.asarray(G, dtype=np.float64)
+    s = np.asarray(s, dtype=np.float64)
+    D = d1 + d2
+    C = (G - np.outer(s, s) / n) / (n - 1)
+    s11 = C[:d1, :d1] + eps * np.eye(d1)
+    s22 = C[d1:, d1:] + eps * np.eye(d2)
+    s12 = C[:d1, d1:]
+    P = np.linalg.solve(s11, s12)
+    Q = np.linalg.solve(s22, s12.T)
+    loss = -float(np.sum(P * Q.T))                 # tr(P Q)
+    G12 = -2.0 * np.linalg.solve(s22, P.T).T
+    G11 = np.linalg.solve(s11, (P @ Q).T).T
+    G22 = np.linalg.solve(s22, (Q @ P).T).T
+    Gamma = np.empty((D, D))
+    Gamma[:d1, :d1] = G11 + G11.T
+    Gamma[:d1, d1:] = G12
+    Gamma[d1:, :d1] = G12.T
+    Gamma[d1:, d1:] = G22 + G22.T
+    return loss, Gamma / (n - 1), s / n
 
 
 def mcca_loss_closed_form(zs, eps=1e-5):
