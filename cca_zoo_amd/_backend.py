@@ -60,6 +60,7 @@ SIGNATURES = {
     "ccz_sync": (_int, [_vp]),
     "ccz_stream_acquire": (_int, [_vp, _vp]),
     "ccz_stream_release": (_int, [_vp, _vp]),
+    "ccz_stream_adopt": (_int, [_vp, _vp]),
     "ccz_loss_status": (_int, [_vp, _int, _pint, _pint]),
     "ccz_device_info": (_int, [_vp, C.POINTER(DevInfo)]),
     "ccz_dev_alloc": (_int, [_vp, C.POINTER(_vp), C.c_size_t]),
@@ -209,6 +210,10 @@ class Handle:
     def release(self, stream_ptr):
         """``stream_ptr`` waits (on the device) for the handle's work so far; the host does not block."""
         self.check(self.lib.ccz_stream_release(self._h, C.c_void_p(int(stream_ptr) or None)))
+
+    def adopt(self, stream_ptr):
+        """Enqueue INTO ``stream_ptr`` from now on (until the next ``acquire``): same hardware queue as the caller."""
+        self.check(self.lib.ccz_stream_adopt(self._h, C.c_void_p(int(stream_ptr) or None)))
 
     def loss_status(self, synchronise=False):
         """(view, pivot) of a factorization failure recorded by an earlier ``ccz_cca_loss`` call, or ``None``;

@@ -122,7 +122,8 @@ const char* ccz_last_error(ccz_handle h) { return h ? h->err.c_str() : "null han
 int ccz_set_stream(ccz_handle h, void* s) {
   CCZ_GUARD(h, {
     CCZ_HIP(hipStreamSynchronize(stream(h)));
-    h->stream = s;
+    h->stream = s ? s : static_cast<void*>(impl(h)->own_stream);       // NULL: back to the handle's own stream
+    impl(h)->adopted = false;
   })
 }
 
@@ -130,23 +131,50 @@ int ccz_sync(ccz_handle h) { CCZ_GUARD(h, sync(h)) }
 
 // Hand-over between a caller's stream and the handle's stream WITHOUT blocking the host.  The handle's own stream is
 // a blocking stream: it is already ordered with the legacy null stream (PyTorch's default stream) in both directions,
-// so nothing is enqueued for ext == NULL; any other stream is joined through an event.
+// so nothing is enqueued between those two; any other pair is joined through an event.  A stream that has been
+// destroyed since (a torch side stream) has no pending work: the failed record is ignored.
 static void stream_join(ccz_ctx* c, hipStream_t from, hipStream_t to, int slot) {
   if (from == to) return;
   Impl* im = impl(c);
-  const bool own_blocking = stream(c) == im->own_stream;
-  if (own_blocking && (from == nullptr || to == nullptr)) return;       // legacy null-stream ordering
+  const bool implicit = (from == im->own_stream && to == nullptr) || (from == nullptr && to == im->own_stream);
+  if (implicit) return;                                                // legacy null-stream ordering
   if (!im->xs_ev[slot]) CCZ_HIP(hipEventCreateWithFlags(&im->xs_ev[slot], hipEventDisableTiming));
-  CCZ_HIP(hipEventRecord(im->xs_ev[slot], from));
+  if (hipEventRecord(im->xs_ev[slot], from) != hipSuccess) { (void)hipGetLastError(); return; }
   CCZ_HIP(hipStreamWaitEvent(to, im->xs_ev[slot], 0));
 }
 
+// the handle goes back to its own stream (after ccz_stream_adopt), ordered after what it enqueued on the adopted one
+static void stream_home(ccz_ctx* c) {
+  Impl* im = impl(c);
+  if (stream(c) == im->own_stream || !im->adopted) return;
+  stream_join(c, stream(c), im->own_stream, 0);
+  c->stream = im->own_stream;
+  im->adopted = false;
+}
+
 int ccz_stream_acquire(ccz_handle h, void* ext) {
-  CCZ_GUARD(h, stream_join(h, static_cast<hipStream_t>(ext), stream(h), 0))
+  CCZ_GUARD(h, {
+    stream_home(h);
+    stream_join(h, static_cast<hipStream_t>(ext), stream(h), 0);
+  })
 }
 
 int ccz_stream_release(ccz_handle h, void* ext) {
-  CCZ_GUARD(h, stream_join(h, stream(h), static_cast<hipStream_t>(ext), 1))
+  CCZ_GUARD(h, {
+    if (!(impl(h)->adopted && stream(h) == static_cast<hipStream_t>(ext)))     // adopted: the work already sits in `ext`
+      stream_join(h, stream(h), static_cast<hipStream_t>(ext), 1);
+  })
+}
+
+int ccz_stream_adopt(ccz_handle h, void* ext) {
+  CCZ_GUARD(h, {
+    hipStream_t e = static_cast<hipStream_t>(ext);
+    if (stream(h) != e) {
+      stream_join(h, stream(h), e, 0);
+      h->stream = e;
+    }
+    impl(h)->adopted = true;
+  })
 }
 
 int ccz_loss_status(ccz_handle h, int synchronise, int* view, int* pivot) {

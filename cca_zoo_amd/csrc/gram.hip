@@ -148,13 +148,13 @@ template <bool FAST>
 __global__ __launch_bounds__(256, 1) void k_gram_f32(const GramTile* __restrict__ tiles, int ntiles, int per_xcd,
                                                      int64_t ksplit, int64_t n, int64_t rows_per_wg,
                                                      double* __restrict__ G, int64_t ldg,
-                                                     const float* __restrict__ pilot, float* __restrict__ partial) {
+                                                     const float* __restrict__ pilot, float* __restrict__ partial, int64_t row0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* lds = reinterpret_cast<float*>(smem);  // [2 buffers][A | B][BK][256]
   const WorkItem wi = locate_work(blockIdx.x, ntiles, per_xcd, ksplit);
   if (!wi.valid) return;
   const GramTile t = tiles[wi.tile];
-  const int64_t k_begin = wi.chunk * rows_per_wg;
+  const int64_t k_begin = row0 + wi.chunk * rows_per_wg;      // row0: first row of this launch (the tail after a FIFO launch)
   const int64_t k_end = min(n, k_begin + rows_per_wg);
   if (k_begin >= k_end) return;
   gptr_f32 A = (gptr_f32)(t.a);
@@ -326,10 +326,25 @@ constexpr int FSLOT = 2 * FSLAB;          // bytes per slot: A slab + B slab
 // One wave's whole pipeline for a 128 x 128 quadrant: rows [0, nrows) of the two 128-column slabs behind srcA / srcB
 // -> acc.  SYM (quadrant on the diagonal of G: A slab == B slab) skips the MFMA tiles with ti > tj: with the strided
 // tile ownership tile (tj, ti) is the transpose of tile (ti, tj), so 10 of the 16 tiles carry all the information.
-template <bool SYM>
+// a + b on packed pairs: two v_pk_add_f32 instead of four v_add_f32 (instructions of a wave are not hidden under
+// its own MFMAs -- every VALU op in the k-step loop costs ~1 % of the kernel)
+typedef float v2f32 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v4f32 pk_add4(v4f32 a, v4f32 b) {
+  v2f32 lo = {a[0], a[1]}, hi = {a[2], a[3]};
+  const v2f32 blo = {b[0], b[1]}, bhi = {b[2], b[3]};
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(lo) : "v"(lo), "v"(blo));
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(hi) : "v"(hi), "v"(bhi));
+  return v4f32{lo[0], lo[1], hi[0], hi[1]};
+}
+
+// PILOT: the per-lane pilot values pa / pb (the fp32 column means of the launch's rows, for the four columns this lane
+// feeds into the A / B operands) are subtracted from the fragments right after the LDS read: 8 VALU subtractions per
+// k-step as four v_pk_add_f32, so that data far from zero accumulates (x - p)(x - p)' like the reference's
+// centre-then-multiply.  Rows past the extent would read as 0 - p: the caller guarantees nrows % (FB * FR) == 0.
+template <bool SYM, bool PILOT>
 __device__ __forceinline__ void gram_fifo_quadrant(v16f32 (&acc)[4][4], char* ring, const char* rd,
                                                    __amdgpu_buffer_rsrc_t srcA, __amdgpu_buffer_rsrc_t srcB, int voffA,
-                                                   int voffB, int stepA, int stepB, int64_t nrows) {
+                                                   int voffB, int stepA, int stepB, int64_t nrows, v4f32 pa, v4f32 pb) {
   typedef __attribute__((address_space(3))) void* lds_ptr;
   int soffA = 0, soffB = 0;          // byte offset of the next k-step to DMA (rows past the extent arrive as 0)
   // prologue: blocks 0, 1, 2 -> slots 0, 1, 2 (12 k-steps = 24 DMA instructions)
@@ -359,7 +374,8 @@ __device__ __forceinline__ void gram_fifo_quadrant(v16f32 (&acc)[4][4], char* ri
         const int nslot = (u + 1 < NU) ? bb : (bb + 1) % FR;
         const int nu = (u + 1 < NU) ? u + 1 : 0;
         const int wsl = (bb + 3) % FR;               // slot being refilled: block b0 + bb + 3
-        const v4f32 a4 = af[cur], b4 = bf[cur];
+        v4f32 a4 = af[cur], b4 = bf[cur];
+        if (PILOT) { a4 = pk_add4(a4, pa); b4 = pk_add4(b4, pb); }      // pa / pb hold the NEGATED pilot
         // -- gap 0: fragment reads for the next k-step
         if (u == NU - 1) {
           // the next k-step opens block b+1: newer than it are block b+2 (8) and 3 k-steps of b+3 (6)
@@ -393,9 +409,10 @@ __device__ __forceinline__ void gram_fifo_quadrant(v16f32 (&acc)[4][4], char* ri
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+template <bool PILOT>
 __global__ __launch_bounds__(256, 1) void k_gram_f32_fifo(const GramTile* __restrict__ tiles, int ntiles, int per_xcd,
                                                           int64_t ksplit, int64_t n, int64_t rows_per_wg,
-                                                          double* __restrict__ G, int64_t ldg) {
+                                                          double* __restrict__ G, int64_t ldg, const float* __restrict__ pilot) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const WorkItem wi = locate_work(blockIdx.x, ntiles, per_xcd, ksplit);
   if (!wi.valid) return;
@@ -416,7 +433,8 @@ __global__ __launch_bounds__(256, 1) void k_gram_f32_fifo(const GramTile* __rest
   const bool sym = diag && wr == wc;
   int64_t row0 = 0, nrows = nrows_wg;
   if (diag && wr != wc) {
-    const int64_t half = ((nrows_wg + 1) / 2 + FB - 1) / FB * FB;
+    constexpr int HB = PILOT ? FB * FR : FB;           // (pilot: both halves stay whole ring periods -- no zero-filled rows)
+    const int64_t half = ((nrows_wg + 1) / 2 + HB - 1) / HB * HB;
     if (wr == 0) nrows = min(half, nrows_wg);          // wave (0,1): rows [0, half)
     else { row0 = min(half, nrows_wg); nrows = nrows_wg - row0; wr = 0; wc = 1; }   // wave (1,0): the rest of Q01
     if (nrows <= 0) return;
@@ -441,8 +459,13 @@ __global__ __launch_bounds__(256, 1) void k_gram_f32_fifo(const GramTile* __rest
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  if (sym) gram_fifo_quadrant<true>(acc, ring, rd, srcA, srcB, voffA, voffB, stepA, stepB, nrows);
-  else gram_fifo_quadrant<false>(acc, ring, rd, srcA, srcB, voffA, voffB, stepA, stepB, nrows);
+  v4f32 pa = {0.f, 0.f, 0.f, 0.f}, pb = {0.f, 0.f, 0.f, 0.f};
+  if (PILOT) {
+    pa = -*reinterpret_cast<const v4f32*>(pilot + t.out_row + wr * 128 + 4 * (lane & 31));    // negated: the loop adds
+    pb = -*reinterpret_cast<const v4f32*>(pilot + t.out_col + wc * 128 + 4 * (lane & 31));
+  }
+  if (sym) gram_fifo_quadrant<true, PILOT>(acc, ring, rd, srcA, srcB, voffA, voffB, stepA, stepB, nrows, pa, pb);
+  else gram_fifo_quadrant<false, PILOT>(acc, ring, rd, srcA, srcB, voffA, voffB, stepA, stepB, nrows, pa, pb);
 
   // epilogue: fp32 chunk sums -> fp64 G (atomics: other row chunks / the other half of Q01 add into the same tile).
   // Tile (ti, tj) owns rows 4 trow + ti and columns 4 (lane & 31) + tj of the quadrant.
@@ -976,6 +999,9 @@ bool launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
   // Row-chunk length: minimise (rounds of workgroups over the CUs) x (rows per workgroup + fixed cost).
   // Every workgroup pays ~45 us to flush its tile (~210 rows of MFMA time) plus the pipeline prologue,
   // and a grid that overshoots a multiple of the CU count by a few workgroups wastes a whole round.
+  // fp32 chunks are whole ring periods of the FIFO kernel (32 rows): its pilot-shifted form must not see zero-filled
+  // rows inside a chunk (they would enter as 0 - p), only the launch's last chunk may be ragged
+  const int64_t gran = (is32 && fast) ? FB * FR : BK;
   int64_t rows_per_wg;
   {
     const int64_t kmin = std::max<int64_t>(1, (n + max_rows - 1) / max_rows);
@@ -983,7 +1009,7 @@ bool launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
     double best = 1e300;
     int64_t best_k = kmin;
     for (int64_t ks = kmin; ks <= kmax; ++ks) {
-      const int64_t rows = ((n + ks - 1) / ks + BK - 1) / BK * BK;
+      const int64_t rows = ((n + ks - 1) / ks + gran - 1) / gran * gran;
       const bool big = int64_t(ntiles) * ks >= 16 * int64_t(ncu);
       int64_t rounds;
       double penalty = 1.0;
@@ -993,7 +1019,7 @@ bool launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
       const double cost = penalty * double(rounds) * double(rows + 320);
       if (cost < best) { best = cost; best_k = ks; }
     }
-    rows_per_wg = ((n + best_k - 1) / best_k + BK - 1) / BK * BK;
+    rows_per_wg = ((n + best_k - 1) / best_k + gran - 1) / gran * gran;
   }
   const int64_t ksplit = (n + rows_per_wg - 1) / rows_per_wg;
   // XCD-aware slicing needs many workgroups per XCD to stay balanced; small grids keep the plain order
@@ -1058,25 +1084,41 @@ bool launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
 
   if (time_it) CCZ_HIP(hipEventRecord(im->ev[0], st));
   static const int impl_sel = [] { const char* e = getenv("CCZ_GRAM_IMPL"); return e ? atoi(e) : 1; }();   // 1: wave-private FIFO (default), 0: register-staged shared tile
+  // pilot-shifted data on a chip-filling grid: the FIFO kernel with the subtraction at the fragment read, on the rows
+  // that form whole ring periods; the (< 32) rows left over go through the staged kernel, same pilot
+  static const int fifo_pilot_env = [] { const char* e = getenv("CCZ_GRAM_FIFO_PILOT"); return e ? atoi(e) : 1; }();
+  const int64_t n_main = n / (FB * FR) * (FB * FR);
+  const bool fifo_pilot = is32 && fast && impl_sel != 0 && use_pilot && fifo_pilot_env != 0 && sliced && n_main >= rows_per_wg;
   // staged fp32 kernel on a small grid: per-(chunk, tile) partial sums + one reduce instead of contended atomics
   float* partial = nullptr;
-  const bool staged32 = is32 && !(fast && impl_sel != 0 && !use_pilot);
+  const bool staged32 = is32 && !(fast && impl_sel != 0 && !use_pilot) && !fifo_pilot;
   if (staged32 && ksplit >= 2 && !sliced) {
     static const int64_t partial_cap = [] { const char* e = getenv("CCZ_GRAM_PARTIAL_MB"); return (e ? atoll(e) : 192LL) << 20; }();
     const int64_t bytes = ksplit * int64_t(ntiles) * T32 * T32 * 4;
     if (bytes <= partial_cap) partial = static_cast<float*>(dev_alloc(c, size_t(bytes)));
   }
   if (is32) {
-    if (fast && impl_sel != 0 && !use_pilot) {
+    if (fifo_pilot) {
+      const size_t fifo_bytes = size_t(4) * FR * FSLOT;
+      CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_f32_fifo<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(fifo_bytes)));
+      hipLaunchKernelGGL(k_gram_f32_fifo<true>, dim3((unsigned)nblocks), dim3(256), fifo_bytes, st, d_tiles, ntiles, per_xcd, ksplit, n_main,
+                         rows_per_wg, G, D, pilot);
+      if (n_main < n) {
+        CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_f32<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
+        hipLaunchKernelGGL(k_gram_f32<true>, dim3((unsigned)ntiles), dim3(256), lds_bytes, st, d_tiles, ntiles, 0, int64_t(1), n, int64_t(FB * FR), G, D,
+                           pilot, static_cast<float*>(nullptr), n_main);
+      }
+    } else if (fast && impl_sel != 0 && !use_pilot) {
       const size_t fifo_bytes = size_t(4) * FR * FSLOT;   // 128 KiB: four wave-private rings
-      CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_f32_fifo), hipFuncAttributeMaxDynamicSharedMemorySize, int(fifo_bytes)));
-      hipLaunchKernelGGL(k_gram_f32_fifo, dim3((unsigned)nblocks), dim3(256), fifo_bytes, st, d_tiles, ntiles, per_xcd, ksplit, n, rows_per_wg, G, D);
+      CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_f32_fifo<false>), hipFuncAttributeMaxDynamicSharedMemorySize, int(fifo_bytes)));
+      hipLaunchKernelGGL(k_gram_f32_fifo<false>, dim3((unsigned)nblocks), dim3(256), fifo_bytes, st, d_tiles, ntiles, per_xcd, ksplit, n, rows_per_wg, G, D,
+                         static_cast<const float*>(nullptr));
     } else if (fast) {
       CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_f32<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
-      hipLaunchKernelGGL(k_gram_f32<true>, dim3((unsigned)nblocks), dim3(256), lds_bytes, st, d_tiles, ntiles, per_xcd, ksplit, n, rows_per_wg, G, D, pilot, partial);
+      hipLaunchKernelGGL(k_gram_f32<true>, dim3((unsigned)nblocks), dim3(256), lds_bytes, st, d_tiles, ntiles, per_xcd, ksplit, n, rows_per_wg, G, D, pilot, partial, int64_t(0));
     } else {
       CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_f32<false>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
-      hipLaunchKernelGGL(k_gram_f32<false>, dim3((unsigned)nblocks), dim3(256), lds_bytes, st, d_tiles, ntiles, per_xcd, ksplit, n, rows_per_wg, G, D, pilot, partial);
+      hipLaunchKernelGGL(k_gram_f32<false>, dim3((unsigned)nblocks), dim3(256), lds_bytes, st, d_tiles, ntiles, per_xcd, ksplit, n, rows_per_wg, G, D, pilot, partial, int64_t(0));
     }
   } else {
     static const int impl64 = [] { const char* e = getenv("CCZ_GRAM64_IMPL"); return e ? atoi(e) : 1; }();   // 1: FIFO, 0: staged

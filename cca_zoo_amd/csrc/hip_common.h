@@ -58,6 +58,7 @@ struct Impl {
   int* loss_status_dev = nullptr;   // device view of the same words
   // hand-over events between a caller's stream and the handle's stream (ccz_stream_acquire / ccz_stream_release)
   hipEvent_t xs_ev[2] = {nullptr, nullptr};
+  bool adopted = false;             // c->stream is a caller's stream (ccz_stream_adopt) until the next acquire
 };
 
 inline Impl* impl(ccz_ctx* c) { return static_cast<Impl*>(c->impl); }

