@@ -73,6 +73,9 @@ SIGNATURES = {
     "ccz_moments_symmetrize": (_int, [_vp, _vp, _i64]),
     "ccz_moments_pack": (_int, [_vp, _vp, _i64, _vp]),
     "ccz_moments_unpack": (_int, [_vp, _vp, _i64, _vp]),
+    "ccz_moments_pack_blocks": (_int, [_vp, _vp, _i64, _pi64, _int, _vp, _int]),
+    "ccz_moments_unpack_blocks": (_int, [_vp, _vp, _i64, _pi64, _int, _vp, _int, _vp]),
+    "ccz_solve_defer": (_int, [_vp, _vp]),
     "ccz_moments_last_ms": (_int, [_vp, _pdbl, _pdbl]),
     "ccz_moments_last_pilot": (_int, [_vp, _pint]),
     "ccz_rcca_solve": (_int, [_vp, _vp, _i64, _pi64, _pdbl, _int, _int, _vp, _vp, _vp, _pint]),
@@ -287,6 +290,22 @@ class Handle:
 
     def moments_unpack(self, packed_ptr, D, moments_ptr):
         self.check(self.lib.ccz_moments_unpack(self._h, _ptr(packed_ptr), int(D), _ptr(moments_ptr)))
+
+    HEAD, TAIL, BOTH = 1, 2, 3
+
+    def moments_pack_blocks(self, moments_ptr, D, dims, packed_ptr, which=3):
+        """moments -> blocks layout ``[diag-block triangles | colsum | n slot || off-diagonal blocks]`` (ccz.h)."""
+        da = (C.c_int64 * len(dims))(*[int(d) for d in dims])
+        self.check(self.lib.ccz_moments_pack_blocks(self._h, _ptr(moments_ptr), int(D), da, len(dims), _ptr(packed_ptr), int(which)))
+
+    def moments_unpack_blocks(self, packed_ptr, D, dims, moments_ptr, which=3, on_stream=None):
+        da = (C.c_int64 * len(dims))(*[int(d) for d in dims])
+        self.check(self.lib.ccz_moments_unpack_blocks(self._h, _ptr(packed_ptr), int(D), da, len(dims), _ptr(moments_ptr), int(which),
+                                                      C.c_void_p(int(on_stream)) if on_stream else None))
+
+    def solve_defer(self, event_ptr):
+        """The next ``*_solve`` waits (on the device) for this hipEvent before reading off-diagonal moment blocks."""
+        self.check(self.lib.ccz_solve_defer(self._h, C.c_void_p(int(event_ptr)) if event_ptr else None))
 
     def moments_axpby(self, D, alpha, x_ptr, beta, y_ptr):
         """y <- alpha x + beta y over two moment buffers (moments are additive over disjoint row sets)."""

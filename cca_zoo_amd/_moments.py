@@ -46,7 +46,40 @@ def _common_float(views):
     return "f32" if all(k == "f32" for k in kinds) else "f64"
 
 
-def compute_moments(views, handle=None):
+#: reusable exchange buffers / side streams of the sharded path, keyed by (device, number of doubles)
+_EXCHANGE = {}
+
+
+def _exchange_buffer(dev, count):
+    """The packed moments travel in ONE buffer per (device, size), kept for the life of the process: no second
+    D^2-sized allocation per fit (it is 1 GB at D = 16384)."""
+    import torch
+
+    key = (str(dev), int(count))
+    buf = _EXCHANGE.get(key)
+    if buf is None:
+        for k in [k for k in _EXCHANGE if k[0] == str(dev) and not isinstance(_EXCHANGE[k], torch.cuda.Stream)]:
+            del _EXCHANGE[k]                                    # a different problem size: let the old buffer go
+        buf = _EXCHANGE[key] = torch.empty(int(count), dtype=torch.float64, device=dev)
+    return buf
+
+
+def _side_stream(dev):
+    import torch
+
+    key = (str(dev), "stream")
+    st = _EXCHANGE.get(key)
+    if st is None:
+        st = _EXCHANGE[key] = torch.cuda.Stream(device=dev)
+    return st
+
+
+def compute_moments(views, handle=None, defer_offdiag=False):
+    """``defer_offdiag`` (the estimators' ``fit`` inside ``row_sharded()``): the exchange is issued in two parts --
+    diagonal blocks + column sums + row count first, the off-diagonal blocks second -- and this function returns as soon
+    as the FIRST part has arrived; the second is unpacked on a side stream and ``ccz_solve_defer`` makes the next
+    ``ccz_*_solve`` wait for it on the device right before it reads an off-diagonal block, i.e. after the Cholesky
+    chain of the diagonal blocks.  Consumers that read the moments themselves must leave it off."""
     h = handle or _backend.handle_for(views)
     n = int(views[0].shape[0])
     dims = [int(v.shape[1]) for v in views]
@@ -57,6 +90,7 @@ def compute_moments(views, handle=None):
         raise ValueError("views must be all host arrays or all CUDA tensors")
     keep = []
     sharded = _dist.is_sharded()
+    stream_ptr = 0
     if on_device or sharded:
         import torch
 
@@ -94,21 +128,48 @@ def compute_moments(views, handle=None):
     LAST["allreduce_ms"] = 0.0
     n_total = n
     if sharded:
-        # the one collective of the path: packed upper triangle + column sums + row count
+        # the one exchange step of the path, in two parts: [diag-block triangles | column sums | row count] and
+        # [off-diagonal blocks] (ccz.h "blocks layout") -- D (D + 1) / 2 + D + 1 doubles in all, as the plain packed form
         import torch
+        import torch.distributed as dist
 
-        npk = D * (D + 1) // 2 + D
-        packed = torch.empty(npk + 1, dtype=torch.float64, device=mom_t.device)
-        h.moments_pack(mom_ptr, D, packed.data_ptr())
-        if on_device:
+        group = _dist.active_group()
+        n_head = sum(d * (d + 1) // 2 for d in dims) + D + 1
+        n_tail = D * (D + 1) // 2 + D + 1 - n_head
+        cuda = mom_t.is_cuda
+        packed = _exchange_buffer(mom_t.device, n_head + n_tail) if cuda else torch.empty(n_head + n_tail, dtype=torch.float64)
+        h.moments_pack_blocks(mom_ptr, D, dims, packed.data_ptr(), h.BOTH)
+        if cuda:
             h.release(stream_ptr)                        # the collective's stream follows libccz's on the device
         else:
             h.sync()
-        packed[npk:].fill_(float(n))                     # the row count rides in the tail slot of the same buffer
+        head, tail = packed[:n_head], packed[n_head:]
+        head[-1:].fill_(float(n))                        # the row count rides in the last slot of the head
         t_ar = time.perf_counter()
-        n_total = _dist.allreduce_moments(packed, _dist.active_group())     # in place; its .item() is the sync
+        w_head = dist.all_reduce(head, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        w_tail = dist.all_reduce(tail, op=dist.ReduceOp.SUM, group=group, async_op=True) if n_tail > 0 else None
+        w_head.wait()
+        n_total = int(round(float(head[-1].item())))     # the one host synchronisation: n is a host argument of the solves
         LAST["allreduce_ms"] = (time.perf_counter() - t_ar) * 1e3
-        h.moments_unpack(packed.data_ptr(), D, mom_ptr)
+        if cuda:
+            h.acquire(stream_ptr)
+        h.moments_unpack_blocks(packed.data_ptr(), D, dims, mom_ptr, h.HEAD)
+        if w_tail is not None:
+            if cuda and defer_offdiag:
+                side = _side_stream(mom_t.device)
+                side.wait_stream(torch.cuda.current_stream(mom_t.device))
+                with torch.cuda.stream(side):
+                    w_tail.wait()                        # the side stream waits for the collective, the host does not
+                h.moments_unpack_blocks(packed.data_ptr(), D, dims, mom_ptr, h.TAIL, on_stream=side.cuda_stream)
+                ev = torch.cuda.Event()
+                ev.record(side)
+                h.solve_defer(ev.cuda_event)
+                keep.append(ev)
+            else:
+                w_tail.wait()
+                if cuda:
+                    h.acquire(stream_ptr)
+                h.moments_unpack_blocks(packed.data_ptr(), D, dims, mom_ptr, h.TAIL)
         keep.append(packed)
     # non-finite inputs (NaN / inf anywhere in a column) surface in that column's sum: the reference's
     # check_array(force_all_finite) ValueError without a host pass over the data

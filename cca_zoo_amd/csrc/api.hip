@@ -109,6 +109,8 @@ int ccz_destroy(ccz_handle h) {
     if (im->aux_stream) (void)hipStreamDestroy(im->aux_stream);
     for (int i = 0; i < 2; ++i) if (im->xs_ev[i]) (void)hipEventDestroy(im->xs_ev[i]);
     if (im->loss_status) (void)hipHostFree(im->loss_status);
+    if (im->wait_ev) (void)hipEventDestroy(im->wait_ev);
+    if (im->d2h_pin) (void)hipHostFree(im->d2h_pin);
     (void)hipFree(im->d_flag);
     (void)hipFree(im->d_small);
     delete im;
@@ -254,6 +256,56 @@ int ccz_moments_unpack(ccz_handle h, const double* packed_dev, int64_t D, double
     unpack_upper(h, D, packed_dev, moments_dev, D);
     d2d(h, moments_dev + D * D, packed_dev + D * (D + 1) / 2, size_t(D) * 8);
   })
+}
+
+// blocks layout of the sharded exchange:  [ upper triangles of the diagonal blocks C_11 .. C_mm | colsum (D) | 1 spare
+// slot (the caller's row count) ]  then  [ the off-diagonal blocks (i < j), each d_i x d_j row-major ]
+static void moments_blocks(ccz_ctx* c, bool pack, double* mom, int64_t D, const int64_t* dims, int m, double* packed, int which,
+                           void* on_stream) {
+  if (!mom || !packed || !dims || m < 1 || D < 1) fail(CCZ_EINVAL, "moments blocks: bad argument");
+  if (which < 1 || which > 3) fail(CCZ_EINVAL, "moments blocks: which must be 1 (head), 2 (tail) or 3 (both)");
+  std::vector<int64_t> off(m + 1, 0);
+  for (int i = 0; i < m; ++i) {
+    if (dims[i] < 1) fail(CCZ_EINVAL, "moments blocks: view %d has no features", i);
+    off[i + 1] = off[i] + dims[i];
+  }
+  if (off[m] != D) fail(CCZ_EINVAL, "moments blocks: dims do not sum to D");
+  void* const prev = c->stream;
+  if (on_stream) c->stream = on_stream;              // plain kernels and copies only: no pooled scratch is involved
+  try {
+    int64_t pos = 0;
+    for (int i = 0; i < m; ++i) {
+      double* blk = mom + off[i] * D + off[i];
+      if (which & 1) { if (pack) pack_upper(c, dims[i], blk, D, packed + pos); else unpack_upper(c, dims[i], packed + pos, blk, D); }
+      pos += dims[i] * (dims[i] + 1) / 2;
+    }
+    if (which & 1) { if (pack) d2d(c, packed + pos, mom + D * D, size_t(D) * 8); else d2d(c, mom + D * D, packed + pos, size_t(D) * 8); }
+    pos += D + 1;
+    for (int i = 0; i < m; ++i)
+      for (int j = i + 1; j < m; ++j) {
+        double* blk = mom + off[i] * D + off[j];
+        if (which & 2) { if (pack) copy2d(c, dims[i], dims[j], blk, D, packed + pos, dims[j]); else copy2d(c, dims[i], dims[j], packed + pos, dims[j], blk, D); }
+        pos += dims[i] * dims[j];
+      }
+  } catch (...) {
+    c->stream = prev;
+    throw;
+  }
+  c->stream = prev;
+}
+
+int ccz_moments_pack_blocks(ccz_handle h, const double* moments_dev, int64_t D, const int64_t* dims, int n_views, double* packed_dev,
+                            int which) {
+  CCZ_GUARD(h, moments_blocks(h, true, const_cast<double*>(moments_dev), D, dims, n_views, packed_dev, which, nullptr))
+}
+
+int ccz_moments_unpack_blocks(ccz_handle h, const double* packed_dev, int64_t D, const int64_t* dims, int n_views, double* moments_dev,
+                              int which, void* on_stream) {
+  CCZ_GUARD(h, moments_blocks(h, false, moments_dev, D, dims, n_views, const_cast<double*>(packed_dev), which, on_stream))
+}
+
+int ccz_solve_defer(ccz_handle h, void* event) {
+  CCZ_GUARD(h, impl(h)->deferred_event = event)
 }
 
 int ccz_moments_last_ms(ccz_handle h, double* gram_ms, double* colsum_ms) {

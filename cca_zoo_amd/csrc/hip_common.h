@@ -58,6 +58,11 @@ struct Impl {
   int* loss_status_dev = nullptr;   // device view of the same words
   // hand-over events between a caller's stream and the handle's stream (ccz_stream_acquire / ccz_stream_release)
   hipEvent_t xs_ev[2] = {nullptr, nullptr};
+  // polled waits (ops_hip.hip: wait_stream_short) and the pinned landing buffer of small device -> host copies
+  hipEvent_t wait_ev = nullptr;
+  void* d2h_pin = nullptr;
+  static constexpr size_t kD2hPinBytes = size_t(4) << 20;
+  void* deferred_event = nullptr;   // ccz_solve_defer: awaited by the next solve before it reads off-diagonal blocks
   bool adopted = false;             // c->stream is a caller's stream (ccz_stream_adopt) until the next acquire
 };
 

@@ -171,6 +171,12 @@ void row_dots(ccz_ctx* c, int64_t rows, int64_t cols, const double* A, int64_t l
 void gather_rows(ccz_ctx* c, int64_t rows, int64_t cols, const double* in, int64_t ldi,
                  const int64_t* perm_host, const double* scale_host, double* out, int64_t ldo);
 
+// The off-diagonal blocks of the moments may still be in flight (the second half of the sharded exchange): every
+// solve driver calls this right before its FIRST read of an off-diagonal block -- after the per-view factorizations,
+// which only need the diagonal blocks.  HIP backend: the handle's stream waits for the event registered with
+// ccz_solve_defer (once); host backend: nothing to wait for.
+void wait_deferred(ccz_ctx* c);
+
 // ---- measurement aid (CCZ_TRACE_PHASES=2) ------------------------------------------
 // trace_mark: note a phase boundary on the handle's stream WITHOUT synchronising (HIP backend: an event, a host
 // time stamp and a 20 us single-wave kernel that measures the shader clock); trace_flush: wait for the stream and

@@ -65,15 +65,21 @@ void dev_free(ccz_ctx* c, void* p) {
   (void)hipFree(p);
 }
 
-void h2d(ccz_ctx* c, void* dst, const void* src, size_t bytes) {
-  if (!bytes) return;
+static void h2d_blocking(ccz_ctx* c, void* dst, const void* src, size_t bytes) {
   CCZ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream(c)));
   CCZ_HIP(hipStreamSynchronize(stream(c)));  // src is pageable host memory owned by the caller
+}
+void h2d(ccz_ctx* c, void* dst, const void* src, size_t bytes) {
+  if (!bytes) return;
+  // small copies (shifts, Ritz values, permutations: the solver's steering data) ride through the pinned ring and do not
+  // make the host wait; the source may be reused as soon as this returns either way
+  if (bytes <= Impl::kSmallBytes) { h2d_small(c, dst, src, bytes); return; }
+  h2d_blocking(c, dst, src, bytes);
 }
 void h2d_small(ccz_ctx* c, void* dst, const void* src, size_t bytes) {
   if (!bytes) return;
   Impl* im = impl(c);
-  if (bytes > Impl::kSmallBytes) { h2d(c, dst, src, bytes); return; }
+  if (bytes > Impl::kSmallBytes) { h2d_blocking(c, dst, src, bytes); return; }
   // next slot of the ring whose previous copy has drained (a deep queue -- many enqueue-only calls behind a long
   // kernel -- must not make the host wait for the device: look for a free slot before blocking on the oldest one)
   int i = im->small_next;
@@ -89,7 +95,7 @@ void h2d_small(ccz_ctx* c, void* dst, const void* src, size_t bytes) {
         hipEventCreateWithFlags(&im->small_ev[i], hipEventDisableTiming) != hipSuccess) {
       (void)hipGetLastError();
       if (im->small_pin[i]) { (void)hipHostFree(im->small_pin[i]); im->small_pin[i] = nullptr; }
-      h2d(c, dst, src, bytes);
+      h2d_blocking(c, dst, src, bytes);
       return;
     }
   } else {
@@ -100,8 +106,62 @@ void h2d_small(ccz_ctx* c, void* dst, const void* src, size_t bytes) {
   CCZ_HIP(hipMemcpyAsync(dst, im->small_pin[i], bytes, hipMemcpyHostToDevice, stream(c)));
   CCZ_HIP(hipEventRecord(im->small_ev[i], stream(c)));
 }
+// ---- short host waits ---------------------------------------------------------------------------------------------
+// The solve is a chain of small launches with a handful of read-backs (pivot flags, residual norms, Ritz values).  A
+// BLOCKING wait (hipStreamSynchronize: the thread sleeps on the completion interrupt) was measured to return 10 - 30 ms
+// after the device had finished, in every OTHER fit of a back-to-back loop (DESIGN.md "the period-2 solve"): the device
+// time of the phase was unchanged, the host sat in the wait.  Waits that are expected to be short therefore POLL the
+// completion event (hipEventQuery) for up to `spin_ms` before they fall back to the blocking call.
+// CCZ_SPIN_WAIT_MS=0 restores the blocking waits.
+static double spin_budget_ms() {
+  static const double v = [] { const char* e = getenv("CCZ_SPIN_WAIT_MS"); return e ? atof(e) : 50.0; }();
+  return v;
+}
+struct WaitStats { double total_ms = 0.0, max_ms = 0.0; long count = 0, fell_back = 0; };
+static WaitStats& wait_stats() { static WaitStats w; return w; }
+
+static void wait_stream_short(ccz_ctx* c) {
+  Impl* im = impl(c);
+  hipStream_t st = stream(c);
+  const auto t0 = std::chrono::steady_clock::now();
+  const double budget = spin_budget_ms();
+  bool done = false;
+  if (budget > 0.0) {
+    if (!im->wait_ev) CCZ_HIP(hipEventCreateWithFlags(&im->wait_ev, hipEventDisableTiming));
+    CCZ_HIP(hipEventRecord(im->wait_ev, st));
+    for (;;) {
+      const hipError_t q = hipEventQuery(im->wait_ev);
+      if (q == hipSuccess) { done = true; break; }
+      if (q != hipErrorNotReady) { (void)hipGetLastError(); break; }
+      if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > budget) break;
+      __builtin_ia32_pause();
+    }
+  }
+  if (!done) { CCZ_HIP(hipStreamSynchronize(st)); ++wait_stats().fell_back; }
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  WaitStats& w = wait_stats();
+  w.total_ms += ms;
+  w.max_ms = std::max(w.max_ms, ms);
+  ++w.count;
+}
+
 void d2h(ccz_ctx* c, void* dst, const void* src, size_t bytes) {
   if (!bytes) return;
+  Impl* im = impl(c);
+  // small read-backs go through a pinned word buffer: the copy is then truly asynchronous (a pageable destination is
+  // staged by the runtime, which may block inside the call) and the wait below polls
+  if (bytes <= Impl::kD2hPinBytes && spin_budget_ms() > 0.0) {
+    if (!im->d2h_pin && hipHostMalloc(&im->d2h_pin, Impl::kD2hPinBytes, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      im->d2h_pin = nullptr;
+    }
+    if (im->d2h_pin) {
+      CCZ_HIP(hipMemcpyAsync(im->d2h_pin, src, bytes, hipMemcpyDeviceToHost, stream(c)));
+      wait_stream_short(c);
+      std::memcpy(dst, im->d2h_pin, bytes);
+      return;
+    }
+  }
   CCZ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream(c)));
   CCZ_HIP(hipStreamSynchronize(stream(c)));
 }
@@ -114,6 +174,17 @@ void zero(ccz_ctx* c, void* dst, size_t bytes) {
   CCZ_HIP(hipMemsetAsync(dst, 0, bytes, stream(c)));
 }
 void sync(ccz_ctx* c) { CCZ_HIP(hipStreamSynchronize(stream(c))); }
+void sync_short(ccz_ctx* c) { wait_stream_short(c); }
+void wait_deferred(ccz_ctx* c) {
+  Impl* im = impl(c);
+  if (!im->deferred_event) return;
+  hipEvent_t ev = static_cast<hipEvent_t>(im->deferred_event);
+  im->deferred_event = nullptr;
+  if (hipStreamWaitEvent(stream(c), ev, 0) != hipSuccess) {          // (an event destroyed meanwhile has nothing pending)
+    (void)hipGetLastError();
+    CCZ_HIP(hipDeviceSynchronize());
+  }
+}
 
 // ---- phase tracing without synchronisation (ops.h: trace_mark / trace_flush) ----
 __global__ void k_clock_probe(long long* out) {
@@ -160,6 +231,10 @@ void trace_flush(ccz_ctx* c, const char* what) {
              ts.marks[i].host_ms - (i > 0 ? ts.marks[i - 1].host_ms : 0.0), mhz);
     line += buf;
   }
+  WaitStats& w = wait_stats();
+  snprintf(buf, sizeof(buf), " || host waits: %ld, total %.2f ms, longest %.2f ms, %ld blocking", w.count, w.total_ms, w.max_ms, w.fell_back);
+  line += buf;
+  w = WaitStats{};
   fprintf(stderr, "[ccz] %s phases (ms; each phase includes a 20 us probe)%s\n", what, line.c_str());
   for (auto& m : ts.marks) ts.spare.push_back(m.ev);
   ts.marks.clear();

@@ -644,11 +644,13 @@ static void rcca_solve_impl(ccz_ctx* c, const double* mom, int64_t n, const int6
   add_diag(c, d1, Rv[0], d1, cc[0]);
   cov_block(c, G, D, s, n, ctr, (1.0 - cc[1]) * inv, d1, d2, d1, d2, Rv[1], d2);
   add_diag(c, d2, Rv[1], d2, cc[1]);
-  cov_block(c, G, D, s, n, ctr, inv, 0, d1, d1, d2, M12, d2);
   pt.mark("cov");
 
+  // the factorizations need the diagonal blocks only: under the sharded exchange the cross block may still be in flight
   std::vector<Whitener> Fv = make_whiteners(c, Rv, {d1, d2}, true);
   pt.mark("factor");
+  wait_deferred(c);
+  cov_block(c, G, D, s, n, ctr, inv, 0, d1, d1, d2, M12, d2);
   Whitener& F1 = Fv[0];
   Whitener& F2 = Fv[1];
   const int64_t r1 = F1.r, r2 = F2.r;
@@ -719,6 +721,7 @@ static void mcca_solve_impl(ccz_ctx* c, const double* mom, int64_t n, const int6
   if (shift > 0.0)
     for (int i = 0; i < m; ++i) add_diag(c, dims[i], R[i], dims[i], shift);
   std::vector<Whitener> F = make_whiteners(c, R, dimv, false);
+  wait_deferred(c);
   // S = L^-1 (C - blockdiag C) L^-T,  zero diagonal blocks
   DBuf S(c, D * D);
   fill2d(c, D, D, S, D, 0.0);
@@ -797,6 +800,7 @@ static void gcca_solve_impl(ccz_ctx* c, const double* mom, int64_t n, const int6
       if (lo[i] < eps) add_diag(c, dims[i], R[i], dims[i], eps - lo[i]);   // per-view floor (_gcca.py:102-104)
   }
   std::vector<Whitener> F = make_whiteners(c, R, dimv, false);
+  wait_deferred(c);
   // Z[:, j] = sqrt(mu_j) Gx[:, j] L_j^-T      (Gx: second moments of the data as fitted)
   DBuf Z(c, D * D), K(c, D * D);
   for (int j = 0; j < m; ++j) {

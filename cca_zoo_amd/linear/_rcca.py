@@ -57,7 +57,7 @@ class rCCA(BaseModel):
         self._check_n_views()
         h = _backend.handle_for(views_)
         t0 = time.perf_counter()
-        mom, keep, n_total, dims, kind = compute_moments(views_, h)
+        mom, keep, n_total, dims, kind = compute_moments(views_, h, defer_offdiag=True)
         t1 = time.perf_counter()
         self.n_samples_ = int(n_total)            # inside row_sharded(): the global row count
         self._fit_moments(h, mom, n_total, dims, kind)

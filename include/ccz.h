@@ -123,6 +123,20 @@ CCZ_API int ccz_moments_symmetrize(ccz_handle h, double* moments_dev, int64_t D)
  * unpack: packed -> upper triangle of moments (+ colsum); the lower triangle is left untouched. */
 CCZ_API int ccz_moments_pack(ccz_handle h, const double* moments_dev, int64_t D, double* packed_dev);
 CCZ_API int ccz_moments_unpack(ccz_handle h, const double* packed_dev, int64_t D, double* moments_dev);
+/* The same exchange in TWO parts, ordered so that the solve can start before the exchange has finished (SURVEY.md 8(e):
+ * the per-view factorizations need the diagonal blocks only).  Blocks layout, doubles:
+ *   head = [ upper triangle of C_11 | .. | upper triangle of C_mm | colsum (D) | 1 spare slot for the caller's row count ]
+ *   tail = [ C_12 | C_13 | .. | C_(m-1)m ]   (each d_i x d_j, row-major)
+ *   packed = [ head | tail ],  sum d_i (d_i + 1) / 2 + D + 1 + sum_{i<j} d_i d_j  =  D (D + 1) / 2 + D + 1 doubles.
+ * which: 1 = head, 2 = tail, 3 = both.  unpack's on_stream (hipStream_t as void*, NULL = the handle's stream) lets the
+ * tail be unpacked on the stream the collective completes on; ccz_solve_defer(h, event) then makes the NEXT
+ * ccz_{rcca,mcca,gcca}_solve wait for `event` (hipEvent_t as void*, recorded after that unpack) on the device right
+ * before its first read of an off-diagonal block -- i.e. after the Cholesky chain of the diagonal blocks. */
+CCZ_API int ccz_moments_pack_blocks(ccz_handle h, const double* moments_dev, int64_t D, const int64_t* dims, int n_views,
+                                    double* packed_dev, int which);
+CCZ_API int ccz_moments_unpack_blocks(ccz_handle h, const double* packed_dev, int64_t D, const int64_t* dims, int n_views,
+                                      double* moments_dev, int which, void* on_stream);
+CCZ_API int ccz_solve_defer(ccz_handle h, void* event);
 /* Moments are additive over disjoint row sets: y <- alpha x + beta y over the D*D + D doubles of two
  * moment buffers.  With (alpha, beta) = (-1, 1) it turns the moments of all rows into those of the rows
  * outside a cross-validation fold -- the Gram reuse behind cca_zoo_amd.model_selection.GridSearchCV

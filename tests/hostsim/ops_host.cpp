@@ -29,6 +29,7 @@ void d2h(ccz_ctx*, void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
 void d2d(ccz_ctx*, void* d, const void* s, size_t n) { std::memmove(d, s, n); }
 void zero(ccz_ctx*, void* d, size_t n) { std::memset(d, 0, n); }
 void sync(ccz_ctx*) {}
+void wait_deferred(ccz_ctx*) {}
 void trace_mark(ccz_ctx*, const char*) {}
 void trace_flush(ccz_ctx*, const char*) {}
 void activate(ccz_ctx*) {}
@@ -408,6 +409,33 @@ int ccz_moments_unpack(ccz_handle, const double* packed, int64_t D, double* mom)
   std::memcpy(mom + D * D, packed + o, size_t(D) * 8);
   return CCZ_OK;
 }
+// blocks layout (ccz.h): [diag-block upper triangles | colsum | 1 spare slot || off-diagonal blocks]
+static int blocks_copy(bool pack, double* mom, int64_t D, const int64_t* dims, int m, double* packed, int which) {
+  if (!mom || !packed || !dims || which < 1 || which > 3) return CCZ_EINVAL;
+  std::vector<int64_t> off(m + 1, 0);
+  for (int i = 0; i < m; ++i) off[i + 1] = off[i] + dims[i];
+  if (off[m] != D) return CCZ_EINVAL;
+  int64_t pos = 0;
+  for (int i = 0; i < m; ++i)
+    for (int64_t r = 0; r < dims[i]; ++r)
+      for (int64_t q = r; q < dims[i]; ++q, ++pos)
+        if (which & 1) { double& g = mom[(off[i] + r) * D + off[i] + q]; if (pack) packed[pos] = g; else g = packed[pos]; }
+  if (which & 1) { if (pack) std::memcpy(packed + pos, mom + D * D, size_t(D) * 8); else std::memcpy(mom + D * D, packed + pos, size_t(D) * 8); }
+  pos += D + 1;
+  for (int i = 0; i < m; ++i)
+    for (int j = i + 1; j < m; ++j)
+      for (int64_t r = 0; r < dims[i]; ++r)
+        for (int64_t q = 0; q < dims[j]; ++q, ++pos)
+          if (which & 2) { double& g = mom[(off[i] + r) * D + off[j] + q]; if (pack) packed[pos] = g; else g = packed[pos]; }
+  return CCZ_OK;
+}
+int ccz_moments_pack_blocks(ccz_handle, const double* mom, int64_t D, const int64_t* dims, int m, double* packed, int which) {
+  return blocks_copy(true, const_cast<double*>(mom), D, dims, m, packed, which);
+}
+int ccz_moments_unpack_blocks(ccz_handle, const double* packed, int64_t D, const int64_t* dims, int m, double* mom, int which, void*) {
+  return blocks_copy(false, mom, D, dims, m, const_cast<double*>(packed), which);
+}
+int ccz_solve_defer(ccz_handle, void*) { return CCZ_OK; }
 int ccz_transform(ccz_handle h, int dtype, const void* X, int64_t n, int64_t d, int64_t ld, const double* mean,
                   const double* W, int64_t k, void* out, int64_t ldo) {
   if (!h || !X || !W || !out) return CCZ_EINVAL;

@@ -208,10 +208,12 @@ def test_seam_functions(H):
 
 
 @pytest.mark.parametrize("n,d,k,ld_extra,ldo_extra", [(9000, 272, 64, 0, 0), (8200, 256, 7, 8, 1), (20000, 1024, 32, 0, 0),
-                                                       (8192, 512, 1, 4, 0), (300, 40, 5, 0, 0)])
+                                                       (8192, 512, 1, 4, 0), (300, 40, 5, 0, 0),
+                                                       (12345, 2048, 64, 0, 0), (8193, 320, 17, 4, 3), (70001, 4096, 48, 0, 0)])
 def test_transform_f32_projection_kernel(H, n, d, k, ld_extra, ldo_extra):
-    """(X - mean) W for fp32 samples: the 256 x 64-tile projection kernel (n >= 8192, d % 16 == 0, k <= 64), ragged
-    row tail, padded output columns, strided input / output -- and the generic path for the small case."""
+    """(X - mean) W for fp32 samples: the projection kernels (n >= 8192, k <= 64: the wave-private FIFO kernel for
+    d % 32 == 0, the 256 x 64 staged tile for d % 16 == 0), ragged row tail, padded output columns, strided input /
+    output -- and the generic path for the small case."""
     from cca_zoo_amd import _backend
 
     rng = np.random.default_rng(n + d + k)
