@@ -311,7 +311,12 @@ __global__ __launch_bounds__(256, 1) void k_gemm_f32_nn_fifo(int64_t M, int64_t 
 // ---------------------------------------------------------------------------------------------------
 // Projection shape: N <= 64 outputs per sample (transform / score: (X - mean) W with k <= 64 directions).
 // 2 n d k flop against n d 4 bytes: at k = 64 the MFMA time (3.3 ms per 1e6 x 4096 view) and the HBM time
-// (2.7 ms at 6 TB/s) are about equal, so the kernel has to keep both busy.  256 rows x 64 columns per
+// (2.7 ms at 6 TB/s) are about equal, so the kernel has to keep both busy.  Measured 5.3 ms (95 TF, 3.0 TB/s) for any
+// k <= 64 and any d.  Round 3 tried the wave-private LDS-DMA FIFO pipeline of K1 on this shape (128 rows x 64 columns
+// per wave, W re-packed so that a lane's B operands are two 16-byte pieces, 6 DMA + 6 ds_read_b128 per 32 MFMAs): 5.5 ms,
+// i.e. no gain, at d = 512 as well as at d = 4096 -- so neither the staging nor the row stride is what holds this shape at
+// 60 % of the MFMA rate (two column tiles per A fragment instead of K1's four: every MFMA pair needs a fresh A
+// operand).  The attempt is in the history (commit "FIFO projection kernel for k <= 64"), not in the tree.  256 rows x 64 columns per
 // workgroup, 4 waves x (64 x 64) = 2 x 2 MFMA tiles each, the same LDS-transposed A staging as above,
 // B (converted once to fp32 and zero-padded to 64 columns) staged as [k][64]; 40 KiB of LDS -> three
 // workgroups per CU hide each other's staging.  Fragments are 8-byte reads (two consecutive m / n feed the
@@ -419,164 +424,6 @@ __global__ __launch_bounds__(256, 3) void k_gemm_f32_nn_tall(int64_t M, int64_t 
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// The projection shape on the wave-private LDS-DMA FIFO (the K1 / k_gemm_f32_nn_fifo pipeline), N <= 64:
-//   * a wave owns 128 sample rows (4 row tiles of 32) and ALL 64 output columns (2 column tiles, strided ownership:
-//     column 2 (lane & 31) + tj), so its A stream is read exactly once and nothing is shared between waves: no barriers;
-//   * A fragment as in k_gemm_f32_nn_fifo: lane l loads A[32 ti + (l & 31)][k0 + 4 (l >> 5) .. + 3] as ONE 16-byte
-//     buffer_load ... lds and uses float t as the A operand of k-step t (k-step t multiplies k0 + t on lanes 0-31 and
-//     k0 + 4 + t on lanes 32-63);
-//   * B = W is small (K x 64) and is re-packed ONCE per call (k_pack_w_tall) so that the 8 floats a lane needs for the
-//     four k-steps of an 8-deep block -- W[k0 + 4 (l >> 5) + t][2 (l & 31) + tj], t = 0..3, tj = 0, 1 -- are two
-//     contiguous 16-byte pieces: 2 DMA instructions per block, against 4 for A;
-//   * per 8-deep block: 6 buffer_load ... lds, 6 ds_read_b128, 32 MFMA 32x32x2 (K1: 4 + 4 per 32), ring of 4 slots of
-//     6 KiB per wave (96 KiB per workgroup, one wave per SIMD), counted s_waitcnt vmcnt only.
-// 2 n d k flop against n d 4 bytes: at k = 64 the MFMA time (3.3 ms per 1e6 x 4096 view at peak) exceeds the HBM time
-// (2.7 ms), below k ~ 48 the kernel is bound by the A stream.
-// ---------------------------------------------------------------------------------------------------
-constexpr int TFA = 4 * 1024;                 // A part of a slot: 4 row tiles x 1 KiB
-constexpr int TFSLOT = TFA + 2 * 1024;        // + the two 1 KiB pieces of packed W
-constexpr int TFR = 4;                        // ring slots per wave
-
-__device__ __forceinline__ void wait_vmcnt_10t() { asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
-__device__ __forceinline__ void wait_vmcnt_12t() { asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
-
-__device__ __forceinline__ void gemm_f32_nn_tall_fifo_body(int64_t M, int64_t N, int64_t K, float alpha, const float* __restrict__ A,
-                                                           int64_t lda, const float* __restrict__ Wp, float beta,
-                                                           float* __restrict__ C, int64_t ldc, const float* __restrict__ bias) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  typedef __attribute__((address_space(3))) void* lds_ptr;
-  char* ring = smem + wave * (TFR * TFSLOT);
-  const char* rd = ring + lane * 16;
-  const int64_t mw = int64_t(blockIdx.x) * 512 + wave * 128;        // first sample row of this wave
-  const int64_t rows_valid = min<int64_t>(128, M - mw);
-  if (rows_valid <= 0) return;                                      // (no barriers in this kernel)
-  const __amdgpu_buffer_rsrc_t srcA = make_rsrc(A + mw * lda, ((rows_valid - 1) * lda + K) * 4);
-  const __amdgpu_buffer_rsrc_t srcB = make_rsrc(Wp, K * 64 * 4);
-  int voffA[4];
-#pragma unroll
-  for (int ti = 0; ti < 4; ++ti) voffA[ti] = int(((32 * ti + (lane & 31)) * lda + 4 * (lane >> 5)) * 4);
-  const int voffB = lane * 16;
-  int soffA = 0, soffB = 0;
-
-  v16f32 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // prologue: blocks 0, 1, 2 -> slots 0, 1, 2 (6 DMA instructions each)
-#pragma unroll
-  for (int s = 0; s < 3; ++s) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(srcA, (lds_ptr)(ring + s * TFSLOT + u * 1024), 16, voffA[u], soffA, 0, 0);
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(srcB, (lds_ptr)(ring + s * TFSLOT + TFA + u * 1024), 16, voffB, soffB + u * 1024, 0, 0);
-    soffA += 32;
-    soffB += 2048;
-  }
-  wait_vmcnt_12t();                       // block 0 landed: blocks 1 and 2 (12 instructions) may stay in flight
-  v4f32 ab[2][4], bw[2][2];
-#pragma unroll
-  for (int ti = 0; ti < 4; ++ti) ab[0][ti] = *reinterpret_cast<const v4f32*>(rd + ti * 1024);
-  bw[0][0] = *reinterpret_cast<const v4f32*>(rd + TFA);
-  bw[0][1] = *reinterpret_cast<const v4f32*>(rd + TFA + 1024);
-
-  const int64_t nblk = K / 8;
-  for (int64_t b0 = 0; b0 < nblk; b0 += TFR) {        // one trip = the whole ring period: slots are static
-#pragma unroll
-    for (int bb = 0; bb < TFR; ++bb) {
-      const int cur = bb & 1, nxt = cur ^ 1;
-      const int nslot = (bb + 1) % TFR, wsl = (bb + 3) % TFR;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        // B operands of k-step t: floats (2 (t & 1), 2 (t & 1) + 1) of piece t >> 1
-        const v4f32 bq = bw[cur][t >> 1];
-        const float b0f = bq[2 * (t & 1)], b1f = bq[2 * (t & 1) + 1];
-        if (t == 3) {
-          // next block's fragments: newer than block b+1 are block b+2 (6) and the 4 instructions of b+3 issued so far
-          // (A tiles 0-2 and the first W piece; this k-step's own two follow below)
-          wait_vmcnt_10t();
-#pragma unroll
-          for (int ti = 0; ti < 4; ++ti) ab[nxt][ti] = *reinterpret_cast<const v4f32*>(rd + nslot * TFSLOT + ti * 1024);
-          bw[nxt][0] = *reinterpret_cast<const v4f32*>(rd + nslot * TFSLOT + TFA);
-          bw[nxt][1] = *reinterpret_cast<const v4f32*>(rd + nslot * TFSLOT + TFA + 1024);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[cur][0][t], b0f, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[cur][0][t], b1f, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[cur][1][t], b0f, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[cur][1][t], b1f, acc[1][1], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        // -- gap: DMA of block b+3 (A tile t; the two W pieces ride with k-steps 2 and 3)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(srcA, (lds_ptr)(ring + wsl * TFSLOT + t * 1024), 16, voffA[t], soffA, 0, 0);
-        if (t == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(srcB, (lds_ptr)(ring + wsl * TFSLOT + TFA), 16, voffB, soffB, 0, 0);
-        if (t == 3) {
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(srcB, (lds_ptr)(ring + wsl * TFSLOT + TFA + 1024), 16, voffB, soffB + 1024, 0, 0);
-          soffA += 32;
-          soffB += 2048;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[cur][2][t], b0f, acc[2][0], 0, 0, 0);
-        acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[cur][2][t], b1f, acc[2][1], 0, 0, 0);
-        acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[cur][3][t], b0f, acc[3][0], 0, 0, 0);
-        acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[cur][3][t], b1f, acc[3][1], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-  }
-  wait_vmcnt_0();
-
-  // epilogue: row tile ti owns rows 32 ti + trow, the lane two consecutive columns
-  const int nb = 2 * (lane & 31);
-  v2f32 b2 = {0.f, 0.f};
-  if (bias) b2 = *reinterpret_cast<const v2f32*>(bias + nb);
-  const bool pair_ok = (ldc & 1) == 0 && nb + 1 < N;
-#pragma unroll
-  for (int ti = 0; ti < 4; ++ti)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int trow = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      const int64_t m = mw + 32 * ti + trow;
-      if (m >= M || nb >= N) continue;
-      float* cp = C + m * ldc + nb;
-      v2f32 v = {acc[ti][0][r], acc[ti][1][r]};
-      v = (v - b2) * alpha;
-      if (pair_ok) {
-        if (beta != 0.f) v += beta * *reinterpret_cast<const v2f32*>(cp);
-        *reinterpret_cast<v2f32*>(cp) = v;
-      } else {
-        cp[0] = beta != 0.f ? v[0] + beta * cp[0] : v[0];
-        if (nb + 1 < N) cp[1] = beta != 0.f ? v[1] + beta * cp[1] : v[1];
-      }
-    }
-}
-
-__global__ __launch_bounds__(256, 1) void k_gemm_f32_nn_tall_fifo(int64_t M, int64_t N, int64_t K, float alpha, const float* __restrict__ A,
-                                                                  int64_t lda, const float* __restrict__ Wp, float beta,
-                                                                  float* __restrict__ C, int64_t ldc, const float* __restrict__ bias) {
-  gemm_f32_nn_tall_fifo_body(M, N, K, alpha, A, lda, Wp, beta, C, ldc, bias);
-}
-
-// W (K x N float64, ld ldb) -> the per-lane packed fp32 form of k_gemm_f32_nn_tall_fifo: block kb (8 k) is 2 KiB =
-// [piece 0: lanes' (t = 0, 1) | piece 1: lanes' (t = 2, 3)], a lane's piece = {W[k][2c], W[k][2c+1]} for its two t
-__global__ void k_pack_w_tall(int64_t K, int64_t N, const double* __restrict__ B, int64_t ldb, float* __restrict__ Wp) {
-  const int64_t total = K * 64;
-  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += int64_t(gridDim.x) * blockDim.x) {
-    const int64_t kb = i >> 9;
-    const int w = int(i & 511), u = w >> 8, lane = (w >> 2) & 63, e = w & 3;
-    const int t = 2 * u + (e >> 1), tj = e & 1, h = lane >> 5, c = lane & 31;
-    const int64_t k = kb * 8 + 4 * h + t, col = 2 * c + tj;
-    Wp[i] = col < N ? float(B[k * ldb + col]) : 0.f;
-  }
-}
-
 // fp64 (rows x cols, ld ldi) -> fp32 (rows x cols_pad, zero-padded columns)
 __global__ void k_f64_to_f32_pad(int64_t rows, int64_t cols, int64_t cols_pad, const double* __restrict__ in, int64_t ldi,
                                  float* __restrict__ out) {
@@ -620,21 +467,6 @@ bool gemm_f32_big_eligible(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t
 void gemm_f32_big(ccz_ctx* c, int64_t M, int64_t N, int64_t K, double alpha, const float* A, int64_t lda,
                   const double* B, int64_t ldb, double beta, float* C, int64_t ldc, const double* bias_row) {
   hipStream_t st = stream(c);
-  static const int tall_impl = [] { const char* e = getenv("CCZ_GEMM_TALL_IMPL"); return e ? atoi(e) : 1; }();   // 1: LDS-DMA FIFO, 0: staged tile
-  if (tall_impl != 0 && tall_eligible(M, N, K, lda, A, C) && K % 32 == 0 && int64_t(128) * lda * 4 < (int64_t(1) << 31)) {
-    float* Wp = static_cast<float*>(dev_alloc(c, size_t(K + 1) * 64 * 4));
-    float* bias32 = bias_row ? Wp + K * 64 : nullptr;
-    hipLaunchKernelGGL(k_pack_w_tall, dim3((unsigned)std::min<int64_t>((K * 64 + 255) / 256, 1 << 16)), dim3(256), 0, st, K, N, B, ldb, Wp);
-    if (bias_row)
-      hipLaunchKernelGGL(k_f64_to_f32_pad, dim3(1), dim3(256), 0, st, int64_t(1), N, int64_t(64), bias_row, N, bias32);
-    const size_t fifo_bytes = size_t(4) * TFR * TFSLOT;      // 96 KiB: four wave-private rings
-    CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_f32_nn_tall_fifo), hipFuncAttributeMaxDynamicSharedMemorySize, int(fifo_bytes)));
-    hipLaunchKernelGGL(k_gemm_f32_nn_tall_fifo, dim3((unsigned)((M + 511) / 512)), dim3(256), fifo_bytes, st, M, N, K, float(alpha), A, lda, Wp,
-                       float(beta), C, ldc, bias32);
-    CCZ_LAUNCH_CHECK();
-    dev_free(c, Wp);
-    return;
-  }
   if (tall_eligible(M, N, K, lda, A, C)) {
     float* B32 = static_cast<float*>(dev_alloc(c, size_t(K + 1) * TN * 4));
     float* bias32 = bias_row ? B32 + K * TN : nullptr;

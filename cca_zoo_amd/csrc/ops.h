@@ -14,6 +14,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -113,6 +114,21 @@ void potrf_lower_batched_aux(ccz_ctx* c, int count, double* const* A, const int6
                              double* const* aux);
 void trsm_right_lower_aux(ccz_ctx* c, bool trans, int64_t r, int64_t d, const double* L, int64_t ldl, double* X,
                           int64_t ldx, const double* aux);
+// A triangular solve that RIDES ALONG a factorization:  X (r x d[matrix], ld ldx) <- X L^-T  with L the factor of matrix
+// `matrix` of the batch, advanced one column block at a time as soon as that block of the factor is final -- the solve's
+// large products fill the chip while the factorization's latency chain crawls on a few workgroups.  `prepare` (optional)
+// runs once, right before the rider first reads X: the caller's last chance to fill it (and to wait for its source).
+// potrf_lower_batched_aux_rider always factors; it returns true if it also performed the rider's solve (then valid iff
+// info[matrix] == 0), false if the backend / shape cannot interleave (X untouched, prepare not called).
+struct TrsmRider {
+  int matrix = -1;
+  int64_t r = 0;
+  double* X = nullptr;
+  int64_t ldx = 0;
+  std::function<void()> prepare;
+};
+bool potrf_lower_batched_aux_rider(ccz_ctx* c, int count, double* const* A, const int64_t* d, const int64_t* lda, int* info,
+                                   double* const* aux, const TrsmRider* rider);
 // The same solve for `count` independent problems with FEW rows each (the back-projections of the k wanted
 // directions, r_b = k): their dependent steps advance together in batched launches.  aux[b] as above (a backend may
 // fall back to a loop over trsm_right_lower_aux when one is null or the shapes do not suit it).

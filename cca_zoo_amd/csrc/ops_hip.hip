@@ -1262,8 +1262,11 @@ struct StreamSwap {
 };
 
 static void potrf_lower_batched_sb(ccz_ctx* c, int count, double* const* A, const int64_t* d, const int64_t* lda, int* info,
-                                   double* const* keep) {
+                                   double* const* keep, const TrsmRider* rider = nullptr, int rider_idx = -1) {
   if (count > 8) fail(CCZ_EUNSUP, "potrf_lower_batched_sb: at most 8 matrices per call");
+  // the rider's r x 512 product buffer (X_J inv(L_JJ)') -- see the end of the J loop
+  DBuf rtmp;
+  if (rider) rtmp = DBuf(c, rider->r * SB);
   Impl* im = impl(c);
   int64_t dmax = 0;
   for (int i = 0; i < count; ++i) dmax = std::max(dmax, d[i]);
@@ -1394,6 +1397,20 @@ static void potrf_lower_batched_sb(ccz_ctx* c, int count, double* const* A, cons
       gemm(c, false, true, rem2, w1, w, -1.0, t2, w, tmp[i], w, 1.0, A[i] + (j1 + w1) * lda[i] + j1, lda[i]);   // column J + 1
       gemm_ex(c, false, true, rem2, rem2, w, -1.0, t2, w, t2, w, 1.0, A[i] + (j1 + w1) * lda[i] + (j1 + w1), lda[i], nullptr, 0, true);
     }
+    // ---- the rider: column block J of its factor is final now (diagonal block, panel top, panel rest), so step J of
+    // X <- X L^-T can go: X_J <- X_J inv(L_JJ)', X[:, below] -= X_J L[below, J]'  (trsm_right_lower_sb, trans branch).
+    // It queues behind update J on the main stream -- throughput work under the factorization chain of block J + 1.
+    if (rider && j0 < d[rider_idx]) {
+      const int i = rider_idx;
+      if (J == 0 && rider->prepare) rider->prepare();
+      const int64_t w = std::min(SB, d[i] - j0), rem = d[i] - j0 - w;
+      const double* Xinv = keep[i] + J * SB * SB;
+      double* X = rider->X;
+      gemm(c, false, true, rider->r, w, w, 1.0, X + j0, rider->ldx, Xinv, SB, 0.0, rtmp, SB);
+      copy2d(c, rider->r, w, rtmp, SB, X + j0, rider->ldx);
+      if (rem > 0)
+        gemm(c, false, true, rider->r, rem, w, -1.0, rtmp, SB, A[i] + (j0 + w) * lda[i] + j0, lda[i], 1.0, X + j0 + w, rider->ldx);
+    }
     if (la && J + 1 < nsb) CCZ_HIP(hipStreamWaitEvent(s_main, im->aux_ev[1], 0));
   }
   std::vector<int> got(nslots, 0x7fffffff);
@@ -1412,8 +1429,8 @@ static void potrf_lower_batched_sb(ccz_ctx* c, int count, double* const* A, cons
   }
 }
 
-static void potrf_lower_batched_new(ccz_ctx* c, int count, double* const* A, const int64_t* d, const int64_t* lda, int* info,
-                                    double* const* aux = nullptr) {
+static bool potrf_lower_batched_new(ccz_ctx* c, int count, double* const* A, const int64_t* d, const int64_t* lda, int* info,
+                                    double* const* aux = nullptr, const TrsmRider* rider = nullptr) {
   // matrices up to 1024 columns go through the step kernels directly; wider ones super-blocked; both batched by 8
   std::vector<double*> As, Ab, Kb;
   std::vector<int64_t> ds, lds_, db, ldb_;
@@ -1427,12 +1444,20 @@ static void potrf_lower_batched_new(ccz_ctx* c, int count, double* const* A, con
     potrf_lower_batched_steps(c, int(As.size()), As.data(), ds.data(), lds_.data(), inf.data());
     for (size_t t = 0; t < idx.size(); ++t) info[idx[t]] = inf[t];
   }
+  bool rode = false;
   for (size_t b0 = 0; b0 < Ab.size(); b0 += 8) {
     const int nbt = int(std::min<size_t>(8, Ab.size() - b0));
     int inf[8];
-    potrf_lower_batched_sb(c, nbt, Ab.data() + b0, db.data() + b0, ldb_.data() + b0, inf, Kb.data() + b0);
+    // the rider needs the kept inverses of its factor's diagonal super-blocks
+    int ridx = -1;
+    if (rider && rider->X && rider->r > 0)
+      for (int t = 0; t < nbt; ++t)
+        if (idb[b0 + t] == rider->matrix && Kb[b0 + t]) ridx = t;
+    potrf_lower_batched_sb(c, nbt, Ab.data() + b0, db.data() + b0, ldb_.data() + b0, inf, Kb.data() + b0, ridx >= 0 ? rider : nullptr, ridx);
+    rode = rode || ridx >= 0;
     for (int t = 0; t < nbt; ++t) info[idb[b0 + t]] = inf[t];
   }
+  return rode;
 }
 
 static void trsm_right_lower_sb(ccz_ctx* c, bool trans, int64_t r, int64_t d, const double* L, int64_t ldl, double* X, int64_t ldx,
@@ -1513,6 +1538,13 @@ void potrf_lower_batched_aux(ccz_ctx* c, int count, double* const* A, const int6
                              double* const* aux) {
   if (solver_legacy() || !aux) { potrf_lower_batched(c, count, A, d, lda, info); return; }
   potrf_lower_batched_new(c, count, A, d, lda, info, aux);
+}
+
+bool potrf_lower_batched_aux_rider(ccz_ctx* c, int count, double* const* A, const int64_t* d, const int64_t* lda, int* info,
+                                   double* const* aux, const TrsmRider* rider) {
+  static const int rider_on = [] { const char* e = getenv("CCZ_POTRF_RIDER"); return e ? atoi(e) : 1; }();
+  if (solver_legacy() || !aux || !rider_on || !rider) { potrf_lower_batched_aux(c, count, A, d, lda, info, aux); return false; }
+  return potrf_lower_batched_new(c, count, A, d, lda, info, aux, rider);
 }
 
 void trsm_right_lower_aux(ccz_ctx* c, bool trans, int64_t r, int64_t d, const double* L, int64_t ldl, double* X,

@@ -464,7 +464,10 @@ void back_project_rows_multi(ccz_ctx* c, const std::vector<const Whitener*>& F, 
 // R_i (d_i x d_i, consumed) -> Whiteners; the Cholesky panel chains of all blocks run batched.
 // allow_floor: a block whose Cholesky fails falls back to the eigen-floored explicit factor
 // (rCCA c = 0 on rank-deficient data); otherwise ENOTSPD.
-std::vector<Whitener> make_whiteners(ccz_ctx* c, std::vector<DBuf>& R, const std::vector<int64_t>& dims, bool allow_floor) {
+// rider (optional): a triangular solve with one of the factors that the backend may interleave with the factorization
+// (ops.h::TrsmRider); *rode tells whether it did.
+std::vector<Whitener> make_whiteners(ccz_ctx* c, std::vector<DBuf>& R, const std::vector<int64_t>& dims, bool allow_floor,
+                                     const TrsmRider* rider = nullptr, bool* rode = nullptr) {
   const int m = int(R.size());
   std::vector<DBuf> keep(m);
   std::vector<double*> ptr(m);
@@ -478,7 +481,8 @@ std::vector<Whitener> make_whiteners(ccz_ctx* c, std::vector<DBuf>& R, const std
     const int64_t na = trsm_aux_size(c, dims[i]);
     if (na > 0) { aux[i] = DBuf(c, na); auxp[i] = aux[i].get(); }
   }
-  potrf_lower_batched_aux(c, m, ptr.data(), dims.data(), ld.data(), info.data(), auxp.data());
+  const bool did = potrf_lower_batched_aux_rider(c, m, ptr.data(), dims.data(), ld.data(), info.data(), auxp.data(), rider);
+  if (rode) *rode = did;
   std::vector<Whitener> out(m);
   for (int i = 0; i < m; ++i) {
     Whitener& w = out[i];
@@ -646,11 +650,24 @@ static void rcca_solve_impl(ccz_ctx* c, const double* mom, int64_t n, const int6
   add_diag(c, d2, Rv[1], d2, cc[1]);
   pt.mark("cov");
 
-  // the factorizations need the diagonal blocks only: under the sharded exchange the cross block may still be in flight
-  std::vector<Whitener> Fv = make_whiteners(c, Rv, {d1, d2}, true);
+  // The factorizations need the diagonal blocks only: under the sharded exchange the cross block may still be in flight.
+  // The first whitening solve  M12 <- M12 L_2^-T  rides along the factorization (its products fill the chip under the
+  // Cholesky chain); M12 is formed -- and the exchange's second part awaited -- right before the rider's first step.
+  auto form_m12 = [&] {
+    wait_deferred(c);
+    cov_block(c, G, D, s, n, ctr, inv, 0, d1, d1, d2, M12, d2);
+  };
+  TrsmRider rider;
+  rider.matrix = 1;
+  rider.r = d1;
+  rider.X = M12.get();
+  rider.ldx = d2;
+  rider.prepare = form_m12;
+  bool rode = false;
+  std::vector<Whitener> Fv = make_whiteners(c, Rv, {d1, d2}, true, &rider, &rode);
   pt.mark("factor");
-  wait_deferred(c);
-  cov_block(c, G, D, s, n, ctr, inv, 0, d1, d1, d2, M12, d2);
+  if (rode && !Fv[1].chol) rode = false;            // the factor it rode on was rejected: M12 holds a partial solve
+  if (!rode) form_m12();
   Whitener& F1 = Fv[0];
   Whitener& F2 = Fv[1];
   const int64_t r1 = F1.r, r2 = F2.r;
@@ -659,7 +676,7 @@ static void rcca_solve_impl(ccz_ctx* c, const double* mom, int64_t n, const int6
   // Y = M12 F2 (d1 x r2);  Tt = Y' F1 = (F1' M12 F2)'  (r2 x r1)
   // (Cholesky whiteners work in place: r_i = d_i, no copies; the eigen-floored fallback has an explicit F)
   DBuf Y;
-  if (F2.chol) { F2.right_apply(c, d1, M12, d2, M12, d2); Y = std::move(M12); }
+  if (F2.chol) { if (!rode) F2.right_apply(c, d1, M12, d2, M12, d2); Y = std::move(M12); }
   else { Y = DBuf(c, d1 * r2); F2.right_apply(c, d1, M12, d2, Y, r2); M12.reset(); }
   DBuf Yt(c, r2 * d1);
   transpose(c, d1, r2, Y, r2, Yt, d1);

@@ -215,6 +215,11 @@ void potrf_lower_batched_aux(ccz_ctx* c, int count, double* const* A, const int6
                              double* const*) {
   potrf_lower_batched(c, count, A, d, lda, info);
 }
+bool potrf_lower_batched_aux_rider(ccz_ctx* c, int count, double* const* A, const int64_t* d, const int64_t* lda, int* info,
+                                   double* const* aux, const TrsmRider*) {
+  potrf_lower_batched_aux(c, count, A, d, lda, info, aux);
+  return false;                          // the host double never interleaves: the caller solves afterwards
+}
 void trsm_right_lower_aux(ccz_ctx* c, bool trans, int64_t r, int64_t d, const double* L, int64_t ldl, double* X,
                           int64_t ldx, const double*) {
   trsm_right_lower(c, trans, r, d, L, ldl, X, ldx);
