@@ -1030,101 +1030,59 @@ bool launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
   if (nblocks > 0x7fffffffLL) fail(CCZ_EUNSUP, "gram: grid too large");
   const size_t lds_bytes = size_t(2) * 2 * BK * tile * sizeof(T);  // 64 KiB either way
 
-  // ---- column sums: they are the means, and for fp32 views they decide (and define) the pilot shift ----
+  // ---- column sums first: they are the means, and for fp32 views they decide (and define) the pilot shift ----
+  // (Round 3 tried to hide this 5.4 ms HBM-bound pass under the MFMA-bound K1 on a second stream, with the pilot decided
+  // from a strided sample: K1 then ran 7 ms LONGER -- the column-sum workgroups share the CUs' issue slots with K1's one
+  // wave per SIMD -- so the pass stays in front.)
   static const int pilot_env = [] { const char* e = getenv("CCZ_GRAM_PILOT"); return e ? atoi(e) : -1; }();   // -1: caller's mode
   if (pilot_env == 0 || pilot_env == 1) pilot_mode = pilot_env == 1 ? 2 : 0;
   if (!is32) pilot_mode = 0;                                  // fp64 views accumulate in fp64: nothing to protect
   static const double pilot_thr = [] { const char* e = getenv("CCZ_GRAM_PILOT_RATIO"); return e ? atof(e) : 2.0; }();
   double* s_launch = s;            // column sums of THIS launch's rows (separate from the running sums in pilot modes)
   double* sq = nullptr;
-  auto colsum_pass = [&](hipStream_t on, int64_t rows, int64_t row_stride, double* sums, double* sums_sq) {
-    // rows `row_stride` apart (1: all of them): a strided pass is the SAMPLE the automatic pilot decision reads
-    int64_t off = 0;
-    for (int v = 0; v < n_views; ++v) {
-      // enough row blocks to cover the chip even for narrow / short views
-      const int64_t colblocks = (views[v].cols + 255) / 256;
-      int64_t rpb = 2048;
-      while (rpb > 64 && colblocks * ((rows + rpb - 1) / rpb) < 4 * int64_t(ncu)) rpb /= 2;
-      dim3 grid((unsigned)colblocks, (unsigned)((rows + rpb - 1) / rpb));
-      if (sums_sq)
-        hipLaunchKernelGGL((k_colsum<T, true>), grid, dim3(256), 0, on, static_cast<const T*>(views[v].data), rows, views[v].cols,
-                           views[v].ld * row_stride, sums + off, sums_sq + off, rpb);
-      else
-        hipLaunchKernelGGL((k_colsum<T, false>), grid, dim3(256), 0, on, static_cast<const T*>(views[v].data), rows, views[v].cols,
-                           views[v].ld * row_stride, sums + off, static_cast<double*>(nullptr), rpb);
-      off += views[v].cols;
-    }
-    CCZ_LAUNCH_CHECK();
-  };
-  // Automatic mode on a large launch: the decision (and, if taken, the pilot) comes from a SAMPLE of every 16th row --
-  // spread over the whole row range, so data that drift away from zero are seen -- and the full column sums run on a
-  // second stream UNDER K1 (K1 is MFMA-bound, the sums are HBM-bound: 5.4 ms of the metric's fit that no longer sit in
-  // front of it).  The pilot only has to be near the mean; the exact sums still enter the fix-up and the moments.
-  static const int overlap_env = [] { const char* e = getenv("CCZ_COLSUM_OVERLAP"); return e ? atoi(e) : 1; }();
-  constexpr int64_t kSampleStride = 16;
-  bool overlap = pilot_mode == 1 && overlap_env != 0 && n >= int64_t(1) << 18 && st != nullptr;
-  hipStream_t s_sum = st;
-  if (overlap) {
-    if (!im->aux_stream) {
-      hipStream_t ns = nullptr;
-      hipEvent_t e0 = nullptr, e1 = nullptr;
-      if (hipStreamCreateWithFlags(&ns, hipStreamNonBlocking) == hipSuccess &&
-          hipEventCreateWithFlags(&e0, hipEventDisableTiming) == hipSuccess &&
-          hipEventCreateWithFlags(&e1, hipEventDisableTiming) == hipSuccess) {
-        im->aux_stream = ns; im->aux_ev[0] = e0; im->aux_ev[1] = e1;
-      } else {
-        (void)hipGetLastError();
-        if (e0) (void)hipEventDestroy(e0);
-        if (ns) (void)hipStreamDestroy(ns);
-        overlap = false;
-      }
-    }
-    if (overlap) s_sum = im->aux_stream;
-  }
   if (pilot_mode != 0) {
-    s_launch = static_cast<double*>(dev_alloc(c, size_t(D) * 8 * (pilot_mode == 1 ? (overlap ? 3 : 2) : 1)));
-    zero(c, s_launch, size_t(D) * 8 * (pilot_mode == 1 ? (overlap ? 3 : 2) : 1));
+    s_launch = static_cast<double*>(dev_alloc(c, size_t(D) * 8 * (pilot_mode == 1 ? 2 : 1)));
+    zero(c, s_launch, size_t(D) * 8 * (pilot_mode == 1 ? 2 : 1));
     if (pilot_mode == 1) sq = s_launch + D;
   }
-  double* s_sample = overlap ? s_launch + 2 * D : nullptr;       // [exact sums | sample squares | sample sums]
-  const int64_t n_sample = (n + kSampleStride - 1) / kSampleStride;
   if (time_it) CCZ_HIP(hipEventRecord(im->ev[2], st));
-  if (overlap) colsum_pass(st, n_sample, kSampleStride, s_sample, sq);
-  else colsum_pass(st, n, 1, s_launch, sq);
+  int64_t off = 0;
+  for (int v = 0; v < n_views; ++v) {
+    // enough row blocks to cover the chip even for narrow / short views
+    const int64_t colblocks = (views[v].cols + 255) / 256;
+    int64_t rpb = 2048;
+    while (rpb > 64 && colblocks * ((n + rpb - 1) / rpb) < 4 * int64_t(ncu)) rpb /= 2;
+    dim3 grid((unsigned)colblocks, (unsigned)((n + rpb - 1) / rpb));
+    if (sq)
+      hipLaunchKernelGGL((k_colsum<T, true>), grid, dim3(256), 0, st, static_cast<const T*>(views[v].data), n, views[v].cols,
+                         views[v].ld, s_launch + off, sq + off, rpb);
+    else
+      hipLaunchKernelGGL((k_colsum<T, false>), grid, dim3(256), 0, st, static_cast<const T*>(views[v].data), n, views[v].cols,
+                         views[v].ld, s_launch + off, static_cast<double*>(nullptr), rpb);
+    off += views[v].cols;
+  }
+  CCZ_LAUNCH_CHECK();
   if (time_it) CCZ_HIP(hipEventRecord(im->ev[3], st));
   bool use_pilot = pilot_mode == 2;
-  const double* pilot_src = s_launch;
-  double pilot_rows = double(n);
   if (pilot_mode == 1) {
     // largest |mean| / std over the columns: fp32 accumulation of raw products loses ~ eps32 sqrt(rows) (mean/std)^2 of
     // a covariance entry (6e-4 at ratio 10, garbage at 1000); the FIFO kernel is kept for ratio <= 2
-    const double* sum_src = overlap ? s_sample : s_launch;
-    const double rows_src = overlap ? double(n_sample) : double(n);
     std::vector<double> hs(size_t(2) * D);
-    d2h(c, hs.data(), sum_src, size_t(D) * 8);
-    d2h(c, hs.data() + D, sq, size_t(D) * 8);
+    d2h(c, hs.data(), s_launch, size_t(2) * D * 8);
     double worst = 0.0;
     for (int64_t j = 0; j < D; ++j) {
-      const double mu = hs[j] / rows_src, var = hs[D + j] / rows_src - mu * mu;
+      const double mu = hs[j] / double(n), var = hs[D + j] / double(n) - mu * mu;
       if (!std::isfinite(mu) || !std::isfinite(var)) continue;          // NaN / inf inputs are reported by the caller
       const double sd = var > 0.0 ? std::sqrt(var) : 0.0;
       const double ratio = std::fabs(mu) <= pilot_thr * sd ? 0.0 : (sd > 0.0 ? std::fabs(mu) / sd : 1e300);
       if (ratio > worst) worst = ratio;
     }
     use_pilot = worst > pilot_thr;
-    if (overlap) { pilot_src = s_sample; pilot_rows = rows_src; }
   }
   float* pilot = nullptr;
   if (use_pilot) {
     pilot = static_cast<float*>(dev_alloc(c, size_t(D) * 4));
-    hipLaunchKernelGGL(k_pilot_from_sums, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, st, pilot_src, D, 1.0 / pilot_rows, pilot);
-  }
-  if (overlap) {
-    // the exact column sums, on the second stream, ordered after the zeroing above and before the fix-up below
-    CCZ_HIP(hipEventRecord(im->aux_ev[0], st));
-    CCZ_HIP(hipStreamWaitEvent(s_sum, im->aux_ev[0], 0));
-    colsum_pass(s_sum, n, 1, s_launch, nullptr);
-    CCZ_HIP(hipEventRecord(im->aux_ev[1], s_sum));
+    hipLaunchKernelGGL(k_pilot_from_sums, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, st, s_launch, D, 1.0 / double(n), pilot);
   }
 
   if (time_it) CCZ_HIP(hipEventRecord(im->ev[0], st));
@@ -1186,7 +1144,6 @@ bool launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
     dev_free(c, partial);
   }
   if (time_it) CCZ_HIP(hipEventRecord(im->ev[1], st));
-  if (overlap) CCZ_HIP(hipStreamWaitEvent(st, im->aux_ev[1], 0));       // the exact column sums are complete
   if (use_pilot) {
     if (D > 65535) fail(CCZ_EUNSUP, "gram: pilot fix-up supports D <= 65535");
     hipLaunchKernelGGL(k_pilot_fixup, dim3((unsigned)((D + 255) / 256), (unsigned)D), dim3(256), 0, st, G, D, s_launch, double(n), pilot);

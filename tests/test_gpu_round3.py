@@ -359,8 +359,7 @@ def test_pilot_inside_the_fifo_kernel(n):
     """fp32 views at 100 sigma from zero on a grid large enough for the XCD-sliced FIFO kernel (2 x 4096 columns):
     k_gram_f32_fifo<PILOT> on the rows that form whole 32-row ring periods + the staged kernel on the ragged tail.
     Covariance from the device moments against float64 (torch on the device as the comparator) within 2e-5 of scale;
-    raw fp32 products would be off by ~5e-2.  From 2^18 rows on the decision and the pilot come from a sample of every
-    16th row and the exact column sums run on a second stream under K1 (n = 300011 covers that route)."""
+    raw fp32 products would be off by ~5e-2."""
     import torch
 
     from cca_zoo_amd import _backend

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--views", type=int, default=2)
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--iters", type=int, default=3)
+    ap.add_argument("--offset", type=float, default=0.0, help="shift every column by this many standard deviations (pilot-shifted K1)")
     a = ap.parse_args()
     import torch
 
@@ -27,6 +28,9 @@ def main():
     tdt = torch.float32 if a.dtype == "f32" else torch.float64
     es = 4 if a.dtype == "f32" else 8
     views = [torch.randn(a.n, a.d, device="cuda", dtype=tdt) for _ in range(a.views)]
+    if a.offset:
+        for v in views:
+            v.add_(a.offset)
     D = a.d * a.views
     mom = torch.empty(D * D + D, dtype=torch.float64, device="cuda")
     torch.cuda.synchronize()
