@@ -305,6 +305,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64_half(int64_t M, int64_t N, 
     }
 }
 
+// Round 3 tried the wave-private LDS-DMA FIFO of K1 on the A B' shape of the Cholesky updates and forward triangular
+// solves (lane l of a 16-row MFMA tile loads X[16 t + (l & 15)][k0 + 2 (l >> 4) .. + 1] as one 16-byte
+// buffer_load ... lds; no barriers, no transposing scatter, 8 DMA + 8 ds_read_b128 per 32 MFMAs).  Correct, and SLOWER than
+// the staged kernels below: rCCA solve 14.4 vs 13.6 ms, GCCA (D = 16384) 201 vs 178 ms.  With the projection kernel's
+// result (gemm_big.hip) the lesson is that the FIFO pays when one DMA instruction moves 1 KiB of CONTIGUOUS memory (K1:
+// a k-step of X'X is two full row segments); gathering 16 - 64-byte pieces from 16 - 32 different rows per instruction runs
+// the texture path at a fraction of that rate, and a cooperative, coalesced stage + LDS transpose wins.  The attempt is in
+// the history (commit "fp64 A B' FIFO GEMM: measured, removed"), not in the tree.
 static int64_t env_ll(const char* name, int64_t dflt) {
   const char* e = getenv(name);
   return e ? atoll(e) : dflt;

@@ -516,3 +516,34 @@ def test_sharded_fits_world_size_one_use_the_deferred_exchange():
     finally:
         if started:
             dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------
+# A B' fp64 products at the shapes of the Cholesky updates and forward triangular solves (csrc/gemm64_big.hip)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K,lda_extra,beta", [
+    (4096, 512, 512, 0, 0.0),        # a super-block product: fewer 128-tiles than CUs -> the 64 x 128 tile
+    (4096, 3584, 512, 512, 1.0),     # a trailing update inside a wider matrix (strided operands)
+    (1000, 777, 96, 2, -0.5),        # ragged rows and columns
+    (130, 129, 32, 0, 0.0),          # barely two tiles each way
+    (2048, 2048, 4096, 0, 1.0),
+])
+def test_gemm_f64_a_bt_shapes(M, N, K, lda_extra, beta):
+    import ctypes as C
+
+    import torch
+
+    from cca_zoo_amd import _backend
+
+    H = _backend.default_handle(0)
+    torch.manual_seed(M + N + K)
+    A = torch.randn(M, K + lda_extra, dtype=torch.float64, device="cuda")
+    B = torch.randn(N, K + lda_extra, dtype=torch.float64, device="cuda")
+    Cm = torch.randn(M, N + 2, dtype=torch.float64, device="cuda")
+    ref = Cm.clone()
+    ref[:, :N] = 0.7 * (A[:, :K] @ B[:, :K].T) + beta * Cm[:, :N]
+    H.check(H.lib.ccz_gemm_f64(H.raw, 0, 1, M, N, K, 0.7, C.c_void_p(A.data_ptr()), A.shape[1], C.c_void_p(B.data_ptr()),
+                               B.shape[1], beta, C.c_void_p(Cm.data_ptr()), Cm.shape[1]))
+    H.sync()
+    assert float((Cm[:, :N] - ref[:, :N]).abs().max() / ref[:, :N].abs().max()) < 1e-12
+    assert torch.equal(Cm[:, N:], ref[:, N:])                # columns past N untouched
