@@ -311,8 +311,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64_half(int64_t M, int64_t N, 
 // the staged kernels below: rCCA solve 14.4 vs 13.6 ms, GCCA (D = 16384) 201 vs 178 ms.  With the projection kernel's
 // result (gemm_big.hip) the lesson is that the FIFO pays when one DMA instruction moves 1 KiB of CONTIGUOUS memory (K1:
 // a k-step of X'X is two full row segments); gathering 16 - 64-byte pieces from 16 - 32 different rows per instruction runs
-// the texture path at a fraction of that rate, and a cooperative, coalesced stage + LDS transpose wins.  The attempt is in
-// the history (commit "fp64 A B' FIFO GEMM: measured, removed"), not in the tree.
+// the texture path at a fraction of that rate, and a cooperative, coalesced stage + LDS transpose wins.  (Measured on the
+// GPU and dropped before it was ever committed; DESIGN.md section 4 keeps the numbers.)
 static int64_t env_ll(const char* name, int64_t dflt) {
   const char* e = getenv(name);
   return e ? atoll(e) : dflt;
