@@ -50,8 +50,8 @@ def parse():
     ap.add_argument("--no-cpu-mcca", action="store_true",
                     help="skip the reference-structured MCCA / GCCA comparators (BASELINE configs[2] / [4] on bounded samples: ~1 min of CPU)")
     ap.add_argument("--cpu-mcca", action="store_true", help="(kept for compatibility: the MCCA comparator is on by default)")
-    ap.add_argument("--cpu-sample-rows", type=int, default=0,
-                    help="rows of the rCCA CPU comparator's sample (0: chosen so that one run takes ~10 s and three runs are timed)")
+    ap.add_argument("--cpu-sample-rows", type=int, default=0, help="rows of the rCCA CPU comparator's sample (0: 2 d)")
+    ap.add_argument("--cpu-runs", type=int, default=1, help="repeats of the rCCA CPU comparator (a run is ~25 s; the median is reported)")
     ap.add_argument("--no-gates", action="store_true", help="skip the parity gates of the extras (the headline gate always runs)")
     return ap.parse_args()
 
@@ -207,12 +207,16 @@ def host_cores():
     return n, quota
 
 
-def cpu_baseline(n_full, d, k, sample_rows=0, target_s=10.0):
-    """``oracle.reference_form.rcca_weights`` -- the reference's structure (thin SVD of each centred n x d view,
-    cca_zoo/linear/_rcca.py:92-100) -- on a bounded sample of the same kind of data, THREE runs, median reported.
-    The sample's row count is chosen from a short pilot run (n = d / 2 rows) so that one run takes about
-    ``target_s`` seconds (rows >= d: the tall side of the thin SVD, where its cost is O(n d^2) like the full
-    problem's); ``value`` is the linear-in-n extrapolation of the measured median, reported next to the measurement."""
+def cpu_baseline(n_full, d, k, sample_rows=0, runs=1):
+    """The reference's rCCA structure (cca_zoo/linear/_rcca.py:92-100: thin SVD of each centred n x d view, whitened
+    cross product, SVD of the d x d matrix T) from the oracle's own building blocks (``oracle.reference_form``), on a
+    bounded sample of ``sample_rows`` rows (default 2 d: the tall side of the thin SVD) of the same kind of data.
+
+    The part that grows with n (the two thin SVDs and the n x d x d cross product: O(n d^2)) is timed separately from
+    the part that does not (the SVD of T, the d x d x k back-multiplication: O(d^3)), and only the former is scaled to
+    the full n -- at n ~ d the fixed part is a third of the run, and scaling it too (as round 2 did) overstated the
+    extrapolation.  ``runs`` defaults to ONE: a run is ~25 s of CPU, BASELINE.md's median-of-three would triple the
+    bench's CPU leg (``--cpu-runs 3`` does it); the JSON says how many were made."""
     import numpy as np
 
     from oracle import reference_form as rf
@@ -227,34 +231,39 @@ def cpu_baseline(n_full, d, k, sample_rows=0, target_s=10.0):
         limiter = threadpool_limits(limits=max(cores, 1))
     except Exception:
         limiter = None
-    pilot_s = None
+    if sample_rows <= 0:
+        sample_rows = 2 * d
+    views = [v.astype(np.float32) for v in rf.joint_data(2, sample_rows, k, [d, d], 1.0, 0)]
+    t_data, t_fixed = [], []
     try:
-        if sample_rows <= 0:
-            rows_p = max(d // 2, 256)
-            vp = [v.astype(np.float32) for v in rf.joint_data(2, rows_p, k, [d, d], 1.0, 1)]
+        for _ in range(max(1, runs)):
             t0 = time.perf_counter()
-            rf.rcca_weights(vp, k, c=0.0)
-            pilot_s = time.perf_counter() - t0
-            del vp
-            # O(n d^2): rows for ~target_s, kept in [d, 4 d] and a multiple of 1024
-            sample_rows = int(min(4 * d, max(d, rows_p * target_s / max(pilot_s, 1e-3))) // 1024 * 1024) or d
-        views = [v.astype(np.float32) for v in rf.joint_data(2, sample_rows, k, [d, d], 1.0, 0)]
-        times = []
-        for _ in range(3):
-            t0 = time.perf_counter()
-            rf.rcca_weights(views, k, c=0.0)
-            times.append(time.perf_counter() - t0)
+            (X1, X2), _means = rf.center_views(views, True)
+            X1w, W1 = rf.thin_svd_whitener(X1, 0.0)
+            X2w, W2 = rf.thin_svd_whitener(X2, 0.0)
+            T = X1w.T @ X2w / (X1.shape[0] - 1)
+            t1 = time.perf_counter()
+            U, _sv, Vt = np.linalg.svd(T, full_matrices=False)
+            kk = min(k, X1w.shape[1], X2w.shape[1])
+            _W = [W1 @ U[:, :kk], W2 @ Vt[:kk].T]
+            t2 = time.perf_counter()
+            t_data.append(t1 - t0)
+            t_fixed.append(t2 - t1)
+            del X1, X2, X1w, X2w, T, U, Vt, _W
     finally:
         if limiter is not None:
             limiter.restore_original_limits()
-    med = float(np.median(times))
-    full = med * (n_full / sample_rows)
+    td, tf = float(np.median(t_data)), float(np.median(t_fixed))
+    full = tf + td * (n_full / sample_rows)
     return {
-        "value": 1.0 / full, "unit": "fit/s (extrapolated linearly in n from the measured sample)", "cores": max(cores, 1), "kind": "port",
-        "sample": (f"oracle.reference_form.rcca_weights (thin SVD per view, as cca_zoo/linear/_rcca.py:92-100) on "
-                   f"{sample_rows} rows (= {sample_rows / d:.2g} d) of 2x{d} fp32 JointData, k={k}; median of 3 runs"),
-        "measured_s": med, "runs_s": [round(t, 3) for t in times], "sample_rows": sample_rows, "pilot_run_s": pilot_s,
-        "extrapolated_full_s": full, "extrapolation": f"measured_s * {n_full}/{sample_rows} (O(n d^2) thin SVD)",
+        "value": 1.0 / full, "unit": "fit/s (extrapolated: only the n-dependent part is scaled to the full n)", "cores": max(cores, 1),
+        "kind": "port",
+        "sample": (f"the reference's rCCA structure (thin SVD per view, cross product, SVD of T: cca_zoo/linear/_rcca.py:92-100) "
+                   f"from oracle.reference_form's building blocks on {sample_rows} rows (= {sample_rows / d:.2g} d) of 2x{d} fp32 "
+                   f"JointData, k={k}; {len(t_data)} run(s)"),
+        "measured_s": td + tf, "data_dependent_s": td, "fixed_s": tf, "runs": len(t_data),
+        "runs_s": [round(a + b, 3) for a, b in zip(t_data, t_fixed)], "sample_rows": sample_rows,
+        "extrapolated_full_s": full, "extrapolation": f"fixed_s + data_dependent_s * {n_full}/{sample_rows}",
         "blas_threads": max(cores, 1) if limiter is not None else None, "sched_affinity": affinity, "cgroup_cpu_quota": quota,
         "logical_cpus": os.cpu_count(),
     }
@@ -821,7 +830,7 @@ def main():
             out["dcca_loss_roofline"] = extra["dcca_loss_metric_shape"]["roofline"]
         # last: its BLAS threads keep spinning for a while and would slow the launch chains of the GPU extras
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.n, a.d, a.k, a.cpu_sample_rows)
+            out["cpu_baseline"] = cpu_baseline(a.n, a.d, a.k, a.cpu_sample_rows, a.cpu_runs)
             if not a.no_extras:
                 out["cpu_baseline"]["dcca_loss_configs3"] = cpu_loss_baseline()
             if not a.no_cpu_mcca and not a.no_extras:

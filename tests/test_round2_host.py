@@ -268,11 +268,11 @@ def test_bench_cpu_comparators_run_on_small_shapes():
     assert r["measured_s"] > 0 and r["data_dependent_s"] > 0 and r["eigen_solve_s"] >= 0
     assert abs(r["extrapolated_full_s"] - (r["eigen_solve_s"] + r["data_dependent_s"] * 10_000 / 200)) < 1e-9
     assert abs(r["value"] * r["extrapolated_full_s"] - 1.0) < 1e-12
-    b = bench.cpu_baseline(5_000, 16, 3, 128)
-    assert b["kind"] == "port" and b["sample_rows"] == 128 and b["measured_s"] > 0
-    assert abs(b["extrapolated_full_s"] - b["measured_s"] * 5_000 / 128) < 1e-9 and len(b["runs_s"]) == 3
-    a = bench.cpu_baseline(50_000, 1024, 3, 0, target_s=0.3)                       # adaptive sample: rows in [d, 4 d]
-    assert 1024 <= a["sample_rows"] <= 4096 and a["sample_rows"] % 1024 == 0 and len(a["runs_s"]) == 3 and a["pilot_run_s"] > 0
+    b = bench.cpu_baseline(5_000, 16, 3, 128, runs=3)
+    assert b["kind"] == "port" and b["sample_rows"] == 128 and b["measured_s"] > 0 and b["runs"] == 3 and len(b["runs_s"]) == 3
+    assert abs(b["extrapolated_full_s"] - (b["fixed_s"] + b["data_dependent_s"] * 5_000 / 128)) < 1e-9
+    a = bench.cpu_baseline(50_000, 64, 3)                                          # default sample: 2 d rows, one run
+    assert a["sample_rows"] == 128 and a["runs"] == 1
     g = bench.cpu_gcca_baseline(n_rows=120, dims=(20, 16, 30), k=4)
     assert g["measured_s"] > 0 and g["extrapolated_full_s"] is None
     t, src = bench.gram_traffic("f32", 8192, 1000)
