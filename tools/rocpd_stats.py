@@ -13,6 +13,7 @@ import sys
 
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "")
     name = re.sub(r"\(.*$", "", name)
     name = re.sub(r"^void ", "", name)
     return name[:90]
