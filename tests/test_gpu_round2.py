@@ -481,6 +481,7 @@ def test_ns_shape_against_oracle(n):
     from oracle import gram_form as gf
 
     d, k = 4096, 64
+    torch.cuda.empty_cache()
     free, _ = torch.cuda.mem_get_info()
     if free < n * 2 * d * 4 * 1.3 + 8e9:
         pytest.skip("not enough free HBM")

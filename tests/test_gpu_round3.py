@@ -120,6 +120,7 @@ def test_metric_shape_loss_full_size():
     from cca_zoo_amd.deep.objectives import CCALoss, check_async_errors
     from oracle import losses as ol
 
+    torch.cuda.empty_cache()                                # blocks cached by earlier tests are not "free" to mem_get_info
     free, _ = torch.cuda.mem_get_info()
     n, d, eps = 1_000_000, 4096, 1e-6
     if free < 4.4 * n * d * 4:
@@ -413,6 +414,7 @@ def test_ns_dimensions_per_column_on_a_separated_spectrum(kind):
 
     d, k, n = 4096, 64, 1_000_000
     tdt = torch.float64 if kind == "f64" else torch.float32
+    torch.cuda.empty_cache()                                # blocks cached by earlier tests are not "free" to mem_get_info
     free, _ = torch.cuda.mem_get_info()
     if free < 2.6 * n * 2 * d * (8 if kind == "f64" else 4) + 12e9:
         pytest.skip("not enough free HBM")
