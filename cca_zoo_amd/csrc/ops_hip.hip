@@ -1286,6 +1286,17 @@ static void potrf_lower_batched_sb(ccz_ctx* c, int count, double* const* A, cons
   // info of super-step J of matrix i: slot J * 8 + (position among the matrices alive at J); all start at "no failure"
   const int nslots = int(nsb) * 8;
   int* info_dev = static_cast<int*>(dev_alloc(c, size_t(nslots) * sizeof(int)));
+  // Unwinding (an allocation or launch failure between the look-ahead launch and the main stream's wait): the pooled
+  // buffers below go back to the pool as the DBufs unwind, and the pool recycles them in the order of the MAIN stream --
+  // so the look-ahead stream must be drained first, and the pivot-flag block released.
+  struct Unwind {
+    ccz_ctx* c; Impl* im; int* info; bool armed = true;
+    ~Unwind() {
+      if (!armed) return;
+      if (im->aux_stream) (void)hipStreamSynchronize(im->aux_stream);
+      dev_free(c, info);
+    }
+  } unwind{c, im, info_dev};
 
   hipStream_t s_main = stream(c), s_aux = s_main;
   bool la = potrf_lookahead() != 0 && nsb > 1;
@@ -1416,6 +1427,7 @@ static void potrf_lower_batched_sb(ccz_ctx* c, int count, double* const* A, cons
   std::vector<int> got(nslots, 0x7fffffff);
   // slots of (J, t) with t >= cnt of that super-step were never written: only read what cholinv_batched initialised
   d2h(c, got.data(), info_dev, size_t(nslots) * sizeof(int));
+  unwind.armed = false;
   dev_free(c, info_dev);
   for (int i = 0; i < count; ++i) info[i] = 0;
   for (int64_t J = 0; J < nsb; ++J) {
