@@ -521,14 +521,24 @@ def timed_fit(make_model, views, runs):
     import numpy as np
     import torch
 
+    import gc
+
     ts, solves, last = [], [], None
-    for _ in range(runs + 1):            # first run warms allocator pools / code objects and is dropped
-        t0 = time.perf_counter()
-        last = make_model().fit(views)
-        torch.cuda.synchronize()
-        ts.append((time.perf_counter() - t0) * 1e3)
-        solves.append(last.timings_["solve_ms"])
+    # interpreter housekeeping out of the timed region, as in the headline loop (and as timeit does): after the gates'
+    # host work a generation-2 collection of the sklearn + torch + scipy heap costs ~30 ms and lands inside a "solve"
+    gc.collect()
+    gc.disable()
+    try:
+        for _ in range(runs + 1):            # first run warms allocator pools / code objects and is dropped
+            t0 = time.perf_counter()
+            last = make_model().fit(views)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+            solves.append(last.timings_["solve_ms"])
+    finally:
+        gc.enable()
     last.timings_["solve_ms_median"] = float(np.median(solves[1:]))
+    last.timings_["solve_ms_all"] = [round(float(x), 2) for x in solves[1:]]
     return float(np.median(ts[1:])), last
 
 
@@ -564,7 +574,7 @@ def config_extras(info, gates=True):
         D = sum(dims)
         flop = float(n) * D * (D + 1)
         kind = "f32" if tdt == torch.float32 else "f64"
-        res = {"config": label, "fit_ms": ms, "fits_per_s": 1e3 / ms, "gram_ms": g_ms, "solve_ms": model.timings_["solve_ms_median"],
+        res = {"config": label, "fit_ms": ms, "fits_per_s": 1e3 / ms, "gram_ms": g_ms, "solve_ms": model.timings_["solve_ms_median"], "solve_ms_runs": model.timings_["solve_ms_all"],
                "gram_tflops": flop / (g_ms * 1e-3) / 1e12, "gram_frac_of_peak": flop / (g_ms * 1e-3) / 1e12 / PEAK_TFLOPS[kind],
                "dtype": kind, "n": n, "pilot_shifted_k1": bool(h.moments_last_pilot()),
                "score_top": float(np.asarray(model.score(views))[0])}

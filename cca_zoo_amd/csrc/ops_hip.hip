@@ -1172,7 +1172,10 @@ static void trsm_right_lower_iter(ccz_ctx* c, bool trans, int64_t r, int64_t d, 
   key = key_mix(key_mix(key, uint64_t(r)), uint64_t(d));
   key = key_mix(key_mix(key_ptr(key_ptr(key, L), X), uint64_t(ldl)), uint64_t(ldx));
   key = key_ptr(key_ptr(key, invT.get()), tmp.get());
-  graph_run(c, key, [&] {
+  // A graph is keyed on every pointer baked into it; capture + instantiation cost ~10 ms.  The few-block solves of the
+  // subspace iteration (d = 80: two blocks, five launches) meet new pointer combinations whenever the pool hands out
+  // other blocks -- the second fit of a new shape paid 20 ms for graphs that save nothing.  Replay only pays for long chains.
+  auto body = [&] {
   diag_inverses(c, L, ldl, d, invT);
   if (trans) {
     // X L' = B, forward over column blocks:  X_j = (B_j - sum_{t<j} X_t L_jt') L_jj^-T
@@ -1194,7 +1197,9 @@ static void trsm_right_lower_iter(ccz_ctx* c, bool trans, int64_t r, int64_t d, 
         gemm(c, false, false, r, j, nb, -1.0, tmp, NB, L + j * ldl, ldl, 1.0, X, ldx);
     }
   }
-  });
+  };
+  if (nblk >= 8) graph_run(c, key, body);
+  else body();
 }
 
 
