@@ -594,11 +594,11 @@ def config_extras(info, gates=True):
     run("c2_rcca", "configs[1]: rCCA n=100k, 2x1024, k=32, float32", (1024, 1024), 100_000, 32, torch.float32,
         lambda: rCCA(latent_dimensions=32, c=0.1), "rcca", 0.1, runs=5)
     run("c3_mcca", "configs[2]: MCCA 4x2048, n=1e6, k=64, float32 (one GPU holds all rows)", (2048,) * 4, 1_000_000, 64,
-        torch.float32, lambda: MCCA(latent_dimensions=64), "mcca", 0.0)
+        torch.float32, lambda: MCCA(latent_dimensions=64), "mcca", 0.0, runs=3)
     run("ns_offset", "metric shape on off-centre data (every column mean = 10 sigma): CCA n=1e6, 2x4096, k=64, float32",
-        (4096, 4096), 1_000_000, 64, torch.float32, lambda: CCA(latent_dimensions=64), "rcca", 0.0, offset=10.0)
+        (4096, 4096), 1_000_000, 64, torch.float32, lambda: CCA(latent_dimensions=64), "rcca", 0.0, runs=3, offset=10.0)
     run("ns_f64", "metric shape in float64: CCA n=1e6, 2x4096, k=64", (4096, 4096), 1_000_000, 64, torch.float64,
-        lambda: CCA(latent_dimensions=64), "rcca", 0.0)
+        lambda: CCA(latent_dimensions=64), "rcca", 0.0, runs=3)
     run("c5_gcca", "configs[4] at the largest n one GPU holds: GCCA d=[4096,4096,8192], n=1e6 (of 2e6), k=128, float64",
         (4096, 4096, 8192), 1_000_000, 128, torch.float64, lambda: GCCA(latent_dimensions=128), "gcca", 0.0)
     return out
