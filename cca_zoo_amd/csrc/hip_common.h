@@ -61,6 +61,7 @@ struct Impl {
   // polled waits (ops_hip.hip: wait_stream_short) and the pinned landing buffer of small device -> host copies
   hipEvent_t wait_ev = nullptr;
   void* d2h_pin = nullptr;
+  void* d2h_pin_dev = nullptr;      // device view of d2h_pin (host-mapped): written by a copy kernel
   static constexpr size_t kD2hPinBytes = size_t(4) << 20;
   void* deferred_event = nullptr;   // ccz_solve_defer: awaited by the next solve before it reads off-diagonal blocks
   bool adopted = false;             // c->stream is a caller's stream (ccz_stream_adopt) until the next acquire

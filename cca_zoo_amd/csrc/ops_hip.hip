@@ -120,6 +120,11 @@ static double spin_budget_ms() {
 struct WaitStats { double total_ms = 0.0, max_ms = 0.0; long count = 0, fell_back = 0; };
 static WaitStats& wait_stats() { static WaitStats w; return w; }
 
+__global__ void k_copy_words(const unsigned long long* __restrict__ src, unsigned long long* __restrict__ dst, int64_t n) {
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) dst[i] = src[i];
+  __threadfence_system();
+}
+
 static void wait_stream_short(ccz_ctx* c) {
   Impl* im = impl(c);
   hipStream_t st = stream(c);
@@ -151,12 +156,27 @@ void d2h(ccz_ctx* c, void* dst, const void* src, size_t bytes) {
   // small read-backs go through a pinned word buffer: the copy is then truly asynchronous (a pageable destination is
   // staged by the runtime, which may block inside the call) and the wait below polls
   if (bytes <= Impl::kD2hPinBytes && spin_budget_ms() > 0.0) {
-    if (!im->d2h_pin && hipHostMalloc(&im->d2h_pin, Impl::kD2hPinBytes, hipHostMallocDefault) != hipSuccess) {
-      (void)hipGetLastError();
-      im->d2h_pin = nullptr;
+    if (!im->d2h_pin) {
+      if (hipHostMalloc(&im->d2h_pin, Impl::kD2hPinBytes, hipHostMallocMapped) != hipSuccess) {
+        (void)hipGetLastError();
+        im->d2h_pin = nullptr;
+      } else if (hipHostGetDevicePointer(&im->d2h_pin_dev, im->d2h_pin, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        im->d2h_pin_dev = nullptr;
+      }
     }
     if (im->d2h_pin) {
-      CCZ_HIP(hipMemcpyAsync(im->d2h_pin, src, bytes, hipMemcpyDeviceToHost, stream(c)));
+      // a KERNEL writes the pinned (host-mapped) buffer: no SDMA engine, hence no cross-engine dependency for the
+      // runtime's helper thread to resolve -- with hipMemcpyAsync the event behind the copy was observed to complete
+      // 15 - 19 ms late on the DEVICE time line in some fits (three read-backs of the back-projection phase)
+      if (im->d2h_pin_dev && bytes % 8 == 0 && reinterpret_cast<uintptr_t>(src) % 8 == 0) {
+        const int64_t words = int64_t(bytes / 8);
+        hipLaunchKernelGGL(k_copy_words, dim3((unsigned)std::min<int64_t>((words + 255) / 256, 2048)), dim3(256), 0, stream(c),
+                           static_cast<const unsigned long long*>(src), static_cast<unsigned long long*>(im->d2h_pin_dev), words);
+        CCZ_LAUNCH_CHECK();
+      } else {
+        CCZ_HIP(hipMemcpyAsync(im->d2h_pin, src, bytes, hipMemcpyDeviceToHost, stream(c)));
+      }
       wait_stream_short(c);
       std::memcpy(dst, im->d2h_pin, bytes);
       return;
