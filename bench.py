@@ -149,7 +149,7 @@ def solution_gate(model, views, est, c, jd=None, seed=None, inertia=True):
     from cca_zoo_amd._moments import compute_moments
     from oracle import certificates as ct
 
-    f32 = views[0].element_size() == 4
+    f32 = (views[0].element_size() if hasattr(views[0], "element_size") else views[0].itemsize) == 4   # torch tensor | ndarray
     tol = 1e-3 if f32 else 1e-7
     rep = {"tol": tol}
     ok = True

@@ -69,3 +69,31 @@ def test_loss_from_moments_equals_the_closed_form():
     assert abs(l - l2) < 1e-12 * abs(l)
     g = (Z - mean) @ Gamma
     assert np.abs(g[:, :11] - g1).max() < 1e-12 and np.abs(g[:, 11:] - g2).max() < 1e-12
+
+
+def test_bench_solution_gate_accepts_fits_and_rejects_perturbed_ones(monkeypatch):
+    """bench.py's gate of the extras (pencil certificate on the moments of the timed views) on the host double: the
+    estimators' own solutions pass for rCCA / MCCA / GCCA, the same models with one weight column disturbed -- or with
+    the two leading columns swapped -- fail.  (On the GPU the gate runs on device moments; the logic is the same code.)"""
+    import bench
+    from cca_zoo_amd import _backend
+    from cca_zoo_amd.linear import GCCA, MCCA, rCCA
+    from oracle import reference_form as rf
+
+    h = hostsim_handle()
+    monkeypatch.setattr(_backend, "default_handle", lambda device=None: h)
+    monkeypatch.setattr(_backend, "handle_for", lambda arrays: h)
+    views = rf.joint_data(3, 400, 4, [14, 11, 9], 2.0, 3)
+    cases = (("rcca", rCCA(latent_dimensions=3, c=0.1), views[:2], 0.1),
+             ("mcca", MCCA(latent_dimensions=3, c=0.2), views, 0.2),
+             ("gcca", GCCA(latent_dimensions=3, c=0.1), views, 0.1))
+    for est, model, vs, c in cases:
+        model.fit(vs)
+        good = bench.solution_gate(model, vs, est, c)
+        assert good["ok"] and good["pencil_eigenvalues_above_lambda_k"] == 3, (est, good)
+        keep = [w.copy() for w in model.weights_]
+        model.weights_[0][:, 1] *= 1.0 + 1e-3                      # a slightly wrong direction / normalisation
+        assert not bench.solution_gate(model, vs, est, c)["ok"], est
+        model.weights_ = [w[:, [1, 0, 2]].copy() for w in keep]    # right subspace, wrong order of the pairs
+        assert not bench.solution_gate(model, vs, est, c)["ok"], est
+        model.weights_ = keep
