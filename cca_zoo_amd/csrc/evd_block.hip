@@ -1,0 +1,544 @@
+// Blocked Jacobi for the dense symmetric EVD / SVD seams above the one-workgroup kernels (d > 160).
+//
+// Reference call sites: numpy.linalg.svd behind svd_whiten (cca_zoo/_utils/_linalg.py:28-40), torch.linalg.eigh
+// behind _inv_sqrtm (cca_zoo/deep/objectives.py:9-21, deep/_base.py:176-188) and _BatchWhiten
+// (cca_zoo/deep/_dcca_noi.py:62-67), numpy.linalg.svd(cross_cov) (cca_zoo/linear/_rcca.py:97).
+//
+// Scalar cyclic Jacobi is a chain of ~ sweeps * d dependent rotation rounds whatever the blocking; what the
+// blocking decides is where the O(d^3) of work per sweep runs.  Here a round of the OUTER tournament pairs the
+// d / 32 column blocks (32 wide) into d / 64 disjoint pairs and splits into two launches:
+//
+//   k_bj_inner   one workgroup per block pair: the pair's 64 x 64 symmetric matrix S (two-sided form: gathered from A;
+//                one-sided form: the Gram matrix of the pair's 64 rows of W) lives in LDS as its packed lower
+//                triangle; 32 rounds of 32 simultaneous rotations annihilate the CROSS block only (pairs (i, 32 +
+//                (i + r) mod 32): every element pair of the two blocks exactly once) -- in the first outer round of a
+//                sweep a full 63-round tournament instead, which also covers the pairs inside each block.  The
+//                accumulated rotation R (64 x 64) is kept transposed in LDS and written out; no O(d) work here.
+//   k_bj_apply   every other tile of the matrix takes  A_KL <- R_K' A_KL R_L  (two 64^3 products on
+//                v_mfma_f64_16x16x4_f64, the second one with the first one's accumulators as its B fragments) and the
+//                eigenvector rows  V'[K] <- R_K' V'[K]: all of the O(d^3) work is MFMA work on 64-wide tiles, one
+//                launch per round, in place (block pairs are disjoint).
+//
+// A is kept in "block-upper" canonical form: 32 x 32 sub-block (x, y), x < y, is stored at its natural place, the
+// mirrored one is never read or written (tiles transpose on load / store), diagonal sub-blocks are stored whole.
+// One sweep = d / 32 - 1 rounds = one hipGraph, replayed per sweep; the host reads one rotation counter per sweep.
+// The one-sided form (thin SVD: rows of W orthogonalised, ccz_gesvj) shares k_bj_inner and the row-tile half of
+// k_bj_apply; its Gram blocks come from k_bj_gram (split over the row length, partials summed in a fixed order).
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "hip_common.h"
+#include "jacobi_dev.h"
+
+namespace ccz {
+
+namespace {
+
+constexpr int BJB = 32;                        // block edge
+constexpr int BJP = 64;                        // pair edge
+constexpr int BJ_NH = BJP * (BJP + 1) / 2;     // packed lower triangle of the pair matrix
+constexpr int BJ_THREADS = 576;                // 9 waves: 528 blocks of S in stage A; wave 0 parameters + waves 1..8 R in stage B
+constexpr int AP_SX = 66;                      // LDS row stride (doubles) for A-fragment reads  (= 2 mod 32)
+constexpr int AP_SB = 80;                      // LDS row stride for B-fragment reads            (= 16 mod 32)
+constexpr double BJ_EPS = 2.220446049250313e-16;
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+typedef double v2f64 __attribute__((ext_vector_type(2)));
+
+struct BjStatus {       // device-resident
+  int rotations;        // of the sweep in flight
+  int bad;              // non-finite input
+  double hmax;          // max |A| (two-sided) / largest squared row norm (one-sided), as set by the prep kernels
+};
+
+__device__ __forceinline__ void bj_pair(int full, int r, int k, int& p, int& q) {
+  if (full) { pair_of(r, k, BJP - 1, p, q); return; }
+  p = k;
+  q = BJB + ((k + r) & (BJB - 1));
+}
+
+// MODE 0: two-sided; S gathered from the canonical symmetric A, written back; rotate when |s_pq| > eps * max|A|
+// MODE 1: one-sided; S = sum of the `nsplit` Gram partials of this pair, not written back; rotate when
+//         |g_pq| > tol * sqrt(g_pp g_qq) and both squared norms exceed the floor (numerically zero rows rest)
+template <int MODE>
+__global__ __launch_bounds__(BJ_THREADS) void k_bj_inner(double* __restrict__ A, int64_t lda, const double* __restrict__ G,
+                                                         int nsplit, double* __restrict__ Rt_out, BjStatus* __restrict__ st,
+                                                         int nb, int round, int full, double tol) {
+  __shared__ __attribute__((aligned(16))) double Hs[BJ_NH];
+  __shared__ __attribute__((aligned(16))) double Rt[BJP * BJP];     // Rt[j][i] = R[i][j]
+  __shared__ __attribute__((aligned(16))) jac_cs csn[2][BJB];
+  __shared__ int rot;
+  const int tid = threadIdx.x;
+  int ba, bb;
+  pair_of(round, blockIdx.x, nb - 1, ba, bb);
+  const double hmax = st->hmax;
+  if (!(hmax > 0.0) || !(hmax < __builtin_inf())) {                 // zero or non-finite input: identity, nothing rotates
+    for (int e = tid; e < BJP * BJP; e += BJ_THREADS) Rt_out[int64_t(blockIdx.x) * (BJP * BJP) + e] = ((e >> 6) == (e & 63)) ? 1.0 : 0.0;
+    if (tid == 0 && !(hmax < __builtin_inf())) st->bad = 1;
+    return;
+  }
+  for (int e = tid; e < BJ_NH; e += BJ_THREADS) {
+    int i, j;
+    tri_decode(e, i, j);                                            // j <= i
+    double h;
+    if (MODE == 0) {
+      const int bi = i < BJB ? ba : bb, bj = j < BJB ? ba : bb, ii = i & (BJB - 1), jj = j & (BJB - 1);
+      h = (bi <= bj) ? A[(int64_t(bi) * BJB + ii) * lda + bj * BJB + jj] : A[(int64_t(bj) * BJB + jj) * lda + bi * BJB + ii];
+    } else {
+      h = 0.0;
+      const double* g = G + int64_t(blockIdx.x) * nsplit * (BJP * BJP) + i * BJP + j;
+      for (int s = 0; s < nsplit; ++s) h += g[int64_t(s) * (BJP * BJP)];
+    }
+    Hs[e] = h;
+  }
+  for (int e = tid; e < BJP * BJP; e += BJ_THREADS) Rt[e] = ((e >> 6) == (e & 63)) ? 1.0 : 0.0;
+  if (tid == 0) rot = 0;
+  const double thr = MODE == 0 ? BJ_EPS * hmax : 0.0, ih = 1.0 / hmax, floor2 = hmax * 1e-28;
+  // roles: S blocks (ka >= kb) on threads 0..527; R items (pair k, rows 4 g .. 4 g + 3) on threads 64..575
+  int ka = 0, kb = 0;
+  const bool son = tid < BJB * (BJB + 1) / 2;
+  if (son) tri_decode(tid, ka, kb);
+  const int item = tid - 64, rk = item >> 4, rg = (item & 15) * 4;
+  const int nr = full ? BJP - 1 : BJB;
+
+  auto params = [&](int r, int buf) {                               // lanes 0..31 of wave 0
+    int a, b;
+    bj_pair(full, r, tid, a, b);
+    const double hpq = Hs[tri_off(a, b)], hqq = Hs[tri_off(b, b)], hpp = Hs[tri_off(a, a)];
+    jac_cs cs = {1.0, 0.0};
+    bool go;
+    if (MODE == 0) go = fabs(hpq) > thr;
+    else go = hpp > floor2 && hqq > floor2 && hpq * hpq > tol * tol * hpp * hqq;
+    if (go) {
+      cs = jac_rotation(hpp, hqq, hpq, ih);
+      atomicAdd(&rot, 1);
+    }
+    csn[buf][tid] = cs;
+  };
+
+  __syncthreads();
+  if (tid < BJB) params(0, 0);
+  __syncthreads();
+  for (int r = 0; r < nr; ++r) {
+    const jac_cs* cur = csn[r & 1];
+    // ---- stage A: S <- J' S J on the packed lower triangle ----
+    if (son) {
+      int p1, q1, p2, q2;
+      bj_pair(full, r, ka, p1, q1);
+      bj_pair(full, r, kb, p2, q2);
+      const int o0 = tri_off(p1, p2), o1 = tri_off(p1, q2), o2 = tri_off(q1, p2), o3 = tri_off(q1, q2);
+      const jac_cs ra = cur[ka], rb = cur[kb];
+      const double m0 = Hs[o0], m1 = Hs[o1], m2 = Hs[o2], m3 = Hs[o3];
+      const double ca = ra.x, sa = ra.y, cb = rb.x, sb = rb.y;
+      const double n00 = cb * m0 - sb * m1, n01 = sb * m0 + cb * m1;
+      const double n10 = cb * m2 - sb * m3, n11 = sb * m2 + cb * m3;
+      double o00 = ca * n00 - sa * n10, o10 = sa * n00 + ca * n10;
+      double o01 = ca * n01 - sa * n11, o11 = sa * n01 + ca * n11;
+      if (ka == kb && sa != 0.0) { o01 = 0.0; o10 = 0.0; }          // the rotated pair itself (one storage cell)
+      Hs[o0] = o00; Hs[o1] = o01; Hs[o2] = o10; Hs[o3] = o11;
+    }
+    lds_barrier();
+    // ---- stage B: wave 0 derives the next round's rotations from the new S; waves 1..8 apply this round's to R ----
+    if (tid < 64) {
+      if (tid < BJB && r + 1 < nr) params(r + 1, (r & 1) ^ 1);
+    } else {
+      int p, q;
+      bj_pair(full, r, rk, p, q);
+      const jac_cs cs = cur[rk];
+      double* xp = Rt + p * BJP + rg;
+      double* xq = Rt + q * BJP + rg;
+      const v2f64 x0 = *reinterpret_cast<v2f64*>(xp), x1 = *reinterpret_cast<v2f64*>(xp + 2);
+      const v2f64 y0 = *reinterpret_cast<v2f64*>(xq), y1 = *reinterpret_cast<v2f64*>(xq + 2);
+      if (cs.y != 0.0) {
+        *reinterpret_cast<v2f64*>(xp) = cs.x * x0 - cs.y * y0;
+        *reinterpret_cast<v2f64*>(xp + 2) = cs.x * x1 - cs.y * y1;
+        *reinterpret_cast<v2f64*>(xq) = cs.y * x0 + cs.x * y0;
+        *reinterpret_cast<v2f64*>(xq + 2) = cs.y * x1 + cs.x * y1;
+      }
+    }
+    lds_barrier();
+  }
+  __syncthreads();
+  if (MODE == 0) {
+    for (int e = tid; e < BJP * BJP; e += BJ_THREADS) {             // whole diagonal sub-blocks + the canonical cross block
+      const int i = e >> 6, j = e & 63;
+      const int bi = i < BJB ? ba : bb, bj = j < BJB ? ba : bb;
+      if (bi > bj) continue;                                        // the mirrored cross block is not stored
+      A[(int64_t(bi) * BJB + (i & (BJB - 1))) * lda + bj * BJB + (j & (BJB - 1))] = Hs[tri_off(i, j)];
+    }
+  }
+  double* ro = Rt_out + int64_t(blockIdx.x) * (BJP * BJP);
+  for (int e = tid; e < BJP * BJP; e += BJ_THREADS) ro[e] = Rt[e];
+  if (tid == 0 && rot > 0) atomicAdd(&st->rotations, rot);
+}
+
+// ---- the O(d^3) half: tiles on the fp64 matrix pipe -------------------------------------------------------------
+// blocks [0, nA): symmetric tiles (K < L) of A;  blocks [nA, nA + nV): row tiles of up to two row-major matrices
+// (V' for the two-sided form; W and Q for the one-sided form), 64 rows (the pair's two 32-row groups) x 64 columns.
+struct BjRows {
+  double* M[2];
+  int64_t ld[2];
+  int chunks[2];          // ceil(cols / 64)
+  int64_t cols[2];
+};
+
+__global__ __launch_bounds__(256, 2) void k_bj_apply(double* __restrict__ A, int64_t lda, BjRows rows, const double* __restrict__ Rt_all,
+                                                     int nb, int round, int nA) {
+  extern __shared__ __attribute__((aligned(16))) char bj_smem[];
+  double* X = reinterpret_cast<double*>(bj_smem);                   // 64 x 80
+  double* Rs = X + BJP * AP_SB;                                     // 64 x 66
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4, cw = wave * 16;
+  const int m1 = nb - 1;
+  v4f64 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = v4f64{0.0, 0.0, 0.0, 0.0};
+
+  if (int(blockIdx.x) < nA) {
+    int ti, tj;
+    tri_decode(blockIdx.x, ti, tj);
+    const int K = tj, L = ti + 1;                                   // K < L
+    int bk[2], bl[2];
+    pair_of(round, K, m1, bk[0], bk[1]);
+    pair_of(round, L, m1, bl[0], bl[1]);
+    // X (64 x 64, stride 66) <- the four sub-blocks, transposing the ones whose canonical copy is the mirrored one
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int si = s >> 1, sj = s & 1, x = bk[si], y = bl[sj];
+      const bool direct = x < y;
+      const double* base = direct ? A + int64_t(x) * BJB * lda + y * BJB : A + int64_t(y) * BJB * lda + x * BJB;
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int piece = tid + 256 * it, row = piece >> 4, c2 = (piece & 15) * 2;
+        const v2f64 v = *reinterpret_cast<const v2f64*>(base + int64_t(row) * lda + c2);
+        if (direct) {
+          *reinterpret_cast<v2f64*>(X + (BJB * si + row) * AP_SX + BJB * sj + c2) = v;
+        } else {
+          X[(BJB * si + c2) * AP_SX + BJB * sj + row] = v.x;
+          X[(BJB * si + c2 + 1) * AP_SX + BJB * sj + row] = v.y;
+        }
+      }
+    }
+    const double* rl = Rt_all + int64_t(L) * (BJP * BJP);
+    const double* rkp = Rt_all + int64_t(K) * (BJP * BJP);
+    v2f64 pre[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int piece = tid + 256 * it, row = piece >> 5, c2 = (piece & 31) * 2;
+      *reinterpret_cast<v2f64*>(Rs + row * AP_SX + c2) = *reinterpret_cast<const v2f64*>(rl + row * BJP + c2);
+      pre[it] = *reinterpret_cast<const v2f64*>(rkp + row * BJP + c2);
+    }
+    __syncthreads();
+    // Y[:, cw .. cw+15] = X R_L :  A fragment X[m][k], B fragment R_L[k][n] = Rt_L[n][k]
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const double b = Rs[(cw + l15) * AP_SX + 4 * ks + l4];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const double a = X[(16 * mt + l15) * AP_SX + 4 * ks + l4];
+        acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[mt], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int piece = tid + 256 * it, row = piece >> 5, c2 = (piece & 31) * 2;
+      *reinterpret_cast<v2f64*>(Rs + row * AP_SX + c2) = pre[it];
+    }
+    __syncthreads();
+    // Z[:, cw ..] = R_K' Y :  A fragment Rt_K[m][k]; B fragment of k-step ks = Y rows 4 ks .. 4 ks + 3 = accumulator
+    // register (ks & 3) of row tile (ks >> 2)  (C layout of v_mfma_f64_16x16x4: row = (lane >> 4) + 4 reg)
+    v4f64 z[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) z[t] = v4f64{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const double b = acc[ks >> 2][ks & 3];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const double a = Rs[(16 * mt + l15) * AP_SX + 4 * ks + l4];
+        z[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, z[mt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) X[(16 * mt + l4 + 4 * r) * AP_SX + cw + l15] = z[mt][r];
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int si = s >> 1, sj = s & 1, x = bk[si], y = bl[sj];
+      const bool direct = x < y;
+      double* base = direct ? A + int64_t(x) * BJB * lda + y * BJB : A + int64_t(y) * BJB * lda + x * BJB;
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int piece = tid + 256 * it, row = piece >> 4, c2 = (piece & 15) * 2;
+        v2f64 v;
+        if (direct) {
+          v = *reinterpret_cast<const v2f64*>(X + (BJB * si + row) * AP_SX + BJB * sj + c2);
+        } else {
+          v.x = X[(BJB * si + c2) * AP_SX + BJB * sj + row];
+          v.y = X[(BJB * si + c2 + 1) * AP_SX + BJB * sj + row];
+        }
+        *reinterpret_cast<v2f64*>(base + int64_t(row) * lda + c2) = v;
+      }
+    }
+    return;
+  }
+
+  // ---- row tile: M[rows of pair K, 64 columns] <- R_K' M[...] ----
+  int t = int(blockIdx.x) - nA;
+  const int np = nb >> 1;
+  int which = 0;
+  if (t >= np * rows.chunks[0]) { t -= np * rows.chunks[0]; which = 1; }
+  const int nch = rows.chunks[which];
+  const int K = t / nch, ch = t - K * nch;
+  double* M = rows.M[which];
+  const int64_t ld = rows.ld[which], c0 = int64_t(ch) * 64, ncol = rows.cols[which];
+  int bk[2];
+  pair_of(round, K, m1, bk[0], bk[1]);
+  const double* rkp = Rt_all + int64_t(K) * (BJP * BJP);
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int piece = tid + 256 * it, row = piece >> 5, c2 = (piece & 31) * 2;
+    *reinterpret_cast<v2f64*>(Rs + row * AP_SX + c2) = *reinterpret_cast<const v2f64*>(rkp + row * BJP + c2);
+    const int64_t grow = int64_t(bk[row >> 5]) * BJB + (row & (BJB - 1));
+    v2f64 v = {0.0, 0.0};
+    if (c0 + c2 + 1 < ncol) v = *reinterpret_cast<const v2f64*>(M + grow * ld + c0 + c2);
+    else if (c0 + c2 < ncol) v.x = M[grow * ld + c0 + c2];
+    *reinterpret_cast<v2f64*>(X + row * AP_SB + c2) = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    const double b = X[(4 * ks + l4) * AP_SB + cw + l15];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const double a = Rs[(16 * mt + l15) * AP_SX + 4 * ks + l4];
+      acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[mt], 0, 0, 0);
+    }
+  }
+  const int64_t gc = c0 + cw + l15;
+  if (gc < ncol) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * mt + l4 + 4 * r;
+        const int64_t grow = int64_t(bk[row >> 5]) * BJB + (row & (BJB - 1));
+        M[grow * ld + gc] = acc[mt][r];
+      }
+  }
+}
+
+// ---- one-sided form: Gram blocks of the pairs' rows, split over the row length --------------------------------------
+// grid (pairs, nsplit): G[pair][split] (64 x 64, full) = W_K[:, slice] W_K[:, slice]'
+__global__ __launch_bounds__(256, 2) void k_bj_gram(const double* __restrict__ W, int64_t ldw, int64_t q, int nb, int round, int nsplit,
+                                                    double* __restrict__ G) {
+  __shared__ __attribute__((aligned(16))) double Xs[BJP * AP_SX];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4, cw = wave * 16;
+  int bk[2];
+  pair_of(round, blockIdx.x, nb - 1, bk[0], bk[1]);
+  const int64_t nchunks = (q + 63) / 64;
+  const int64_t per = (nchunks + nsplit - 1) / nsplit;
+  const int64_t ch0 = int64_t(blockIdx.y) * per, ch1 = min(nchunks, ch0 + per);
+  v4f64 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = v4f64{0.0, 0.0, 0.0, 0.0};
+  for (int64_t ch = ch0; ch < ch1; ++ch) {
+    const int64_t c0 = ch * 64;
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int piece = tid + 256 * it, row = piece >> 5, c2 = (piece & 31) * 2;
+      const int64_t grow = int64_t(bk[row >> 5]) * BJB + (row & (BJB - 1));
+      v2f64 v = {0.0, 0.0};
+      if (c0 + c2 + 1 < q) v = *reinterpret_cast<const v2f64*>(W + grow * ldw + c0 + c2);
+      else if (c0 + c2 < q) v.x = W[grow * ldw + c0 + c2];
+      *reinterpret_cast<v2f64*>(Xs + row * AP_SX + c2) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const double b = Xs[(cw + l15) * AP_SX + 4 * ks + l4];        // B[k][n] = W_K[n][k]
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const double a = Xs[(16 * mt + l15) * AP_SX + 4 * ks + l4];
+        acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[mt], 0, 0, 0);
+      }
+    }
+  }
+  double* g = G + (int64_t(blockIdx.x) * nsplit + blockIdx.y) * (BJP * BJP);
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) g[(16 * mt + l4 + 4 * r) * BJP + cw + l15] = acc[mt][r];
+}
+
+// ---- preparation / extraction -----------------------------------------------------------------------------------
+__device__ __forceinline__ void atomic_max_nonneg(double* addr, double v) {   // v >= 0 or non-finite (NaN -> inf)
+  if (!(v <= 1.79769313486231570e308)) v = __builtin_inf();
+  atomicMax(reinterpret_cast<unsigned long long*>(addr), static_cast<unsigned long long>(__double_as_longlong(v)));
+}
+
+// Aw (dp x dp, canonical + whole diagonal sub-blocks; everything is written) <- (A + A') / 2, zero padded; Vt <- I
+__global__ __launch_bounds__(256) void k_bj_prep_sym(const double* __restrict__ A, int64_t lda, int64_t d, int64_t dp, double* __restrict__ Aw,
+                                                     double* __restrict__ Vt, BjStatus* __restrict__ st) {
+  __shared__ double red[4];
+  double mx = 0.0;
+  const int64_t total = dp * dp;
+  for (int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x; e < total; e += int64_t(gridDim.x) * 256) {
+    const int64_t i = e / dp, j = e - i * dp;
+    double h = 0.0;
+    if (i < d && j < d) {
+      h = 0.5 * (A[i * lda + j] + A[j * lda + i]);
+      const double a = fabs(h);
+      mx = (a <= 1.79769313486231570e308) ? fmax(mx, a) : __builtin_inf();
+    }
+    Aw[e] = h;
+    Vt[e] = (i == j) ? 1.0 : 0.0;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) atomic_max_nonneg(&st->hmax, fmax(fmax(red[0], red[1]), fmax(red[2], red[3])));
+}
+
+// one-sided: hmax <- largest squared row norm of W (p x q); one wave per row
+__global__ __launch_bounds__(64) void k_bj_prep_rows(const double* __restrict__ W, int64_t ldw, int64_t q, BjStatus* __restrict__ st) {
+  const double* w = W + int64_t(blockIdx.x) * ldw;
+  double s = 0.0;
+  for (int64_t t = threadIdx.x; t < q; t += 64) { const double x = w[t]; s += x * x; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (threadIdx.x == 0) atomic_max_nonneg(&st->hmax, s);
+}
+
+__global__ void k_bj_diag(const double* __restrict__ Aw, int64_t dp, int64_t d, double* __restrict__ w) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < d) w[i] = Aw[i * dp + i];
+}
+
+int bj_max_gram_split() {
+  static const int v = [] { const char* e = getenv("CCZ_BJ_GRAM_SPLIT"); return e ? std::max(1, atoi(e)) : 0; }();
+  return v;
+}
+
+struct StatusBuf {
+  ccz_ctx* c;
+  BjStatus* dev;
+  explicit StatusBuf(ccz_ctx* c_) : c(c_), dev(static_cast<BjStatus*>(dev_alloc(c_, sizeof(BjStatus)))) {}
+  ~StatusBuf() { dev_free(c, dev); }
+};
+
+constexpr size_t kApplyLds = size_t(BJP) * (AP_SB + AP_SX) * 8;     // 74752 B: two workgroups per CU
+
+void apply_attr_once() {
+  static const bool done = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bj_apply), hipFuncAttributeMaxDynamicSharedMemorySize, int(kApplyLds));
+    return true;
+  }();
+  (void)done;
+}
+
+}  // namespace
+
+int syev_block_min(ccz_ctx*) { return 2; }
+
+// Two-sided block Jacobi: A (d x d, only read, symmetrised on load) -> w_dev (d, unsorted), rows of Vrows = eigenvectors
+int syev_block(ccz_ctx* c, const double* A, int64_t d, int64_t lda, double* w_dev, double* Vrows, int64_t ldv, int max_sweeps) {
+  if (d < 1) fail(CCZ_EINVAL, "syev_block: d >= 1 required");
+  const int64_t dp = (d + BJP - 1) / BJP * BJP;
+  const int nb = int(dp / BJB), np = nb / 2;
+  DBuf Aw(c, dp * dp), Vt(c, dp * dp), Rt(c, int64_t(np) * BJP * BJP);
+  StatusBuf sb(c);
+  hipStream_t st = stream(c);
+  apply_attr_once();
+  CCZ_HIP(hipMemsetAsync(sb.dev, 0, sizeof(BjStatus), st));
+  hipLaunchKernelGGL(k_bj_prep_sym, dim3((unsigned)std::min<int64_t>((dp * dp + 255) / 256, 4096)), dim3(256), 0, st, A, lda, d, dp,
+                     Aw.get(), Vt.get(), sb.dev);
+  CCZ_LAUNCH_CHECK();
+  const int nA = np * (np - 1) / 2, vch = int(dp / 64);
+  BjRows rows{};
+  rows.M[0] = Vt.get(); rows.ld[0] = dp; rows.chunks[0] = vch; rows.cols[0] = dp;
+  rows.M[1] = nullptr; rows.ld[1] = 0; rows.chunks[1] = 0; rows.cols[1] = 0;
+  const int nV = np * vch;
+  uint64_t key = graph_key_mix(graph_key_mix(0x424a5359ull, uint64_t(dp)), reinterpret_cast<uint64_t>(Aw.get()));
+  key = graph_key_mix(graph_key_mix(key, reinterpret_cast<uint64_t>(Vt.get())), reinterpret_cast<uint64_t>(Rt.get()));
+  key = graph_key_mix(key, reinterpret_cast<uint64_t>(sb.dev));
+  int sweeps = -1;
+  for (int sweep = 1; sweep <= max_sweeps; ++sweep) {
+    CCZ_HIP(hipMemsetAsync(&sb.dev->rotations, 0, sizeof(int), st));
+    graph_run_fn(c, key, [&] {
+      for (int round = 0; round < nb - 1; ++round) {
+        hipLaunchKernelGGL(k_bj_inner<0>, dim3(np), dim3(BJ_THREADS), 0, st, Aw.get(), dp, (const double*)nullptr, 0, Rt.get(), sb.dev, nb,
+                           round, round == 0 ? 1 : 0, 0.0);
+        hipLaunchKernelGGL(k_bj_apply, dim3(nA + nV), dim3(256), kApplyLds, st, Aw.get(), dp, rows, (const double*)Rt.get(), nb, round, nA);
+      }
+      CCZ_LAUNCH_CHECK();
+    });
+    BjStatus h{};
+    d2h(c, &h, sb.dev, sizeof(BjStatus));
+    if (h.bad || !(h.hmax < INFINITY)) fail(CCZ_EINVAL, "syev: matrix has non-finite entries");
+    if (h.rotations == 0) { sweeps = sweep; break; }
+  }
+  if (sweeps < 0) fail(CCZ_ENOCONV, "block Jacobi did not converge in %d sweeps (d=%lld)", max_sweeps, (long long)d);
+  hipLaunchKernelGGL(k_bj_diag, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st, (const double*)Aw.get(), dp, d, w_dev);
+  CCZ_LAUNCH_CHECK();
+  if (Vrows) copy2d(c, d, d, Vt.get(), dp, Vrows, ldv);
+  return sweeps;
+}
+
+// One-sided block Jacobi on the ROWS of W (p x q, p a multiple of 64 -- the caller pads with zero rows): the rows
+// end up mutually orthogonal; the same rotations go to the rows of Q (p x qc) when Q != null.
+int jacobi_rows_block(ccz_ctx* c, int64_t p, int64_t q, double* W, int64_t ldw, double* Q, int64_t qc, int64_t ldq, int max_sweeps) {
+  if (p < BJP || p % BJP != 0) fail(CCZ_EINVAL, "jacobi_rows_block: p must be a positive multiple of 64");
+  const int nb = int(p / BJB), np = nb / 2;
+  int nsplit = bj_max_gram_split();
+  if (nsplit <= 0) {                                   // fill the chip: pairs x splits ~ 512 workgroups, >= 4 chunks of 64 per split
+    const int64_t nchunks = (q + 63) / 64;
+    nsplit = int(std::max<int64_t>(1, std::min<int64_t>(nchunks / 4, (512 + np - 1) / np)));
+  }
+  DBuf Rt(c, int64_t(np) * BJP * BJP), G(c, int64_t(np) * nsplit * BJP * BJP);
+  StatusBuf sb(c);
+  hipStream_t st = stream(c);
+  apply_attr_once();
+  CCZ_HIP(hipMemsetAsync(sb.dev, 0, sizeof(BjStatus), st));
+  hipLaunchKernelGGL(k_bj_prep_rows, dim3((unsigned)p), dim3(64), 0, st, (const double*)W, ldw, q, sb.dev);
+  CCZ_LAUNCH_CHECK();
+  BjRows rows{};
+  rows.M[0] = W; rows.ld[0] = ldw; rows.chunks[0] = int((q + 63) / 64); rows.cols[0] = q;
+  rows.M[1] = Q; rows.ld[1] = ldq; rows.chunks[1] = Q ? int((qc + 63) / 64) : 0; rows.cols[1] = Q ? qc : 0;
+  const int nV = np * (rows.chunks[0] + rows.chunks[1]);
+  const double tol = BJ_EPS * std::sqrt(double(q)) * 4.0;
+  uint64_t key = graph_key_mix(graph_key_mix(0x424a4f53ull, uint64_t(p)), uint64_t(q));
+  key = graph_key_mix(graph_key_mix(key, reinterpret_cast<uint64_t>(W)), reinterpret_cast<uint64_t>(Q));
+  key = graph_key_mix(graph_key_mix(key, uint64_t(ldw)), uint64_t(ldq));
+  key = graph_key_mix(graph_key_mix(key, uint64_t(qc)), reinterpret_cast<uint64_t>(Rt.get()));
+  key = graph_key_mix(graph_key_mix(key, reinterpret_cast<uint64_t>(G.get())), reinterpret_cast<uint64_t>(sb.dev));
+  key = graph_key_mix(key, uint64_t(nsplit));
+  for (int sweep = 1; sweep <= max_sweeps; ++sweep) {
+    CCZ_HIP(hipMemsetAsync(&sb.dev->rotations, 0, sizeof(int), st));
+    graph_run_fn(c, key, [&] {
+      for (int round = 0; round < nb - 1; ++round) {
+        hipLaunchKernelGGL(k_bj_gram, dim3(np, nsplit), dim3(256), 0, st, (const double*)W, ldw, q, nb, round, nsplit, G.get());
+        hipLaunchKernelGGL(k_bj_inner<1>, dim3(np), dim3(BJ_THREADS), 0, st, (double*)nullptr, int64_t(0), (const double*)G.get(), nsplit,
+                           Rt.get(), sb.dev, nb, round, round == 0 ? 1 : 0, tol);
+        hipLaunchKernelGGL(k_bj_apply, dim3(nV), dim3(256), kApplyLds, st, (double*)nullptr, int64_t(0), rows, (const double*)Rt.get(), nb,
+                           round, 0);
+      }
+      CCZ_LAUNCH_CHECK();
+    });
+    BjStatus h{};
+    d2h(c, &h, sb.dev, sizeof(BjStatus));
+    if (h.bad || !(h.hmax < INFINITY)) fail(CCZ_EINVAL, "gesvj: matrix has non-finite entries");
+    if (h.rotations == 0) return sweep;
+  }
+  fail(CCZ_ENOCONV, "block Jacobi did not converge in %d sweeps (p=%lld, q=%lld)", max_sweeps, (long long)p, (long long)q);
+}
+
+}  // namespace ccz

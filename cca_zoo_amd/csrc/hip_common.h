@@ -80,6 +80,14 @@ inline hipStream_t stream(ccz_ctx* c) { return static_cast<hipStream_t>(c->strea
 
 #define CCZ_LAUNCH_CHECK() CCZ_HIP(hipGetLastError())
 
+// ops_hip.hip: capture-once / replay-later for launch-bound fixed sequences, keyed on shapes AND pointers
+uint64_t graph_key_mix(uint64_t h, uint64_t v);
+void graph_run_fn(ccz_ctx* c, uint64_t key, const std::function<void()>& fn);
+void sync_short(ccz_ctx* c);   // polled wait for the handle's stream (short waits)
+
+// evd_block.hip: one-sided block Jacobi on the rows of W (p a multiple of 64, even leading dimensions)
+int jacobi_rows_block(ccz_ctx* c, int64_t p, int64_t q, double* W, int64_t ldw, double* Q, int64_t qc, int64_t ldq, int max_sweeps);
+
 // gram.hip
 // pilot_mode: 0 never / 1 automatic (one small host read-back) / 2 always (no host sync) -- fp32 views only;
 // time_it: record HIP events around the Gram and column-sum kernels (costs a host wait at the end)

@@ -180,6 +180,12 @@ int jacobi_rows(ccz_ctx* c, int64_t p, int64_t q, double* W, int64_t ldw, double
 int syev_small_max(ccz_ctx* c);
 int syev_small(ccz_ctx* c, const double* A, int64_t d, int64_t lda, double* w_dev, double* Vrows, int64_t ldv,
                int max_sweeps);
+// Two-sided BLOCK Jacobi EVD for the sizes above syev_small_max (HIP backend: evd_block.hip -- 32-wide column blocks,
+// the pair sub-problems in LDS, every O(d^3) update as 64-wide tiles on the fp64 matrix pipe).  A (d x d) is only read
+// and symmetrised on load; w_dev[i] = eigenvalue i (unsorted), row i of Vrows (ld ldv) = its eigenvector.  Returns
+// sweeps; EINVAL on non-finite input, ENOCONV beyond max_sweeps.
+int syev_block(ccz_ctx* c, const double* A, int64_t d, int64_t lda, double* w_dev, double* Vrows, int64_t ldv,
+               int max_sweeps);
 // out[i] = dot(A[i,:], B[i,:]) for i < rows
 void row_dots(ccz_ctx* c, int64_t rows, int64_t cols, const double* A, int64_t lda,
               const double* B, int64_t ldb, double* out);

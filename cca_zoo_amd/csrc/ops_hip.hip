@@ -15,6 +15,7 @@
 #include <cstring>
 
 #include "hip_common.h"
+#include "jacobi_dev.h"
 #include "rng_hash.h"
 
 namespace ccz {
@@ -1126,6 +1127,10 @@ static void graph_run(ccz_ctx* c, uint64_t key, F&& fn) {
   CCZ_HIP(hipGraphLaunch(exec, st));
 }
 
+// the same for other translation units (evd_block.hip): key helpers + a type-erased entry
+uint64_t graph_key_mix(uint64_t h, uint64_t v) { return key_mix(h, v); }
+void graph_run_fn(ccz_ctx* c, uint64_t key, const std::function<void()>& fn) { graph_run(c, key, fn); }
+
 // ---- iterative (one 64-column panel at a time) variants: fewer, smaller launches ----
 static void potrf_lower_batched_iter(ccz_ctx* c, int count, double* const* A, const int64_t* d, const int64_t* lda, int* info) {
   Impl* im = impl(c);
@@ -1806,6 +1811,22 @@ int jacobi_rows(ccz_ctx* c, int64_t p, int64_t q, double* W, int64_t ldw, double
     if (sw < 0) fail(CCZ_ENOCONV, "Jacobi did not converge in %d sweeps (p=%lld, q=%lld)", max_sweeps, (long long)p, (long long)q);
     return sw;
   }
+  static const bool legacy = [] { const char* e = getenv("CCZ_EVD_LEGACY"); return e && atoi(e) != 0; }();
+  if (!legacy) {
+    // evd_block.hip: 32-row blocks, Gram blocks + rotations as MFMA tiles.  It wants a multiple of 64 rows and even
+    // leading dimensions (16-byte row pieces): pad with zero rows (they never rotate) when the caller's shape differs.
+    const int64_t pp = (p + 63) / 64 * 64;
+    if (pp == p && (ldw & 1) == 0 && (!Q || (ldq & 1) == 0)) return jacobi_rows_block(c, p, q, W, ldw, Q, qc, ldq, max_sweeps);
+    const int64_t lw = (q + 1) & ~int64_t(1), lq = (qc + 1) & ~int64_t(1);
+    DBuf Wp(c, pp * lw), Qp(c, Q ? pp * lq : 0);
+    fill2d(c, pp, lw, Wp, lw, 0.0);
+    copy2d(c, p, q, W, ldw, Wp, lw);
+    if (Q) { fill2d(c, pp, lq, Qp, lq, 0.0); copy2d(c, p, qc, Q, ldq, Qp, lq); }
+    const int sw = jacobi_rows_block(c, pp, q, Wp, lw, Q ? Qp.get() : nullptr, qc, lq, max_sweeps);
+    copy2d(c, p, q, Wp, lw, W, ldw);
+    if (Q) copy2d(c, p, qc, Qp, lq, Q, ldq);
+    return sw;
+  }
   const bool small = std::max(q, Q ? qc : 0) <= 256;
   dim3 grid((unsigned)(pe / 2));
   for (int sweep = 1; sweep <= max_sweeps; ++sweep) {
@@ -1845,41 +1866,6 @@ int jacobi_rows(ccz_ctx* c, int64_t p, int64_t q, double* W, int64_t ldw, double
 // Stopping: a sweep without a rotation; a pair is rotated when |h_pq| > tol * max|H| (absolute: the Rayleigh-Ritz
 // matrices are indefinite, zero diagonals happen -- MCCA with two views has exact +lam / -lam pairs).
 // Rows/columns are padded to an even count; the pad row/column is zero and stays zero (its pair never rotates).
-__device__ __forceinline__ double rsq_nr(double x) {
-  double y = __builtin_amdgcn_rsq(x);
-  y = y * fma(-0.5 * x * y, y, 1.5);
-  y = y * fma(-0.5 * x * y, y, 1.5);
-  return y;
-}
-__device__ __forceinline__ double rsq_nr3(double x) {      // the cosine: c^2 + s^2 = 1 must hold to rounding
-  double y = rsq_nr(x);
-  return y * fma(-0.5 * x * y, y, 1.5);
-}
-typedef double jac_cs __attribute__((ext_vector_type(2)));   // (cosine, sine) of one rotation
-__device__ __forceinline__ void pair_of(int round, int k, int m1, int& a, int& b) {
-  if (k == 0) { a = m1; b = round; return; }
-  a = round + k; if (a >= m1) a -= m1;
-  b = round - k; if (b < 0) b += m1;
-}
-
-// (c, s) of the rotation that annihilates h_pq, from the pair's three entries scaled by 1 / max|H|.
-// A dependent fp64 VALU operation costs 32 cycles on gfx950 (measured: tools/probes/clock_probe.hip), and this chain is
-// the serial part of every round, so it is written for depth, not for operation count:
-//   u = |al| / r,  r = sqrt(al^2 + h^2),  al = (h_qq - h_pp) / 2:   c = sqrt((1 + u) / 2),  s = sgn(al) h / (2 r c)
-// with two reciprocal square roots (1 / r and 1 / c) -- 18 dependent operations instead of the 31 of
-// t = h / (|al| + r), c = 1 / sqrt(1 + t^2), s = t c.  c^2 + s^2 = (1 + u)/2 + (1 - u)/2 holds to rounding.
-__device__ __forceinline__ jac_cs jac_rotation(double hpp, double hqq, double hpq, double ih) {
-  const double al = 0.5 * (hqq - hpp) * ih, hq = hpq * ih;
-  const double x = fma(al, al, hq * hq);
-  const double y = rsq_nr(x);                              // 1 / r
-  const double c2 = fma(0.5 * fabs(al), y, 0.5);           // c^2 = (1 + |al| / r) / 2  in [1/2, 1]
-  const double z = rsq_nr3(c2);                            // 1 / c
-  jac_cs r;
-  r.x = c2 * z;
-  r.y = (al >= 0.0 ? 0.5 : -0.5) * hq * y * z;
-  return r;
-}
-
 template <int NB_, int NV_>   // H blocks / V' items per thread (compile-time: the slot arrays must stay in registers)
 __device__ __forceinline__ void syev_small_body(char* smem, int d, const double* __restrict__ A, int64_t lda, double* __restrict__ w,
                                                 double* __restrict__ Vt, int64_t ldv, double tol, int max_sweeps,
@@ -2063,19 +2049,6 @@ __global__ __launch_bounds__(1024) void k_syev_small_wide(int d, const double* _
 // with a global store in flight (the rotation log) every wave would wait for its acknowledgement (~1 us) at every
 // barrier of the round loop.  The log is consumed by a later kernel, so only this wave's LDS operations must have
 // completed before the barrier.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-__device__ __forceinline__ int tri_off(int i, int j) {
-  const int hi = max(i, j), lo = min(i, j);
-  return ((hi * (hi + 1)) >> 1) + lo;
-}
-__device__ __forceinline__ void tri_decode(int e, int& i, int& j) {   // e = i (i + 1) / 2 + j, j <= i
-  i = int((sqrtf(8.0f * float(e) + 1.0f) - 1.0f) * 0.5f);
-  while (i * (i + 1) / 2 > e) --i;
-  while ((i + 1) * (i + 2) / 2 <= e) ++i;
-  j = e - i * (i + 1) / 2;
-}
-
 template <int NB_>
 __device__ __forceinline__ void syev_packed_body(char* smem, int d, const double* __restrict__ A, int64_t lda, double* __restrict__ w,
                                                  jac_cs* __restrict__ log, double tol, int max_sweeps, int* __restrict__ status) {

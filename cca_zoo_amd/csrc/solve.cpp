@@ -57,12 +57,32 @@ std::vector<int64_t> offsets(const int64_t* dims, int m) {
 // definite so that +lam / -lam pairs (MCCA with two views has them exactly)
 // cannot mix; pass psd=true to skip it and keep relative accuracy of small
 // eigenvalues of a covariance / Gram matrix.
+static bool legacy_evd() {   // CCZ_EVD_LEGACY=1: rounds 1-3's launch-per-round one-sided Jacobi above d = 160 (A/B)
+  static const bool v = [] { const char* e = getenv("CCZ_EVD_LEGACY"); return e && atoi(e) != 0; }();
+  return v;
+}
 static int syev_full_impl(ccz_ctx* c, double* A, int64_t d, bool psd, std::vector<double>& w,
                           double* Vrows, int64_t ldv) {
   if (!psd && d >= 2 && d <= syev_small_max(c)) {
     // Rayleigh-Ritz sized problems: two-sided Jacobi in one workgroup (no shift needed, no definiteness assumed)
     DBuf wd(c, d), V(c, d * d);
     const int sweeps = syev_small(c, A, d, d, wd, V, d, kMaxSweeps);
+    std::vector<double> lh(d);
+    d2h(c, lh.data(), wd, size_t(d) * 8);
+    std::vector<int64_t> perm(d);
+    std::iota(perm.begin(), perm.end(), 0);
+    std::stable_sort(perm.begin(), perm.end(), [&](int64_t a, int64_t b) { return lh[a] > lh[b]; });
+    w.resize(d);
+    for (int64_t i = 0; i < d; ++i) w[i] = lh[perm[i]];
+    if (Vrows) gather_rows(c, d, d, V, d, perm.data(), nullptr, Vrows, ldv);
+    return sweeps;
+  }
+  // PSD matrices small enough for the one-workgroup ONE-sided kernel keep it (relative accuracy of tiny eigenvalues)
+  const bool lds_one_sided = psd && size_t(2) * d * (d | 1) * 8 <= size_t(144) * 1024;
+  if (d >= 2 && !legacy_evd() && !lds_one_sided) {
+    // everything wider: two-sided block Jacobi (no shift, no definiteness assumed; A is only read)
+    DBuf wd(c, d), V(c, d * d);
+    const int sweeps = syev_block(c, A, d, d, wd, V, d, kMaxSweeps);
     std::vector<double> lh(d);
     d2h(c, lh.data(), wd, size_t(d) * 8);
     std::vector<int64_t> perm(d);

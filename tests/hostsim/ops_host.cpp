@@ -310,6 +310,148 @@ int syev_small(ccz_ctx*, const double* A, int64_t d, int64_t lda, double* w, dou
   fail(CCZ_ENOCONV, "Jacobi did not converge in %d sweeps (d=%lld)", max_sweeps, (long long)d);
 }
 
+// Two-sided BLOCK Jacobi in the device algorithm's own structure (cca_zoo_amd/csrc/evd_block.hip): 32-wide blocks,
+// round-robin tournament over the blocks, per pair a 64 x 64 sub-problem rotated CROSS-block only (a full 63-round
+// tournament in the first round of every sweep), the accumulated 64 x 64 rotation applied to the pair's rows and
+// columns of A and to the rows of V'.  Host loops over a full (uncompressed) matrix.
+namespace {
+void blk_pair_of(int round, int k, int m1, int& a, int& b) {
+  if (k == 0) { a = m1; b = round; return; }
+  a = (round + k) % m1;
+  b = ((round - k) % m1 + m1) % m1;
+}
+void blk_elem_pair(bool full, int r, int k, int& p, int& q) {
+  if (full) { blk_pair_of(r, k, 63, p, q); return; }
+  p = k;
+  q = 32 + ((k + r) & 31);
+}
+}  // namespace
+int syev_block(ccz_ctx*, const double* A, int64_t d, int64_t lda, double* w, double* Vrows, int64_t ldv, int max_sweeps) {
+  if (d < 1) fail(CCZ_EINVAL, "syev_block: d >= 1 required");
+  const int64_t dp = (d + 63) / 64 * 64;
+  const int nb = int(dp / 32), np = nb / 2;
+  std::vector<double> Aw(size_t(dp) * dp, 0.0), Vt(size_t(dp) * dp, 0.0);
+  double hmax = 0.0;
+  for (int64_t i = 0; i < dp; ++i) Vt[i * dp + i] = 1.0;
+  for (int64_t i = 0; i < d; ++i)
+    for (int64_t j = 0; j < d; ++j) {
+      const double h = 0.5 * (A[i * lda + j] + A[j * lda + i]);
+      if (!(std::fabs(h) <= 1.79769313486231570e308)) fail(CCZ_EINVAL, "syev: matrix has non-finite entries");
+      Aw[i * dp + j] = h;
+      hmax = std::max(hmax, std::fabs(h));
+    }
+  const double thr = 2.220446049250313e-16 * hmax;
+  std::vector<double> S(64 * 64), R(size_t(np) * 64 * 64), T(64 * size_t(dp));
+  std::vector<int64_t> idx(size_t(np) * 64);
+  for (int sweep = 1; sweep <= max_sweeps; ++sweep) {
+    int64_t rot = 0;
+    for (int round = 0; round < nb - 1 && hmax > 0.0; ++round) {
+      const bool full = round == 0;
+      for (int K = 0; K < np; ++K) {
+        int ba, bb;
+        blk_pair_of(round, K, nb - 1, ba, bb);
+        int64_t* ix = idx.data() + size_t(K) * 64;
+        for (int i = 0; i < 32; ++i) { ix[i] = int64_t(ba) * 32 + i; ix[32 + i] = int64_t(bb) * 32 + i; }
+        double* Rk = R.data() + size_t(K) * 4096;
+        for (int i = 0; i < 64; ++i)
+          for (int j = 0; j < 64; ++j) { S[i * 64 + j] = Aw[ix[i] * dp + ix[j]]; Rk[i * 64 + j] = i == j ? 1.0 : 0.0; }
+        const int nr = full ? 63 : 32;
+        for (int r = 0; r < nr; ++r) {
+          double cs[32], sn[32];
+          int pp[32], qq[32];
+          for (int k = 0; k < 32; ++k) {
+            blk_elem_pair(full, r, k, pp[k], qq[k]);
+            const double hpq = S[pp[k] * 64 + qq[k]];
+            cs[k] = 1.0; sn[k] = 0.0;
+            if (std::fabs(hpq) > thr) {
+              const double al = 0.5 * (S[qq[k] * 64 + qq[k]] - S[pp[k] * 64 + pp[k]]);
+              const double rr = std::sqrt(al * al + hpq * hpq);
+              const double t = (al >= 0.0 ? hpq : -hpq) / (std::fabs(al) + rr);
+              cs[k] = 1.0 / std::sqrt(1.0 + t * t);
+              sn[k] = t * cs[k];
+              ++rot;
+            }
+          }
+          for (int k = 0; k < 32; ++k) {            // columns of S and of R
+            if (sn[k] == 0.0) continue;
+            for (int i = 0; i < 64; ++i) {
+              double& x = S[i * 64 + pp[k]];
+              double& y = S[i * 64 + qq[k]];
+              const double a = x, b = y;
+              x = cs[k] * a - sn[k] * b; y = sn[k] * a + cs[k] * b;
+              double& u = Rk[i * 64 + pp[k]];
+              double& v = Rk[i * 64 + qq[k]];
+              const double e = u, f = v;
+              u = cs[k] * e - sn[k] * f; v = sn[k] * e + cs[k] * f;
+            }
+          }
+          for (int k = 0; k < 32; ++k) {            // rows of S
+            if (sn[k] == 0.0) continue;
+            for (int j = 0; j < 64; ++j) {
+              double& x = S[pp[k] * 64 + j];
+              double& y = S[qq[k] * 64 + j];
+              const double a = x, b = y;
+              x = cs[k] * a - sn[k] * b; y = sn[k] * a + cs[k] * b;
+            }
+            S[pp[k] * 64 + qq[k]] = 0.0; S[qq[k] * 64 + pp[k]] = 0.0;
+          }
+        }
+        for (int i = 0; i < 64; ++i)                // the pair's own tile: the rotated sub-problem itself
+          for (int j = 0; j < 64; ++j) Aw[ix[i] * dp + ix[j]] = 0.5 * (S[i * 64 + j] + S[j * 64 + i]);
+      }
+      // A <- Rh' A Rh off the pair tiles, V' <- Rh' V'
+      for (int K = 0; K < np; ++K) {                // columns of every other pair's rows
+        const int64_t* ix = idx.data() + size_t(K) * 64;
+        const double* Rk = R.data() + size_t(K) * 4096;
+        for (int64_t i = 0; i < dp; ++i) {
+          bool own = false;
+          for (int t = 0; t < 64; ++t) own = own || ix[t] == i;
+          if (own) continue;
+          double tmp[64];
+          for (int j = 0; j < 64; ++j) {
+            double s = 0.0;
+            for (int t = 0; t < 64; ++t) s += Aw[i * dp + ix[t]] * Rk[t * 64 + j];
+            tmp[j] = s;
+          }
+          for (int j = 0; j < 64; ++j) Aw[i * dp + ix[j]] = tmp[j];
+        }
+      }
+      for (int K = 0; K < np; ++K) {                // rows (the pair's own tile keeps the rotated sub-problem), then V'
+        const int64_t* ix = idx.data() + size_t(K) * 64;
+        const double* Rk = R.data() + size_t(K) * 4096;
+        for (int i = 0; i < 64; ++i)
+          for (int64_t j = 0; j < dp; ++j) {
+            double s = 0.0;
+            for (int t = 0; t < 64; ++t) s += Rk[t * 64 + i] * Aw[ix[t] * dp + j];
+            T[i * dp + j] = s;
+          }
+        for (int i = 0; i < 64; ++i)
+          for (int64_t j = 0; j < dp; ++j) {
+            bool own = false;
+            for (int t = 0; t < 64; ++t) own = own || ix[t] == j;
+            if (!own) Aw[ix[i] * dp + j] = T[i * dp + j];
+          }
+        for (int i = 0; i < 64; ++i)
+          for (int64_t j = 0; j < dp; ++j) {
+            double v = 0.0;
+            for (int t = 0; t < 64; ++t) v += Rk[t * 64 + i] * Vt[ix[t] * dp + j];
+            T[i * dp + j] = v;
+          }
+        for (int i = 0; i < 64; ++i)
+          for (int64_t j = 0; j < dp; ++j) Vt[ix[i] * dp + j] = T[i * dp + j];
+      }
+    }
+    if (rot == 0) {
+      for (int64_t i = 0; i < d; ++i) {
+        w[i] = Aw[i * dp + i];
+        if (Vrows) for (int64_t j = 0; j < d; ++j) Vrows[i * ldv + j] = Vt[i * dp + j];
+      }
+      return sweep;
+    }
+  }
+  fail(CCZ_ENOCONV, "block Jacobi did not converge in %d sweeps (d=%lld)", max_sweeps, (long long)d);
+}
+
 void row_dots(ccz_ctx*, int64_t rows, int64_t cols, const double* A, int64_t lda, const double* B, int64_t ldb,
               double* out) {
   for (int64_t i = 0; i < rows; ++i) {
