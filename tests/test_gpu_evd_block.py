@@ -170,13 +170,19 @@ def test_svd_whiten_on_a_config2_view(H):
     xw_ref, W_ref = rf.thin_svd_whitener(X.astype(np.float64), 0.1)
     S = np.sign(np.sum(W * W_ref, axis=0))
     err = np.linalg.norm(W * S - W_ref, axis=0) / np.linalg.norm(W_ref, axis=0)
-    print(f"[evd] svd_whiten 1e5 x 1024 fp32: median column error {np.median(err):.2e}, max {err.max():.2e}")
-    # fp32 view: the north-star bar for float32 inputs is 1e-3 (sign-aligned); clustered noise directions dominate the max
-    assert np.median(err) < 1e-3
-    C_w = (xw.astype(np.float64).T @ xw.astype(np.float64)) / (n - 1)
-    R_w = W.astype(np.float64).T @ ((0.9 * (X.astype(np.float64).T @ X.astype(np.float64)) / (n - 1)) + 0.1 * np.eye(d)) @ W.astype(np.float64)
-    np.testing.assert_allclose(R_w, np.eye(d), atol=2e-3)
-    assert C_w.shape == (d, d)
+    W64 = W.astype(np.float64)
+    inv_err = np.linalg.norm(W64 @ W64.T - W_ref @ W_ref.T) / np.linalg.norm(W_ref @ W_ref.T)
+    print(f"[evd] svd_whiten 1e5 x 1024 fp32: signal columns {err[:64].max():.2e}, all columns median {np.median(err):.2e}; "
+          f"W W' = R^-1 {inv_err:.2e}")
+    # float32 view, bar 1e-3 (north star, float32, sign-aligned).  The 64 signal directions are separated and compare per
+    # column; the 960 noise directions have eigenvalue spacings ~ 4e-4 of the spectrum, where float32 data moves individual
+    # eigenvectors by more than the bar in ANY solver -- they are compared through the rotation-invariant W W' = R^-1.
+    assert err[:64].max() < 1e-4
+    assert inv_err < 1e-3
+    R = 0.9 * (X.astype(np.float64).T @ X.astype(np.float64)) / (n - 1) + 0.1 * np.eye(d)
+    np.testing.assert_allclose(W64.T @ R @ W64, np.eye(d), atol=2e-3)
+    xw_err = np.linalg.norm(xw.astype(np.float64)[:, :64] * S[:64] - xw_ref[:, :64]) / np.linalg.norm(xw_ref[:, :64])
+    assert xw_err < 1e-3, xw_err
 
 
 @pytest.mark.parametrize("shape", [(300, 40), (512, 512), (1024, 1024), (4096, 1024), (1000, 1500)])
