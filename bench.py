@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="rows of the rCCA CPU comparator's sample (0: 2 d)")
     ap.add_argument("--cpu-runs", type=int, default=1, help="repeats of the rCCA CPU comparator (a run is ~25 s; the median is reported)")
     ap.add_argument("--no-gates", action="store_true", help="skip the parity gates of the extras (the headline gate always runs)")
+    ap.add_argument("--launch-test", action="store_true",
+                    help="(CPU test of the launcher) rendezvous over gloo, one all-reduce, ONE JSON line on rank 0; no GPU work")
     return ap.parse_args()
 
 
@@ -678,8 +680,52 @@ def gram_traffic(dtype, D, n_local):
     return best[0]["bytes_per_row"] * n_local, f"profiles/{best[1]} (PMC pass at n={best[0].get('n')}, scaled by rows)"
 
 
+def relaunch(n_gpus):
+    """``python bench.py --gpus N`` without a launcher: start the N ranks ourselves (one process per GPU under
+    ``torch.distributed.run``, rendezvous on 127.0.0.1, a free port) and pass their output through -- rank 0 prints the ONE
+    JSON line.  The driver's own ``python -m torch.distributed.run ... bench.py --gpus N`` form sets WORLD_SIZE and never
+    comes here."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, n_gpus))))
+    return subprocess.call(cmd, env=env)
+
+
+def launch_test():
+    """The launcher logic without a GPU: every rank joins a gloo group, one all-reduce, rank 0 prints ONE JSON line."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29519")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t)
+    ranks = dist.get_world_size()
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"launch_test": True, "n_gpus": world, "ranks": ranks, "sum": float(t.item())}), flush=True)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch(a.gpus))
+    if int(os.environ.get("WORLD_SIZE", "1")) != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE')} "
+                 "(launch N ranks for --gpus N, or let bench.py start them)")
+    if a.launch_test:
+        return launch_test()
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -687,9 +733,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("launch with torch.distributed.run for --gpus > 1")
     torch.cuda.set_device(local)
     os.environ["CCZ_DEVICE"] = str(local)
     # CCZ_BENCH_FORCE_SHARDED=1 runs the N > 1 code path (process group, row_sharded fits, sharded loss) with one rank
@@ -722,7 +765,10 @@ def main():
         else:
             model.fit(views)
 
-    gram_ms, colsum_ms, solve_ms, allreduce_ms = [], [], [], []
+    gram_ms, colsum_ms, solve_ms, allreduce_ms, exchange_events = [], [], [], [], []
+    from cca_zoo_amd import _moments
+
+    _moments.TIME_EXCHANGE = distributed                  # event pairs around the two parts of the exchange (no host waits)
     # Process warm-up that is not a property of the step: allocator pools, code-object loads and whatever else makes
     # the first two or three fits of a process 15-30 ms slower.  Two untimed fits during set-up, in
     # addition to the W warm-up steps the caller asks for; reported as config.setup_fits.
@@ -752,6 +798,8 @@ def main():
         solve_ms.append(model.timings_["solve_ms"])
         allreduce_ms.append(model.timings_["allreduce_ms"])
         step_ms.append((time.perf_counter() - ts) * 1e3)
+        if distributed:
+            exchange_events.append(_moments.exchange_events())
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
@@ -763,6 +811,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / a.steps * 1e3
+    # the exchange on the device time line: head = pack -> first all-reduce done; tail = first done -> second unpacked
+    # (the solve's factorization overlaps the tail; what it could not hide is inside phases_ms.solve)
+    exchange_split = None
+    evs = [e for e in exchange_events if e]
+    if evs:
+        exchange_split = {"head_ms": float(np.mean([e[0].elapsed_time(e[1]) for e in evs])),
+                          "tail_ms": float(np.mean([e[1].elapsed_time(e[2]) for e in evs if e[2] is not None] or [0.0])),
+                          "host_wait_for_head_ms": float(np.mean(allreduce_ms))}
+    k1_ms_per_rank = [float(np.mean(gram_ms))]
+    rccl_ranks = 1
+    if distributed:
+        rccl_ranks = dist.get_world_size()
+        gt = torch.zeros(world, dtype=torch.float64, device=f"cuda:{local}")
+        gt[rank] = float(np.mean(gram_ms))
+        dist.all_reduce(gt)
+        k1_ms_per_rank = [float(x) for x in gt.cpu().tolist()]
 
     # ---- parity gate on the views that were timed (every rank takes part: transform / score all-reduce) ----
     gate = check_fit_properties(model, views, jd, seed=DATA_SEED, row0=lo, sharded=distributed)
@@ -789,7 +853,7 @@ def main():
         out = {
             "metric": "CCA fit()/sec at n=1e6 d=4096 k=64",
             "value": 1e3 / ms_per_step, "unit": "fit/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
+            "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
             "step_ms": [round(x, 2) for x in step_ms],
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic (JointData latent-variable model, counter-based generator, drawn in HBM)",
@@ -802,7 +866,8 @@ def main():
                          "kernel_ms": g_ms, "flop_per_launch": flop,
                          "bytes_per_launch": float(n_local) * D * (4 if a.dtype == "f32" else 8),
                          "gram_share_of_step": g_ms / ms_per_step},
-            "phases_ms": {"gram": g_ms, "colsum": float(np.mean(colsum_ms)), "allreduce": float(np.mean(allreduce_ms)),
+            "phases_ms": {"gram": g_ms, "gram_per_rank": k1_ms_per_rank, "colsum": float(np.mean(colsum_ms)),
+                          "allreduce": float(np.mean(allreduce_ms)), "allreduce_split": exchange_split,
                           "solve": float(np.mean(solve_ms)), "solve_min": float(np.min(solve_ms))},
             "parity_gate": gate,
         }

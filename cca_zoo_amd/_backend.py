@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 import threading
 
 import numpy as np
@@ -25,6 +26,7 @@ _ERRORS = {
     -4: np.linalg.LinAlgError,
     -5: np.linalg.LinAlgError,
     -6: ValueError,
+    -7: RuntimeError,
 }
 
 
@@ -76,6 +78,13 @@ SIGNATURES = {
     "ccz_moments_pack_blocks": (_int, [_vp, _vp, _i64, _pi64, _int, _vp, _int]),
     "ccz_moments_unpack_blocks": (_int, [_vp, _vp, _i64, _pi64, _int, _vp, _int, _vp]),
     "ccz_solve_defer": (_int, [_vp, _vp]),
+    "ccz_comm_unique_id": (_int, [_vp, _vp]),
+    "ccz_comm_init_rank": (_int, [_vp, _vp, _int, _int]),
+    "ccz_comm_init_all": (_int, [C.POINTER(_vp), _int]),
+    "ccz_comm_info": (_int, [_vp, _pint, _pint]),
+    "ccz_comm_destroy": (_int, [_vp]),
+    "ccz_allreduce_sum_f64": (_int, [_vp, _vp, _i64]),
+    "ccz_allreduce_sum_f64_multi": (_int, [C.POINTER(_vp), C.POINTER(_vp), _int, _i64]),
     "ccz_moments_last_ms": (_int, [_vp, _pdbl, _pdbl]),
     "ccz_moments_last_pilot": (_int, [_vp, _pint]),
     "ccz_rcca_solve": (_int, [_vp, _vp, _i64, _pi64, _pdbl, _int, _int, _vp, _vp, _vp, _pint]),
@@ -137,10 +146,13 @@ def library():
             # as /opt/rocm's.  Whichever is mapped first serves the whole process; torch cannot start
             # on top of the system runtime ("No HIP GPUs are available"), the other order works and
             # gives one shared runtime (same null stream, same allocations).  So: torch first.
-            try:
-                import torch  # noqa: F401
-            except ImportError:  # pragma: no cover - torch-less deployment uses /opt/rocm's runtime
-                pass
+            # CCZ_TORCHLESS=1 (a ctypes-only deployment of the linear path: NumPy views, ccz_comm_* for sharding) skips
+            # the import and runs on /opt/rocm's runtime; importing torch LATER in such a process is not supported.
+            if "torch" not in sys.modules and os.environ.get("CCZ_TORCHLESS", "0") != "1":
+                try:
+                    import torch  # noqa: F401
+                except ImportError:  # pragma: no cover - torch-less deployment uses /opt/rocm's runtime
+                    pass
             path = library_path()
             if not os.path.exists(path):
                 raise CCZError(
@@ -302,6 +314,32 @@ class Handle:
         da = (C.c_int64 * len(dims))(*[int(d) for d in dims])
         self.check(self.lib.ccz_moments_unpack_blocks(self._h, _ptr(packed_ptr), int(D), da, len(dims), _ptr(moments_ptr), int(which),
                                                       C.c_void_p(int(on_stream)) if on_stream else None))
+
+    # -- the exchange step behind the ABI (RCCL; no torch.distributed needed) -------------------
+    def comm_unique_id(self) -> bytes:
+        """128 opaque bytes (rank 0 creates them; every rank passes the same bytes to ``comm_init_rank``)."""
+        buf = C.create_string_buffer(128)
+        self.check(self.lib.ccz_comm_unique_id(self._h, C.cast(buf, C.c_void_p)))
+        return buf.raw
+
+    def comm_init_rank(self, unique_id: bytes, world: int, rank: int):
+        if len(unique_id) != 128:
+            raise ValueError("the communicator id is 128 bytes (Handle.comm_unique_id())")
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self.check(self.lib.ccz_comm_init_rank(self._h, C.cast(buf, C.c_void_p), int(world), int(rank)))
+
+    def comm_info(self):
+        """(world size, rank) of the handle's communicator; (0, -1) without one."""
+        w, r = C.c_int(0), C.c_int(-1)
+        self.check(self.lib.ccz_comm_info(self._h, C.byref(w), C.byref(r)))
+        return w.value, r.value
+
+    def comm_destroy(self):
+        self.check(self.lib.ccz_comm_destroy(self._h))
+
+    def allreduce_sum_f64(self, ptr, count):
+        """In-place float64 SUM over the communicator's ranks, enqueued on the handle's stream."""
+        self.check(self.lib.ccz_allreduce_sum_f64(self._h, _ptr(ptr), int(count)))
 
     def solve_defer(self, event_ptr):
         """The next ``*_solve`` waits (on the device) for this hipEvent before reading off-diagonal moment blocks."""

@@ -21,6 +21,55 @@ import threading
 _state = threading.local()
 
 
+class CczComm:
+    """A row-sharding group that lives entirely behind libccz's C ABI (``ccz_comm_*`` / ``ccz_allreduce_sum_f64``: RCCL
+    over xGMI, one process per GPU) -- for callers of the linear path that do not run ``torch.distributed``.
+
+    ``CczComm(handle, unique_id, world, rank)`` joins the communicator (rank 0 obtains ``unique_id`` from
+    ``handle.comm_unique_id()`` and ships the 128 bytes to the other ranks); ``CczComm.from_file(path, world, rank)`` does
+    the shipping through a file on a shared file system.  Pass it to ``row_sharded(group=comm)``.
+    """
+
+    def __init__(self, handle, unique_id, world, rank):
+        self.handle, self.world, self.rank = handle, int(world), int(rank)
+        handle.comm_init_rank(unique_id, world, rank)
+
+    @classmethod
+    def from_file(cls, path, world, rank, handle=None, timeout_s=120.0):
+        import os
+        import time
+
+        from cca_zoo_amd import _backend
+
+        h = handle or _backend.default_handle()
+        if rank == 0:
+            uid = h.comm_unique_id()
+            tmp = f"{path}.tmp.{os.getpid()}"
+            with open(tmp, "wb") as f:
+                f.write(uid)
+            os.replace(tmp, path)                      # atomic: readers never see a partial id
+        else:
+            t0 = time.time()
+            while not (os.path.exists(path) and os.path.getsize(path) == 128):
+                if time.time() - t0 > timeout_s:
+                    raise TimeoutError(f"no communicator id at {path} after {timeout_s:.0f} s")
+                time.sleep(0.02)
+            with open(path, "rb") as f:
+                uid = f.read()
+        return cls(h, uid, world, rank)
+
+    def close(self):
+        self.handle.comm_destroy()
+
+    def allreduce_small(self, values):
+        import numpy as np
+
+        a = np.ascontiguousarray(values, dtype=np.float64)
+        buf = self.handle.to_device(a.reshape(-1))
+        self.handle.allreduce_sum_f64(buf.ptr, a.size)
+        return self.handle.to_host(buf, a.shape)
+
+
 def shard_bounds(n_rows: int, rank: int, world: int) -> tuple[int, int]:
     """Contiguous, balanced partition: the first ``n % world`` ranks get one extra row."""
     if world < 1 or not (0 <= rank < world):
@@ -42,10 +91,11 @@ def is_sharded() -> bool:
 @contextlib.contextmanager
 def row_sharded(group=None):
     """Treat the views given to ``fit`` as this rank's row shard of a global dataset."""
-    import torch.distributed as dist
+    if not isinstance(group, CczComm):
+        import torch.distributed as dist
 
-    if not dist.is_available() or not dist.is_initialized():
-        raise RuntimeError("row_sharded() needs an initialised torch.distributed process group")
+        if not dist.is_available() or not dist.is_initialized():
+            raise RuntimeError("row_sharded() needs an initialised torch.distributed process group or a CczComm")
     prev = (getattr(_state, "on", False), getattr(_state, "group", None))
     _state.on, _state.group = True, group
     try:
@@ -85,16 +135,20 @@ def allreduce_moments(buf, group=None):
 
 def rank_and_world(group=None):
     """(rank, world size) of the enclosing ``row_sharded`` block; (0, 1) outside one."""
-    import torch.distributed as dist
-
     if not is_sharded():
         return 0, 1
+    if isinstance(group, CczComm):
+        return group.rank, group.world
+    import torch.distributed as dist
+
     return dist.get_rank(group), dist.get_world_size(group)
 
 
 def allreduce_small(values, device, group=None):
     """SUM-reduce a small float64 NumPy array over the ranks (host bookkeeping such as per-setting scores); the
     tensor lives on ``device`` (CUDA for nccl, CPU for gloo)."""
+    if isinstance(group, CczComm):
+        return group.allreduce_small(values)
     import numpy as np
     import torch
     import torch.distributed as dist

@@ -49,6 +49,16 @@ def _common_float(views):
 #: reusable exchange buffers / side streams of the sharded path, keyed by (device, number of doubles)
 _EXCHANGE = {}
 
+#: bench.py: record (start, head done, tail unpacked) events around the two parts of the exchange -- no host waits added
+TIME_EXCHANGE = False
+_last_events = None
+
+
+def exchange_events():
+    """The event triple of the last sharded ``compute_moments`` on CUDA (``None`` otherwise); read it after a
+    synchronisation: ``start.elapsed_time(head)``, ``head.elapsed_time(tail)``."""
+    return _last_events
+
 
 def _exchange_buffer(dev, count):
     """The packed moments travel in ONE buffer per (device, size), kept for the life of the process: no second
@@ -90,8 +100,9 @@ def compute_moments(views, handle=None, defer_offdiag=False):
         raise ValueError("views must be all host arrays or all CUDA tensors")
     keep = []
     sharded = _dist.is_sharded()
+    ccz_comm = _dist.active_group() if sharded and isinstance(_dist.active_group(), _dist.CczComm) else None
     stream_ptr = 0
-    if on_device or sharded:
+    if on_device or (sharded and ccz_comm is None):
         import torch
 
         # (a test double of the library keeps "device" memory on the host and says so: gloo tests on CPU)
@@ -127,7 +138,25 @@ def compute_moments(views, handle=None, defer_offdiag=False):
     LAST["moments_ms"] = (time.perf_counter() - t_k1) * 1e3
     LAST["allreduce_ms"] = 0.0
     n_total = n
-    if sharded:
+    if ccz_comm is not None:
+        # the exchange behind the C ABI (no torch.distributed): the packed blocks layout with the row count in the head's
+        # spare slot, ONE ccz_allreduce_sum_f64 on the handle's stream, one 8-byte read-back for n
+        if ccz_comm.handle is not h:
+            raise ValueError("the CczComm of row_sharded() belongs to another handle / device than the views")
+        count = D * (D + 1) // 2 + D + 1
+        n_head = sum(d * (d + 1) // 2 for d in dims) + D + 1
+        packed = h.alloc(count * 8)
+        if on_device:
+            h.acquire(stream_ptr)
+        h.moments_pack_blocks(mom_ptr, D, dims, packed.ptr, h.BOTH)
+        h.h2d(packed.ptr + (n_head - 1) * 8, np.array([float(n)]))
+        t_ar = time.perf_counter()
+        h.allreduce_sum_f64(packed.ptr, count)
+        n_total = int(round(float(h.to_host(packed, (1,), offset_bytes=(n_head - 1) * 8)[0])))
+        LAST["allreduce_ms"] = (time.perf_counter() - t_ar) * 1e3
+        h.moments_unpack_blocks(packed.ptr, D, dims, mom_ptr, h.BOTH)
+        keep.append(packed)
+    elif sharded:
         # the one exchange step of the path, in two parts: [diag-block triangles | column sums | row count] and
         # [off-diagonal blocks] (ccz.h "blocks layout") -- D (D + 1) / 2 + D + 1 doubles in all, as the plain packed form
         import torch
@@ -145,10 +174,19 @@ def compute_moments(views, handle=None, defer_offdiag=False):
             h.sync()
         head, tail = packed[:n_head], packed[n_head:]
         head[-1:].fill_(float(n))                        # the row count rides in the last slot of the head
+        global _last_events
+        _last_events = None
+        timed = TIME_EXCHANGE and cuda
+        if timed:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         t_ar = time.perf_counter()
         w_head = dist.all_reduce(head, op=dist.ReduceOp.SUM, group=group, async_op=True)
         w_tail = dist.all_reduce(tail, op=dist.ReduceOp.SUM, group=group, async_op=True) if n_tail > 0 else None
         w_head.wait()
+        if timed:
+            ev1.record()
+            _last_events = (ev0, ev1, None)
         n_total = int(round(float(head[-1].item())))     # the one host synchronisation: n is a host argument of the solves
         LAST["allreduce_ms"] = (time.perf_counter() - t_ar) * 1e3
         if cuda:
@@ -160,11 +198,15 @@ def compute_moments(views, handle=None, defer_offdiag=False):
                 side.wait_stream(torch.cuda.current_stream(mom_t.device))
                 with torch.cuda.stream(side):
                     w_tail.wait()                        # the side stream waits for the collective, the host does not
+                # libccz records an event it OWNS behind this unpack and the next *_solve waits for it on the device
+                # (every solve entry consumes the registration on every exit path); the side stream's writes into
+                # mom_t are made known to torch's allocator
                 h.moments_unpack_blocks(packed.data_ptr(), D, dims, mom_ptr, h.TAIL, on_stream=side.cuda_stream)
-                ev = torch.cuda.Event()
-                ev.record(side)
-                h.solve_defer(ev.cuda_event)
-                keep.append(ev)
+                mom_t.record_stream(side)
+                if timed:
+                    ev2 = torch.cuda.Event(enable_timing=True)
+                    ev2.record(side)
+                    _last_events = (ev0, ev1, ev2)
             else:
                 w_tail.wait()
                 if cuda:

@@ -93,6 +93,7 @@ int ccz_destroy(ccz_handle h) {
   if (im) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
+    if (im->comm) (void)ccz_comm_destroy(h);
     for (auto& g : im->graphs) (void)hipGraphExecDestroy(g.exec);
     if (im->own_stream) (void)hipStreamDestroy(im->own_stream);
     for (auto& b : im->pool) (void)hipFree(b.p);
@@ -110,6 +111,7 @@ int ccz_destroy(ccz_handle h) {
     for (int i = 0; i < 2; ++i) if (im->xs_ev[i]) (void)hipEventDestroy(im->xs_ev[i]);
     if (im->loss_status) (void)hipHostFree(im->loss_status);
     if (im->wait_ev) (void)hipEventDestroy(im->wait_ev);
+    if (im->defer_own_ev) (void)hipEventDestroy(im->defer_own_ev);
     if (im->d2h_pin) (void)hipHostFree(im->d2h_pin);
     (void)hipFree(im->d_flag);
     (void)hipFree(im->d_small);
@@ -301,7 +303,18 @@ int ccz_moments_pack_blocks(ccz_handle h, const double* moments_dev, int64_t D, 
 
 int ccz_moments_unpack_blocks(ccz_handle h, const double* packed_dev, int64_t D, const int64_t* dims, int n_views, double* moments_dev,
                               int which, void* on_stream) {
-  CCZ_GUARD(h, moments_blocks(h, false, moments_dev, D, dims, n_views, const_cast<double*>(packed_dev), which, on_stream))
+  CCZ_GUARD(h, {
+    moments_blocks(h, false, moments_dev, D, dims, n_views, const_cast<double*>(packed_dev), which, on_stream);
+    if (on_stream && on_stream != h->stream) {
+      // an unpack on a FOREIGN stream is by construction the deferred half of an exchange: record an event the handle
+      // OWNS behind it and make the next solve wait for it on the device.  (A borrowed event -- ccz_solve_defer --
+      // can be destroyed by its owner while still registered; this one lives as long as the handle.)
+      Impl* im = impl(h);
+      if (!im->defer_own_ev) CCZ_HIP(hipEventCreateWithFlags(&im->defer_own_ev, hipEventDisableTiming));
+      CCZ_HIP(hipEventRecord(im->defer_own_ev, static_cast<hipStream_t>(on_stream)));
+      im->deferred_event = im->defer_own_ev;
+    }
+  })
 }
 
 int ccz_solve_defer(ccz_handle h, void* event) {

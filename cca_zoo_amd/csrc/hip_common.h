@@ -63,8 +63,13 @@ struct Impl {
   void* d2h_pin = nullptr;
   void* d2h_pin_dev = nullptr;      // device view of d2h_pin (host-mapped): written by a copy kernel
   static constexpr size_t kD2hPinBytes = size_t(4) << 20;
-  void* deferred_event = nullptr;   // ccz_solve_defer: awaited by the next solve before it reads off-diagonal blocks
+  void* deferred_event = nullptr;   // awaited by the next solve before it reads off-diagonal blocks (ccz_solve_defer, or the
+                                    // handle's own event behind an unpack on a foreign stream)
+  hipEvent_t defer_own_ev = nullptr;
   bool adopted = false;             // c->stream is a caller's stream (ccz_stream_adopt) until the next acquire
+  // comm.hip: the RCCL communicator of this handle's device (ncclComm_t), its size and this handle's rank
+  void* comm = nullptr;
+  int comm_world = 0, comm_rank = -1;
 };
 
 inline Impl* impl(ccz_ctx* c) { return static_cast<Impl*>(c->impl); }

@@ -1036,12 +1036,25 @@ static void factor_loadings_impl(ccz_ctx* c, const double* mom, int64_t n, int64
     return CCZ_EHIP;                                                   \
   }
 
+namespace {
+// The off-diagonal half of a sharded exchange may still be in flight when a solve starts (ccz_solve_defer).  Whatever
+// way a solve ends -- including an early fail() in the argument / SPD checks, before its own wait_deferred -- the
+// registration is consumed here, so that it can neither leak into the next (possibly unsharded) solve nor leave the
+// side stream's unpack un-awaited.
+struct DeferGuard {
+  ccz_ctx* c;
+  explicit DeferGuard(ccz_ctx* c_) : c(c_) {}
+  ~DeferGuard() { try { ccz::wait_deferred(c); } catch (...) {} }
+};
+}  // namespace
+
 extern "C" {
 
 int ccz_rcca_solve(ccz_handle h, const double* moments_dev, int64_t n, const int64_t dims[2],
                    const double c[2], int center, int k, double* weights_host, double* means_host,
                    double* vals_host, int* k_out) {
   CCZ_GUARD(h, {
+    DeferGuard defer_guard(h);
     if (!c || !weights_host) ccz::fail(CCZ_EINVAL, "null argument");
     ccz::rcca_solve_impl(h, moments_dev, n, dims, c, center, k, weights_host, means_host, vals_host, k_out);
   })
@@ -1051,6 +1064,7 @@ int ccz_mcca_solve(ccz_handle h, const double* moments_dev, int64_t n, const int
                    int n_views, const double* c, double eps, int center, int k,
                    double* weights_host, double* means_host, double* vals_host, int* k_out) {
   CCZ_GUARD(h, {
+    DeferGuard defer_guard(h);
     if (!c || !weights_host) ccz::fail(CCZ_EINVAL, "null argument");
     ccz::mcca_solve_impl(h, moments_dev, n, dims, n_views, c, eps, center, k, weights_host, means_host, vals_host, k_out);
   })
@@ -1061,6 +1075,7 @@ int ccz_gcca_solve(ccz_handle h, const double* moments_dev, int64_t n, const int
                    int center, int k, double* weights_host, double* means_host,
                    double* vals_host, int* k_out) {
   CCZ_GUARD(h, {
+    DeferGuard defer_guard(h);
     if (!c || !weights_host) ccz::fail(CCZ_EINVAL, "null argument");
     ccz::gcca_solve_impl(h, moments_dev, n, dims, n_views, c, view_weights, eps, center, k, weights_host, means_host, vals_host, k_out);
   })

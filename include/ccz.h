@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CCZ_VERSION 120 /* 0.1.2 */
+#define CCZ_VERSION 130 /* 0.1.3: ccz_comm_*, ccz_allreduce_sum_f64*; blocked Jacobi behind ccz_syevj / ccz_gesvj */
 
 #if defined(__GNUC__)
 #define CCZ_API __attribute__((visibility("default")))
@@ -40,6 +40,7 @@ extern "C" {
 #define CCZ_ENOCONV (-4)  /* iterative solver did not converge              -> LinAlgError  */
 #define CCZ_ENOTSPD (-5)  /* Cholesky met a non-positive pivot              -> LinAlgError  */
 #define CCZ_EUNSUP (-6)   /* unsupported dtype / configuration              -> ValueError   */
+#define CCZ_ERCCL (-7)    /* RCCL unavailable / collective failed           -> RuntimeError */
 
 #define CCZ_F32 0
 #define CCZ_F64 1
@@ -137,6 +138,23 @@ CCZ_API int ccz_moments_pack_blocks(ccz_handle h, const double* moments_dev, int
 CCZ_API int ccz_moments_unpack_blocks(ccz_handle h, const double* packed_dev, int64_t D, const int64_t* dims, int n_views,
                                       double* moments_dev, int which, void* on_stream);
 CCZ_API int ccz_solve_defer(ccz_handle h, void* event);
+/* ---- the exchange step itself: RCCL all-reduce(sum) over xGMI (SURVEY.md 8(b) "ccz_allreduce_sum_f64", 8(e)) ----------
+ * The reference has no counterpart (single process, NumPy).  A caller WITHOUT torch.distributed shards like this:
+ *   one process per GPU:  rank 0 calls ccz_comm_unique_id and ships the 128 bytes to the other ranks (file, socket, MPI);
+ *     every rank: ccz_comm_init_rank(h, id, world, rank);  per fit: ccz_moments -> ccz_moments_pack[_blocks] ->
+ *     ccz_allreduce_sum_f64(h, packed_dev, count) -> ccz_moments_unpack[_blocks] -> ccz_*_solve.
+ *   one process, several GPUs:  ccz_comm_init_all(handles, n) once; per fit the packed buffers of all devices go through
+ *     ONE grouped call, ccz_allreduce_sum_f64_multi(handles, bufs_dev, n, count).
+ * The collective is enqueued on the handle's stream (in place, float64, sum) and does not block the host.  librccl is
+ * dlopen'ed at the first of these calls (CCZ_ERCCL if it cannot be found); ccz_comm_destroy (or ccz_destroy) frees the
+ * communicator.  ccz_comm_info: world size (0: none) and this handle's rank. */
+CCZ_API int ccz_comm_unique_id(ccz_handle h, void* id_out_128);
+CCZ_API int ccz_comm_init_rank(ccz_handle h, const void* id_128, int world, int rank);
+CCZ_API int ccz_comm_init_all(ccz_handle* handles, int n);
+CCZ_API int ccz_comm_info(ccz_handle h, int* world_out, int* rank_out);
+CCZ_API int ccz_comm_destroy(ccz_handle h);
+CCZ_API int ccz_allreduce_sum_f64(ccz_handle h, double* buf_dev, int64_t count);
+CCZ_API int ccz_allreduce_sum_f64_multi(ccz_handle* handles, double* const* bufs_dev, int n, int64_t count);
 /* Moments are additive over disjoint row sets: y <- alpha x + beta y over the D*D + D doubles of two
  * moment buffers.  With (alpha, beta) = (-1, 1) it turns the moments of all rows into those of the rows
  * outside a cross-validation fold -- the Gram reuse behind cca_zoo_amd.model_selection.GridSearchCV

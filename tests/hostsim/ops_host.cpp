@@ -583,6 +583,31 @@ int ccz_moments_unpack_blocks(ccz_handle, const double* packed, int64_t D, const
   return blocks_copy(false, mom, D, dims, m, const_cast<double*>(packed), which);
 }
 int ccz_solve_defer(ccz_handle, void*) { return CCZ_OK; }
+// the exchange behind the ABI: the double has no transport -- a world of one is a no-op, anything larger is refused
+int ccz_comm_unique_id(ccz_handle h, void* id) { if (!h || !id) return CCZ_EINVAL; std::memset(id, 0x5a, 128); return CCZ_OK; }
+int ccz_comm_init_rank(ccz_handle h, const void* id, int world, int rank) {
+  if (!h || !id || world < 1 || rank < 0 || rank >= world) return CCZ_EINVAL;
+  if (world != 1) { h->err = "the host double has no collective transport (world size 1 only)"; return CCZ_ERCCL; }
+  h->last_pilot = 1000;   // marker: communicator present (the double has no Impl)
+  return CCZ_OK;
+}
+int ccz_comm_init_all(ccz_handle* hs, int n) { return (hs && n == 1 && hs[0]) ? ccz_comm_init_rank(hs[0], "", 1, 0) : CCZ_ERCCL; }
+int ccz_comm_info(ccz_handle h, int* w, int* r) {
+  if (!h) return CCZ_EINVAL;
+  const bool on = h->last_pilot == 1000;
+  if (w) *w = on ? 1 : 0;
+  if (r) *r = on ? 0 : -1;
+  return CCZ_OK;
+}
+int ccz_comm_destroy(ccz_handle h) { if (!h) return CCZ_EINVAL; h->last_pilot = 0; return CCZ_OK; }
+int ccz_allreduce_sum_f64(ccz_handle h, double* buf, int64_t count) {
+  if (!h || !buf || count < 1) return CCZ_EINVAL;
+  if (h->last_pilot != 1000) { h->err = "the handle has no communicator (ccz_comm_init_rank / ccz_comm_init_all)"; return CCZ_EINVAL; }
+  return CCZ_OK;
+}
+int ccz_allreduce_sum_f64_multi(ccz_handle* hs, double* const* bufs, int n, int64_t count) {
+  return (hs && bufs && n == 1) ? ccz_allreduce_sum_f64(hs[0], bufs[0], count) : CCZ_ERCCL;
+}
 int ccz_transform(ccz_handle h, int dtype, const void* X, int64_t n, int64_t d, int64_t ld, const double* mean,
                   const double* W, int64_t k, void* out, int64_t ldo) {
   if (!h || !X || !W || !out) return CCZ_EINVAL;

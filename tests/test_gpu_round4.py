@@ -1,0 +1,124 @@
+"""GPU tests of round 4: the RCCL collective behind the C ABI (world size one: the GPU box has one GPU), the
+torch-less linear path, the exception safety of the deferred exchange."""
+
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def H():
+    from cca_zoo_amd import _backend
+
+    return _backend.default_handle(0)
+
+
+def test_rccl_allreduce_behind_the_abi_world_size_one(H):
+    """ccz_comm_unique_id -> ccz_comm_init_rank -> ccz_allreduce_sum_f64 on RCCL with ONE rank: the sum over one rank
+    is the buffer itself; the communicator is reported and released; a second init on the same handle is refused."""
+    uid = H.comm_unique_id()
+    assert len(uid) == 128 and uid != b"\x00" * 128
+    H.comm_init_rank(uid, 1, 0)
+    try:
+        assert H.comm_info() == (1, 0)
+        with pytest.raises(ValueError, match="already has a communicator"):
+            H.comm_init_rank(uid, 1, 0)
+        x = np.random.default_rng(0).standard_normal(1 << 20)
+        buf = H.to_device(x)
+        H.allreduce_sum_f64(buf.ptr, x.size)
+        np.testing.assert_array_equal(H.to_host(buf, x.shape), x)
+    finally:
+        H.comm_destroy()
+    assert H.comm_info() == (0, -1)
+    with pytest.raises(ValueError, match="no communicator"):
+        H.allreduce_sum_f64(H.alloc(64).ptr, 8)
+
+
+def test_row_sharded_over_a_ccz_comm_matches_the_plain_fit(H):
+    """The linear path sharded WITHOUT torch.distributed: K1 -> pack -> ccz_allreduce_sum_f64 -> unpack -> solve, host
+    (NumPy) views and HBM-resident views."""
+    import torch
+
+    from cca_zoo_amd import _dist, row_sharded
+    from cca_zoo_amd.linear import GCCA, rCCA
+    from oracle import reference_form as rf
+
+    views = rf.joint_data(3, 3000, 4, [96, 80, 72], 2.0, 9)
+    comm = _dist.CczComm(H, H.comm_unique_id(), 1, 0)
+    try:
+        for make, vs in ((lambda: rCCA(latent_dimensions=4, c=0.1), views[:2]), (lambda: GCCA(latent_dimensions=4, c=0.05), views)):
+            plain = make().fit(vs)
+            with row_sharded(group=comm):
+                host = make().fit(vs)
+                dev = make().fit([torch.as_tensor(v, device="cuda") for v in vs])
+                sc = host.score(vs)
+            for a, b, c in zip(plain.weights_, host.weights_, dev.weights_):
+                np.testing.assert_allclose(b, a, rtol=1e-10, atol=1e-12)
+                np.testing.assert_allclose(c, a, rtol=1e-10, atol=1e-12)
+            np.testing.assert_allclose(sc, plain.score(vs), rtol=1e-10)
+            assert host.timings_["allreduce_ms"] > 0.0
+    finally:
+        comm.close()
+
+
+def test_torchless_process_fits_and_matches_the_oracle():
+    """A ctypes-only process (CCZ_TORCHLESS=1: torch is never imported, libccz runs on /opt/rocm's HIP runtime) fits CCA
+    on NumPy views and agrees with the oracle at 1e-8."""
+    code = f"""
+import os, sys
+os.environ['CCZ_TORCHLESS'] = '1'
+sys.path.insert(0, {ROOT!r})
+import numpy as np
+from cca_zoo_amd.linear import CCA, MCCA
+from oracle import reference_form as rf
+views = rf.joint_data(2, 2000, 3, [64, 48], 2.0, 1)
+m = CCA(latent_dimensions=3).fit(views)
+W_ref, _ = rf.rcca_weights(views, 3, c=0.0)
+for w, r in zip(m.weights_, W_ref):
+    s = np.sign(np.sum(w * r, axis=0))
+    assert (np.linalg.norm(w * s - r, axis=0) / np.linalg.norm(r, axis=0)).max() < 1e-8
+sc = m.score(views)
+mm = MCCA(latent_dimensions=3, c=0.1).fit(views)
+assert 'torch' not in sys.modules, 'the linear path imported torch'
+print('ok', sc)
+"""
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and p.stdout.startswith("ok"), (p.stdout[-500:], p.stderr[-3000:])
+
+
+def test_failed_solve_consumes_the_deferred_exchange(H):
+    """an unpack on a side stream registers the handle's OWN event; a solve that fails early (here:
+    a bad regularisation) must consume it, and the next, unrelated solve on the handle must run normally."""
+    import torch
+
+    from cca_zoo_amd.linear import rCCA
+    from oracle import reference_form as rf
+
+    views = rf.joint_data(2, 1500, 3, [40, 30], 2.0, 2)
+    ref = rCCA(latent_dimensions=3, c=0.1).fit(views)
+    D, dims = 70, [40, 30]
+    tv = [torch.as_tensor(v, device="cuda") for v in views]
+    mom = torch.empty(D * D + D, dtype=torch.float64, device="cuda")
+    H.moments([(t.data_ptr(), t.shape[1], t.stride(0)) for t in tv], 1500, 1, True, mom.data_ptr())
+    count = D * (D + 1) // 2 + D + 1
+    packed = torch.empty(count, dtype=torch.float64, device="cuda")
+    H.moments_pack_blocks(mom.data_ptr(), D, dims, packed.data_ptr(), H.BOTH)
+    H.sync()
+    side = torch.cuda.Stream()
+    out = torch.zeros_like(mom)
+    H.moments_unpack_blocks(packed.data_ptr(), D, dims, out.data_ptr(), H.HEAD)
+    H.moments_unpack_blocks(packed.data_ptr(), D, dims, out.data_ptr(), H.TAIL, on_stream=side.cuda_stream)   # registers the deferral
+    with pytest.raises(ValueError):
+        H.rcca_solve(out.data_ptr(), 1500, dims, [-1.0, 0.1], True, 3)        # fails in the argument checks
+    W, _, _ = H.rcca_solve(out.data_ptr(), 1500, dims, [0.1, 0.1], True, 3)
+    for a, b in zip(W, ref.weights_):
+        s = np.sign(np.sum(a * b, axis=0))
+        np.testing.assert_allclose(a * s, b, rtol=1e-9, atol=1e-11)

@@ -1,0 +1,95 @@
+"""CPU tests of round 4's host logic: bench.py's self-launch, the C-ABI collective's Python route (CczComm) on the host
+double, the torch-less load of libccz, the exported comm symbols."""
+
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from hostsim_util import hostsim_handle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher re-executes itself under torch.distributed.run (one process per
+    GPU, rendezvous on 127.0.0.1, free port) and still prints ONE JSON line -- here with gloo and no GPU work."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-test"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out == {"launch_test": True, "n_gpus": 2, "ranks": 2, "sum": 3.0}
+
+
+def test_bench_refuses_a_world_size_mismatch():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--launch-test"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE=2" in p.stderr
+
+
+def test_comm_symbols_are_exported_and_bound():
+    from cca_zoo_amd import _backend
+
+    lib = _backend.bind(C.CDLL(_backend.library_path()), strict=True)
+    for name in ("ccz_comm_unique_id", "ccz_comm_init_rank", "ccz_comm_init_all", "ccz_comm_info", "ccz_comm_destroy",
+                 "ccz_allreduce_sum_f64", "ccz_allreduce_sum_f64_multi"):
+        assert hasattr(lib, name)
+        assert name in _backend.SIGNATURES
+    header = open(os.path.join(ROOT, "include", "ccz.h")).read()
+    assert "ccz_allreduce_sum_f64(ccz_handle h, double* buf_dev, int64_t count)" in header
+
+
+def test_ccz_comm_route_of_row_sharded_on_the_host_double(monkeypatch):
+    """row_sharded(group=CczComm): pack -> ccz_allreduce_sum_f64 -> unpack -> solve, without torch.distributed.  World
+    size one on the host double (its collective is a no-op): the fit must equal the unsharded fit bit for bit, the
+    timings record the exchange, and a bigger world is refused by the double (it has no transport)."""
+    from cca_zoo_amd import _backend, _dist, row_sharded
+    from cca_zoo_amd.linear import MCCA, rCCA
+    from oracle import reference_form as rf
+
+    h = hostsim_handle()
+    monkeypatch.setattr(_backend, "default_handle", lambda device=None: h)
+    views = rf.joint_data(3, 240, 3, [14, 11, 9], 2.0, 3)
+    uid = h.comm_unique_id()
+    assert len(uid) == 128
+    with pytest.raises(RuntimeError, match="transport"):
+        _dist.CczComm(h, uid, 2, 0)
+    comm = _dist.CczComm(h, uid, 1, 0)
+    assert h.comm_info() == (1, 0)
+    try:
+        for make in (lambda: rCCA(latent_dimensions=3, c=0.2), lambda: MCCA(latent_dimensions=3, c=0.1)):
+            vs = views[:2] if isinstance(make(), rCCA) else views
+            plain = make().fit(vs)
+            with row_sharded(group=comm):
+                assert _dist.is_sharded() and _dist.rank_and_world(comm) == (0, 1)
+                sharded = make().fit(vs)
+                sc = sharded.score(vs)
+            for a, b in zip(plain.weights_, sharded.weights_):
+                np.testing.assert_array_equal(a, b)
+            np.testing.assert_allclose(sc, plain.score(vs), rtol=1e-12)
+            assert sharded.n_samples_ == 240
+    finally:
+        comm.close()
+    assert h.comm_info() == (0, -1)
+    with pytest.raises(ValueError, match="no communicator"):
+        h.allreduce_sum_f64(h.alloc(64).ptr, 8)
+
+
+def test_torchless_load_does_not_import_torch():
+    """CCZ_TORCHLESS=1: a ctypes-only caller of the linear path loads libccz on /opt/rocm's runtime without torch
+    (VERDICT r3 item 10).  The default still maps torch's runtime first (one HIP runtime per process)."""
+    code = ("import os, sys; os.environ['CCZ_TORCHLESS'] = '1'; sys.path.insert(0, %r); "
+            "from cca_zoo_amd import _backend; lib = _backend.library(); "
+            "assert lib.ccz_version() >= 130; assert 'torch' not in sys.modules; print('ok')" % ROOT)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and p.stdout.strip() == "ok", p.stderr[-2000:]
