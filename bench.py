@@ -51,7 +51,7 @@ def parse():
                     help="skip the reference-structured MCCA / GCCA comparators (BASELINE configs[2] / [4] on bounded samples: ~1 min of CPU)")
     ap.add_argument("--cpu-mcca", action="store_true", help="(kept for compatibility: the MCCA comparator is on by default)")
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="rows of the rCCA CPU comparator's sample (0: 2 d)")
-    ap.add_argument("--cpu-runs", type=int, default=1, help="repeats of the rCCA CPU comparator (a run is ~25 s; the median is reported)")
+    ap.add_argument("--cpu-runs", type=int, default=3, help="repeats of the rCCA CPU comparator at n = 2 d (a run is ~25 s; the median is reported)")
     ap.add_argument("--no-gates", action="store_true", help="skip the parity gates of the extras (the headline gate always runs)")
     ap.add_argument("--launch-test", action="store_true",
                     help="(CPU test of the launcher) rendezvous over gloo, one all-reduce, ONE JSON line on rank 0; no GPU work")
@@ -136,8 +136,52 @@ def check_fit_properties(model, views, jd, seed, row0=0, sharded=False, n_check=
     rep["singular_values"] = [float(sv[0]), float(sv[-1])]
     ok = ok and rep["unit_variance_dev"] < 3 * tol and within < 3 * tol and rep["cross_view_dev"] < 3 * tol
     ok = ok and rep["score_vs_singular_values"] < 3 * tol and bool(np.all(np.diff(sv) <= 1e-9)) and 0.0 < sv[-1] and sv[0] <= 1.0 + 1e-9
+    # ---- THE top-k solution, not just A CCA solution: the pencil certificate of oracle/certificates.py
+    # with the inertia count, on second moments of the timed views formed by a COMPARATOR (torch float64 products over
+    # row chunks; summed over the ranks under sharding) -- not by the product's K1
+    cert = topk_certificate(model, views, sharded)
+    rep.update(cert)
+    ok = ok and cert["pencil_residual"] < tol and cert["pencil_orthonormality"] < tol
+    ok = ok and cert["pencil_eigenvalues_above_lambda_k"] == k
     rep["ok"] = bool(ok)
     return rep
+
+
+def topk_certificate(model, views, sharded=False, chunk=32768):
+    """Eigen-residual, B-orthonormality and the number of pencil eigenvalues above lambda_k (by inertia: one LDL'
+    factorization on the host) for the two-view pencil of ``cca_zoo/linear/_rcca.py:92-100`` at c = 0, from float64
+    moments that torch accumulates here.  Every rank takes part; the factorization runs on every rank (same numbers)."""
+    import numpy as np
+    import torch
+
+    from oracle import certificates as ct
+
+    dims = [int(v.shape[1]) for v in views]
+    D, n_loc, dev = sum(dims), int(views[0].shape[0]), views[0].device
+    G = torch.zeros(D, D, dtype=torch.float64, device=dev)
+    sm = torch.zeros(D, dtype=torch.float64, device=dev)
+    for a in range(0, n_loc, chunk):
+        X = torch.cat([v[a:a + chunk].to(torch.float64) for v in views], dim=1)
+        G.addmm_(X.T, X)
+        sm += X.sum(0)
+        del X
+    n_tot = torch.tensor([float(n_loc)], dtype=torch.float64, device=dev)
+    if sharded:
+        import torch.distributed as dist
+
+        for t in (G, sm, n_tot):
+            dist.all_reduce(t)
+    Gh, sh, n = G.cpu().numpy(), sm.cpu().numpy(), int(round(float(n_tot.item())))
+    del G, sm
+    torch.cuda.empty_cache()
+    A, B = ct.rcca_pencil(Gh, sh, n, dims, [0.0] * len(dims))
+    V = np.vstack(model.weights_).astype(np.float64) / np.sqrt(2.0)
+    lam = np.asarray(model.singular_values_, dtype=np.float64)
+    f32 = views[0].element_size() == 4
+    r = ct.pencil_certificate(A, B, V, lam, delta=1e-4 if f32 else 1e-6, inertia=True)
+    return {"pencil_residual": float(r["residual"]), "pencil_orthonormality": float(r["orthonormality"]),
+            "pencil_eigenvalues_above_lambda_k": int(r["n_above"]), "k": int(r["k"]),
+            "moments_by": "torch float64 addmm over row chunks (comparator)"}
 
 
 def solution_gate(model, views, est, c, jd=None, seed=None, inertia=True):
@@ -209,16 +253,15 @@ def host_cores():
     return n, quota
 
 
-def cpu_baseline(n_full, d, k, sample_rows=0, runs=1):
+def cpu_baseline(n_full, d, k, sample_rows=0, runs=3):
     """The reference's rCCA structure (cca_zoo/linear/_rcca.py:92-100: thin SVD of each centred n x d view, whitened
-    cross product, SVD of the d x d matrix T) from the oracle's own building blocks (``oracle.reference_form``), on a
-    bounded sample of ``sample_rows`` rows (default 2 d: the tall side of the thin SVD) of the same kind of data.
-
-    The part that grows with n (the two thin SVDs and the n x d x d cross product: O(n d^2)) is timed separately from
-    the part that does not (the SVD of T, the d x d x k back-multiplication: O(d^3)), and only the former is scaled to
-    the full n -- at n ~ d the fixed part is a third of the run, and scaling it too (as round 2 did) overstated the
-    extrapolation.  ``runs`` defaults to ONE: a run is ~25 s of CPU, BASELINE.md's median-of-three would triple the
-    bench's CPU leg (``--cpu-runs 3`` does it); the JSON says how many were made."""
+    cross product, SVD of the d x d matrix T) from the oracle's own building blocks (``oracle.reference_form``), timed as
+    a SLOPE: the n-dependent part (two thin SVDs + the n x d x d cross product) is measured at TWO
+    sample sizes, n1 = 2 d rows (median of ``runs``, default 3) and n2 = 4 d rows (two runs), and the cost at the full n
+    is  fixed + t(n1) + per_row * (n_full - n1)  with  per_row = (t(n2) - t(n1)) / (n2 - n1)  -- at n ~ d the "n-dependent"
+    part still holds large d^3 terms of LAPACK's gesdd that do not grow with n, which a plain ratio n_full / n1 (round 3)
+    scaled along with everything else.  The part that does not depend on n at all (SVD of T, back-multiplication) is
+    timed on its own.  ~2.2 min of CPU on 16 cores."""
     import numpy as np
 
     from oracle import reference_form as rf
@@ -233,42 +276,101 @@ def cpu_baseline(n_full, d, k, sample_rows=0, runs=1):
         limiter = threadpool_limits(limits=max(cores, 1))
     except Exception:
         limiter = None
-    if sample_rows <= 0:
-        sample_rows = 2 * d
-    views = [v.astype(np.float32) for v in rf.joint_data(2, sample_rows, k, [d, d], 1.0, 0)]
-    t_data, t_fixed = [], []
+    n1 = sample_rows if sample_rows > 0 else 2 * d
+    n2 = 2 * n1
+    views2 = [v.astype(np.float32) for v in rf.joint_data(2, n2, k, [d, d], 1.0, 0)]
+
+    def data_part(rows):
+        t0 = time.perf_counter()
+        (X1, X2), _means = rf.center_views([v[:rows] for v in views2], True)
+        X1w, W1 = rf.thin_svd_whitener(X1, 0.0)
+        X2w, W2 = rf.thin_svd_whitener(X2, 0.0)
+        T = X1w.T @ X2w / (X1.shape[0] - 1)
+        return time.perf_counter() - t0, T, W1, W2, min(k, X1w.shape[1], X2w.shape[1])
+
+    t_n1, t_n2, t_fixed = [], [], []
     try:
         for _ in range(max(1, runs)):
-            t0 = time.perf_counter()
-            (X1, X2), _means = rf.center_views(views, True)
-            X1w, W1 = rf.thin_svd_whitener(X1, 0.0)
-            X2w, W2 = rf.thin_svd_whitener(X2, 0.0)
-            T = X1w.T @ X2w / (X1.shape[0] - 1)
+            td, T, W1, W2, kk = data_part(n1)
             t1 = time.perf_counter()
             U, _sv, Vt = np.linalg.svd(T, full_matrices=False)
-            kk = min(k, X1w.shape[1], X2w.shape[1])
             _W = [W1 @ U[:, :kk], W2 @ Vt[:kk].T]
-            t2 = time.perf_counter()
-            t_data.append(t1 - t0)
-            t_fixed.append(t2 - t1)
-            del X1, X2, X1w, X2w, T, U, Vt, _W
+            t_fixed.append(time.perf_counter() - t1)
+            t_n1.append(td)
+            del T, U, Vt, _W, W1, W2
+        for _ in range(2 if runs > 1 else 1):
+            t_n2.append(data_part(n2)[0])
     finally:
         if limiter is not None:
             limiter.restore_original_limits()
-    td, tf = float(np.median(t_data)), float(np.median(t_fixed))
-    full = tf + td * (n_full / sample_rows)
+    td1, td2, tf = float(np.median(t_n1)), float(np.median(t_n2)), float(np.median(t_fixed))
+    per_row = max((td2 - td1) / (n2 - n1), 0.0)
+    full = tf + td1 + per_row * (n_full - n1)
     return {
-        "value": 1.0 / full, "unit": "fit/s (extrapolated: only the n-dependent part is scaled to the full n)", "cores": max(cores, 1),
+        "value": 1.0 / full, "unit": "fit/s (extrapolated along the measured per-row slope)", "cores": max(cores, 1),
         "kind": "port",
         "sample": (f"the reference's rCCA structure (thin SVD per view, cross product, SVD of T: cca_zoo/linear/_rcca.py:92-100) "
-                   f"from oracle.reference_form's building blocks on {sample_rows} rows (= {sample_rows / d:.2g} d) of 2x{d} fp32 "
-                   f"JointData, k={k}; {len(t_data)} run(s)"),
-        "measured_s": td + tf, "data_dependent_s": td, "fixed_s": tf, "runs": len(t_data),
-        "runs_s": [round(a + b, 3) for a, b in zip(t_data, t_fixed)], "sample_rows": sample_rows,
-        "extrapolated_full_s": full, "extrapolation": f"fixed_s + data_dependent_s * {n_full}/{sample_rows}",
+                   f"from oracle.reference_form's building blocks on {n1} and {n2} rows (2 d, 4 d) of 2x{d} fp32 JointData, k={k}; "
+                   f"{len(t_n1)} + {len(t_n2)} runs"),
+        "n_dependent_s": {"rows": [n1, n2], "median_s": [td1, td2], "runs_s": [[round(x, 3) for x in t_n1], [round(x, 3) for x in t_n2]]},
+        "per_row_s": per_row, "intercept_s": td1 - per_row * n1, "fixed_s": tf, "runs": len(t_n1),
+        "measured_s": td1 + tf, "extrapolated_full_s": full,
+        "extrapolation": f"fixed_s + t({n1}) + per_row_s * ({n_full} - {n1});  per_row_s = (t({n2}) - t({n1})) / {n2 - n1}",
+        "ratio_extrapolation_s_for_comparison": tf + td1 * (n_full / n1),
         "blas_threads": max(cores, 1) if limiter is not None else None, "sched_affinity": affinity, "cgroup_cpu_quota": quota,
         "logical_cpus": os.cpu_count(),
     }
+
+
+def cpu_c2_whole(k=32, c=0.1, n=100_000, d=1024):
+    """BASELINE configs[1] WHOLE on the host, no extrapolation: the oracle's reference-form
+    ``rcca_weights`` (cca_zoo/linear/_rcca.py:69-101) on the very views the GPU fits -- n = 1e5, 2 x 1024, float32 --
+    timed, and the two solutions compared per column (sign-aligned, float32 bar 1e-3) and by score."""
+    import numpy as np
+    import torch
+
+    from cca_zoo_amd.datasets import JointData
+    from cca_zoo_amd.linear import rCCA
+    from oracle import reference_form as rf
+
+    affinity, quota = host_cores()
+    cores = int(min(affinity, quota)) if quota else affinity
+    jd = JointData(n_views=2, n_samples=1, latent_dimensions=k, n_features=[d, d], random_state=1,
+                   latent_scales=list(np.linspace(2.0, 0.5, k)))
+    views = jd.sample_device(device="cuda", dtype=torch.float32, n_samples=n, seed=DATA_SEED + 1)
+    model = rCCA(latent_dimensions=k, c=c).fit(views)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    model = rCCA(latent_dimensions=k, c=c).fit(views)
+    torch.cuda.synchronize()
+    gpu_s = time.perf_counter() - t0
+    host = [v.cpu().numpy() for v in views]
+    gpu_score = np.asarray(model.score(views), dtype=np.float64)
+    del views
+    torch.cuda.empty_cache()
+    try:
+        from threadpoolctl import threadpool_limits
+
+        limiter = threadpool_limits(limits=max(cores, 1))
+    except Exception:
+        limiter = None
+    try:
+        t0 = time.perf_counter()
+        W_ref, means_ref = rf.rcca_weights(host, k, c=c)
+        cpu_s = time.perf_counter() - t0
+    finally:
+        if limiter is not None:
+            limiter.restore_original_limits()
+    errs = []
+    for w, r in zip(model.weights_, W_ref):
+        w, r = np.asarray(w, dtype=np.float64), np.asarray(r, dtype=np.float64)
+        sgn = np.sign(np.sum(w * r, axis=0))
+        errs.append(float((np.linalg.norm(w * sgn - r, axis=0) / np.linalg.norm(r, axis=0)).max()))
+    ref_score = rf.mean_offdiag_corr([h.astype(np.float64) for h in host], W_ref, means_ref)
+    return {"config": f"configs[1] whole: rCCA n={n}, 2x{d}, k={k}, c={c}, float32", "cpu_s": cpu_s, "cpu_fits_per_s": 1.0 / cpu_s,
+            "gpu_fit_s": gpu_s, "gpu_over_cpu": cpu_s / gpu_s, "cores": max(cores, 1), "extrapolated": False,
+            "weights_max_col_rel_err": max(errs), "score_max_abs_diff": float(np.abs(gpu_score - np.asarray(ref_score)).max()),
+            "agree_at_1e-3": bool(max(errs) < 1e-3)}
 
 
 def cpu_mcca_baseline(n_full=1_000_000, d=2048, m=4, k=64, sample_rows=4096):
@@ -562,7 +664,7 @@ def config_extras(info, gates=True):
     def run(tag, label, dims, n, k, tdt, make_model, est, c, runs=2, offset=0.0):
         free, _ = torch.cuda.mem_get_info()
         need = n * sum(dims) * (4 if tdt == torch.float32 else 8)
-        if need * 1.15 > free:
+        if need * 1.04 + 14e9 > free:
             out[tag] = {"config": label, "skipped": f"needs {need / 1e9:.0f} GB of HBM, {free / 1e9:.0f} GB free"}
             return
         jd = JointData(n_views=len(dims), n_samples=1, latent_dimensions=k, n_features=list(dims), random_state=1,
@@ -601,8 +703,19 @@ def config_extras(info, gates=True):
         (4096, 4096), 1_000_000, 64, torch.float32, lambda: CCA(latent_dimensions=64), "rcca", 0.0, runs=3, offset=10.0)
     run("ns_f64", "metric shape in float64: CCA n=1e6, 2x4096, k=64", (4096, 4096), 1_000_000, 64, torch.float64,
         lambda: CCA(latent_dimensions=64), "rcca", 0.0, runs=3)
-    run("c5_gcca", "configs[4] at the largest n one GPU holds: GCCA d=[4096,4096,8192], n=1e6 (of 2e6), k=128, float64",
-        (4096, 4096, 8192), 1_000_000, 128, torch.float64, lambda: GCCA(latent_dimensions=128), "gcca", 0.0)
+    # configs[4]: the largest n ONE GPU holds, chosen from what is free now (views n x 16384 float64 + 2.1 GB of moments +
+    # ~30 GB for the solver's D x D scratch blocks, the generator's chunks and allocator slack), in steps of 65536 rows, at most the configuration's own 2e6
+    free, _ = torch.cuda.mem_get_info()
+    n5 = int(min(2_000_000, max(65536, ((free - 32e9) / 1.03 / (16384 * 8)) // 65536 * 65536)))
+    for n_try in (n5, 1_000_000):
+        try:
+            run("c5_gcca", f"configs[4] at the largest n one GPU holds: GCCA d=[4096,4096,8192], n={n_try} (of 2e6; chosen from "
+                f"{free / 1e9:.0f} GB free), k=128, float64", (4096, 4096, 8192), n_try, 128, torch.float64,
+                lambda: GCCA(latent_dimensions=128), "gcca", 0.0)
+            break
+        except (torch.cuda.OutOfMemoryError, MemoryError) as e:                # (libccz's pool reports CCZ_ENOMEM as MemoryError)
+            out["c5_gcca"] = {"config": f"configs[4], n={n_try}", "skipped": f"out of HBM: {e}"[:300]}
+            torch.cuda.empty_cache()
     return out
 
 
@@ -640,6 +753,127 @@ def sharded_dcca_extra(n_local, d, world, steps=2, warmup=1):
     t = torch.tensor([(time.perf_counter() - t0) / steps], dtype=torch.float64, device="cuda")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def evd_extra(sizes=(512, 1024, 2048, 4096)):
+    """The dense symmetric EVD behind ``svd_whiten`` / ``_inv_sqrtm`` / ``_BatchWhiten`` (``ccz_syevj``, blocked Jacobi of
+    csrc/evd_block.hip; reference: numpy.linalg.svd / torch.linalg.eigh at cca_zoo/_utils/_linalg.py:28, deep/objectives.py:19)
+    and the thin SVD behind ``np.linalg.svd(cross_cov)`` (``ccz_gesvj``; cca_zoo/linear/_rcca.py:97) at the seams' sizes:
+    warm milliseconds, sweeps, the nominal 9 d^3 rate, and the gate -- ||A V - V L|| / ||A|| and ||V'V - I|| (Frobenius,
+    formed with torch float64 as the comparator) below 1e-11."""
+    import ctypes as C
+
+    import numpy as np
+    import torch
+
+    from cca_zoo_amd import _backend
+
+    h = _backend.default_handle()
+    out, ok = {}, True
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for d in sizes:
+        X = torch.randn(3 * d, d, dtype=torch.float64, device="cuda", generator=g) * torch.linspace(2.0, 0.05, d, dtype=torch.float64, device="cuda")
+        A = (X.T @ X / (3 * d - 1)).contiguous()
+        w = torch.empty(d, dtype=torch.float64, device="cuda")
+        V = torch.empty(d, d, dtype=torch.float64, device="cuda")
+        sw = C.c_int(0)
+        ts = []
+        for _ in range(4):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            h.check(h.lib.ccz_syevj(h.raw, C.c_void_p(A.data_ptr()), d, C.c_void_p(w.data_ptr()), C.c_void_p(V.data_ptr()), C.byref(sw)))
+            h.sync()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        ms = float(min(ts[1:]))
+        resid = float(torch.linalg.norm(A @ V.T - V.T * w) / torch.linalg.norm(A))
+        orth = float(torch.linalg.norm(V @ V.T - torch.eye(d, dtype=torch.float64, device="cuda")))
+        good = resid < 1e-11 and orth < 1e-11 and bool(torch.all(w[:-1] >= w[1:]))
+        ok = ok and good
+        out[f"syev_{d}"] = {"ms": ms, "first_call_ms": ts[0], "sweeps": sw.value, "nominal_tflops_9d3": 9.0 * d ** 3 / (ms * 1e-3) / 1e12,
+                            "residual": resid, "orthogonality": orth}
+        del X, A, V
+    for p, q in ((1024, 1024), (4096, 1024)):
+        A = torch.randn(p, q, dtype=torch.float64, device="cuda", generator=g)
+        r = min(p, q)
+        U = torch.empty(p, r, dtype=torch.float64, device="cuda")
+        sg = torch.empty(r, dtype=torch.float64, device="cuda")
+        Vt = torch.empty(r, q, dtype=torch.float64, device="cuda")
+        sw = C.c_int(0)
+        ts = []
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            h.check(h.lib.ccz_gesvj(h.raw, C.c_void_p(A.data_ptr()), p, q, C.c_void_p(U.data_ptr()), C.c_void_p(sg.data_ptr()),
+                                    C.c_void_p(Vt.data_ptr()), C.byref(sw)))
+            h.sync()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        rec = float(torch.linalg.norm(U * sg @ Vt - A) / torch.linalg.norm(A))
+        orth = float(max(torch.linalg.norm(U.T @ U - torch.eye(r, dtype=torch.float64, device="cuda")),
+                         torch.linalg.norm(Vt @ Vt.T - torch.eye(r, dtype=torch.float64, device="cuda"))))
+        good = rec < 1e-11 and orth < 1e-10
+        ok = ok and good
+        out[f"gesv_{p}x{q}"] = {"ms": float(min(ts)), "sweeps": sw.value, "reconstruction": rec, "orthogonality": orth}
+        del A, U, Vt
+    torch.cuda.empty_cache()
+    out["parity_gate"] = {"ok": bool(ok)}
+    return out
+
+
+def host_inputs_extra(views, k, rows=262_144):
+    """The scikit-learn surface's NATIVE input: ``CCA(k).fit`` on HOST NumPy views -- pageable (what
+    ``np.asarray`` gives: libccz packs row chunks into pinned bounce buffers on host threads || DMA || K1) and pinned
+    (``torch.Tensor.pin_memory().numpy()``: the DMA reads the caller's pages directly) -- at the metric shape's widths on
+    the first ``rows`` rows of the timed views.  Reported: inclusive seconds per fit, the PCIe rate that implies, and the
+    rate of a plain pinned copy of the same bytes on this box (the link's achievable peak).  Gate: the weights equal those
+    of the HBM-resident fit of the same rows (float32 bar 1e-3 per column) and the scores agree."""
+    import numpy as np
+    import torch
+
+    from cca_zoo_amd.linear import CCA
+
+    rows = min(rows, int(views[0].shape[0]))
+    dev_views = [v[:rows] for v in views]
+    ref = CCA(latent_dimensions=k).fit(dev_views)
+    ref_score = np.asarray(ref.score(dev_views), dtype=np.float64)
+    pageable = [v.cpu().numpy() for v in dev_views]
+    nbytes = float(sum(p.nbytes for p in pageable))
+    pinned_t = [torch.from_numpy(p).pin_memory() for p in pageable]
+    pinned = [t.numpy() for t in pinned_t]
+    # the link: a plain pinned -> HBM copy of the same bytes
+    dst = [torch.empty_like(v) for v in dev_views]
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for d, t in zip(dst, pinned_t):
+            d.copy_(t, non_blocking=True)
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    del dst
+    link = nbytes / best / 1e9
+    out = {"rows": rows, "bytes": nbytes, "pinned_copy_GBps": link}
+    ok = True
+    for name, hv in (("pageable", pageable), ("pinned", pinned)):
+        m = CCA(latent_dimensions=k).fit(hv)             # warm-up: bounce buffers, staging blocks
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            m = CCA(latent_dimensions=k).fit(hv)
+            ts.append(time.perf_counter() - t0)
+        t = float(np.median(ts))
+        errs = []
+        for w, r in zip(m.weights_, ref.weights_):
+            w, r = np.asarray(w, dtype=np.float64), np.asarray(r, dtype=np.float64)
+            sgn = np.sign(np.sum(w * r, axis=0))
+            errs.append(float((np.linalg.norm(w * sgn - r, axis=0) / np.linalg.norm(r, axis=0)).max()))
+        sc = float(np.abs(np.asarray(m.score(hv), dtype=np.float64) - ref_score).max())
+        good = max(errs) < 1e-3 and sc < 1e-4
+        ok = ok and good
+        out[name] = {"fit_s": t, "fits_s": [round(x, 4) for x in ts], "inclusive_GBps": nbytes / t / 1e9,
+                     "frac_of_pinned_copy": nbytes / t / 1e9 / link, "weights_vs_hbm_resident_fit": max(errs), "score_diff": sc,
+                     "fit_per_s_at_n_1e6_extrapolated": 1.0 / (t * 1e6 / rows)}
+    out["parity_gate"] = {"ok": bool(ok)}
+    return out
 
 
 def grid_extra(views, k, fit_ms):
@@ -892,6 +1126,10 @@ def main():
                 gated("dcca_loss", dcca_extra(gate=gates))
                 extra["dcca_training_step"] = training_step_extra()
             extra["grid_search"] = grid_extra(views, a.k, ms_per_step)
+            try:
+                gated("host_inputs", host_inputs_extra(views, a.k))
+            except (MemoryError, RuntimeError) as e:          # a host without 17 GB to spare for the two copies
+                extra["host_inputs"] = {"skipped": f"{type(e).__name__}: {e}"[:300]}
             del views
             views = None
             torch.cuda.empty_cache()
@@ -899,6 +1137,7 @@ def main():
                 gated("dcca_loss_metric_shape", dcca_extra(steps=3, warmup=1, batch=a.n, d=a.d, label="metric shape", gate=gates))
                 torch.cuda.empty_cache()
             extra["configs"] = config_extras(info, gates=gates)
+            gated("dense_evd", evd_extra())
         if extra:
             out["extra"] = extra
         if "value" in extra.get("dcca_loss_metric_shape", {}):
@@ -909,6 +1148,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.n, a.d, a.k, a.cpu_sample_rows, a.cpu_runs)
             if not a.no_extras:
+                out["cpu_baseline"]["c2_rcca"] = cpu_c2_whole()
                 out["cpu_baseline"]["dcca_loss_configs3"] = cpu_loss_baseline()
             if not a.no_cpu_mcca and not a.no_extras:
                 out["cpu_baseline"]["mcca_configs2"] = cpu_mcca_baseline()

@@ -1258,6 +1258,22 @@ void moments_impl(ccz_ctx* c, int dtype, const ccz_view* views, int n_views, int
   const bool piped = n_rows * row_bytes >= (int64_t(64) << 20) && n_rows > chunk / 2 && ensure_pipe(c, size_t(chunk) * row_bytes);
   const int nslots = piped ? 2 : 1;
   Impl* im = impl(c);
+  // PINNED sources (hipHostMalloc / hipHostRegister, torch's pin_memory()): the DMA engine reads the caller's pages
+  // directly -- no packing pass through the bounce buffers, the host only enqueues
+  bool src_pinned = piped;
+  for (int v = 0; v < n_views && src_pinned; ++v) {
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, views[v].data) != hipSuccess) { (void)hipGetLastError(); src_pinned = false; break; }
+    src_pinned = at.type == hipMemoryTypeHost;
+    if (src_pinned) {   // ... for the whole extent that will be read
+      const char* last = static_cast<const char*>(views[v].data) + (size_t(n_rows - 1) * views[v].ld + views[v].cols) * es - 1;
+      hipPointerAttribute_t a2{};
+      if (hipPointerGetAttributes(&a2, last) != hipSuccess) { (void)hipGetLastError(); src_pinned = false; }
+      else src_pinned = a2.type == hipMemoryTypeHost;
+    }
+  }
+  static const bool pinned_direct = [] { const char* e = getenv("CCZ_H2D_PINNED_DIRECT"); return !e || atoi(e) != 0; }();
+  src_pinned = src_pinned && pinned_direct;
   std::vector<void*> stage(size_t(nslots) * n_views, nullptr);
   std::vector<ccz_view> dv(size_t(nslots) * n_views);
   void* tile_tab[2] = {nullptr, nullptr};
@@ -1288,13 +1304,20 @@ void moments_impl(ccz_ctx* c, int dtype, const ccz_view* views, int n_views, int
       const int64_t rows = std::min(chunk, n_rows - r0);
       const int sl = piped ? int(ci & 1) : 0;
       if (piped) {
-        if (ci >= 2) CCZ_HIP(hipEventSynchronize(im->pipe_ev[sl]));          // DMA of chunk ci-2 has drained this bounce buffer
-        pack_rows(static_cast<char*>(im->pin_buf[sl]), views, n_views, es, r0, rows, n_threads);
+        if (ci >= 2 && !src_pinned) CCZ_HIP(hipEventSynchronize(im->pipe_ev[sl]));   // DMA of chunk ci-2 has drained this bounce buffer
+        if (!src_pinned) pack_rows(static_cast<char*>(im->pin_buf[sl]), views, n_views, es, r0, rows, n_threads);
         if (ci >= 2) CCZ_HIP(hipStreamWaitEvent(im->copy_stream, im->pipe_ev[2 + sl], 0));   // K1 of chunk ci-2 done with this staging slot
         size_t off = 0;
         for (int v = 0; v < n_views; ++v) {
           const size_t bytes = size_t(rows) * views[v].cols * es;
-          CCZ_HIP(hipMemcpyAsync(stage[sl * n_views + v], static_cast<char*>(im->pin_buf[sl]) + off, bytes, hipMemcpyHostToDevice, im->copy_stream));
+          if (src_pinned) {
+            const char* src = static_cast<const char*>(views[v].data) + size_t(r0) * views[v].ld * es;
+            if (views[v].ld == views[v].cols) CCZ_HIP(hipMemcpyAsync(stage[sl * n_views + v], src, bytes, hipMemcpyHostToDevice, im->copy_stream));
+            else CCZ_HIP(hipMemcpy2DAsync(stage[sl * n_views + v], size_t(views[v].cols) * es, src, size_t(views[v].ld) * es,
+                                          size_t(views[v].cols) * es, size_t(rows), hipMemcpyHostToDevice, im->copy_stream));
+          } else {
+            CCZ_HIP(hipMemcpyAsync(stage[sl * n_views + v], static_cast<char*>(im->pin_buf[sl]) + off, bytes, hipMemcpyHostToDevice, im->copy_stream));
+          }
           off += bytes;
         }
         CCZ_HIP(hipEventRecord(im->pipe_ev[sl], im->copy_stream));

@@ -268,11 +268,15 @@ def test_bench_cpu_comparators_run_on_small_shapes():
     assert r["measured_s"] > 0 and r["data_dependent_s"] > 0 and r["eigen_solve_s"] >= 0
     assert abs(r["extrapolated_full_s"] - (r["eigen_solve_s"] + r["data_dependent_s"] * 10_000 / 200)) < 1e-9
     assert abs(r["value"] * r["extrapolated_full_s"] - 1.0) < 1e-12
-    b = bench.cpu_baseline(5_000, 16, 3, 128, runs=3)
-    assert b["kind"] == "port" and b["sample_rows"] == 128 and b["measured_s"] > 0 and b["runs"] == 3 and len(b["runs_s"]) == 3
-    assert abs(b["extrapolated_full_s"] - (b["fixed_s"] + b["data_dependent_s"] * 5_000 / 128)) < 1e-9
-    a = bench.cpu_baseline(50_000, 64, 3)                                          # default sample: 2 d rows, one run
-    assert a["sample_rows"] == 128 and a["runs"] == 1
+    b = bench.cpu_baseline(5_000, 16, 3, 128, runs=3)                               # slope from two sample sizes (round 4)
+    assert b["kind"] == "port" and b["n_dependent_s"]["rows"] == [128, 256] and b["measured_s"] > 0 and b["runs"] == 3
+    assert len(b["n_dependent_s"]["runs_s"][0]) == 3 and len(b["n_dependent_s"]["runs_s"][1]) == 2 and b["per_row_s"] >= 0
+    t1, t2 = b["n_dependent_s"]["median_s"]
+    assert abs(b["per_row_s"] - max((t2 - t1) / 128, 0.0)) < 1e-12
+    assert abs(b["extrapolated_full_s"] - (b["fixed_s"] + t1 + b["per_row_s"] * (5_000 - 128))) < 1e-9
+    assert abs(b["value"] * b["extrapolated_full_s"] - 1.0) < 1e-12
+    a = bench.cpu_baseline(50_000, 64, 3, runs=1)                                  # default sample: 2 d and 4 d rows
+    assert a["n_dependent_s"]["rows"] == [128, 256] and a["runs"] == 1
     g = bench.cpu_gcca_baseline(n_rows=120, dims=(20, 16, 30), k=4)
     assert g["measured_s"] > 0 and g["extrapolated_full_s"] is None
     t, src = bench.gram_traffic("f32", 8192, 1000)
