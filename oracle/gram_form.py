@@ -159,13 +159,14 @@ def _pinv_sym(Gii, rhs):
     return (V[:, keep] / lam[keep]) @ (V[:, keep].T @ rhs)
 
 
-def gcca_from_moments(G, s, n, dims, k, c=None, view_weights=None, eps=1e-6, center=True):
+def gcca_from_moments(G, s, n, dims, k, c=None, view_weights=None, eps=1e-6, center=True, topk=None):
     """GCCA weights (cca_zoo/linear/_gcca.py:80-110) in D x D Gram form.
 
     ``R_i`` always from the centred covariance (+ per-view eps floor);
     ``K_ij = sqrt(mu_i mu_j) L_i^-1 Gx_ij L_j^-T`` with ``Gx`` the second
     moments of the data *as fitted* (centred iff ``center``); top-k
     ``K u = lam u``; ``W_i = Gx_ii^+ sum_j sqrt(mu_j) Gx_ij L_j^-T u_j / sqrt(lam)``.
+    ``topk(K, k)``: optional replacement of the dense ``eigh`` for the top-k pairs (Lanczos at D = 16384).
     """
     m = len(dims)
     c = [0.0] * m if c is None else list(c)
@@ -188,8 +189,11 @@ def gcca_from_moments(G, s, n, dims, k, c=None, view_weights=None, eps=1e-6, cen
         K[bl[i], :] = np.sqrt(mu[i]) * scipy.linalg.solve_triangular(L[i], Z[bl[i], :], lower=True)
     K = 0.5 * (K + K.T)
     k = min(k, D, n)
-    lam, Uv = np.linalg.eigh(K)
-    lam, Uv = lam[::-1][:k], Uv[:, ::-1][:, :k]
+    if topk is None:
+        lam, Uv = np.linalg.eigh(K)
+        lam, Uv = lam[::-1][:k], Uv[:, ::-1][:, :k]
+    else:                                            # a sparse top-k solver for sizes where the dense eigh takes minutes
+        lam, Uv = topk(K, k)                         # (descending eigenvalues (k,), eigenvectors (D, k))
     rhs = Z @ Uv / np.sqrt(lam)                      # X' T  stacked by view   (D x k)
     W = [_pinv_sym(Gx[bl[i], bl[i]], rhs[bl[i]]) for i in range(m)]
     means = [s[b] / n if center else np.zeros(d) for b, d in zip(bl, dims)]
