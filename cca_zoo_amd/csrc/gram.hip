@@ -1241,13 +1241,13 @@ void moments_impl(ccz_ctx* c, int dtype, const ccz_view* views, int n_views, int
     else launch_moments<double>(c, views, n_views, n_rows, G, s, D, time_it, nullptr, 0);
     return;
   }
-  // Host-resident (pageable) views: a three-stage pipeline over ~512 MiB row chunks,
+  // Host-resident (pageable) views: a three-stage pipeline over ~1 GiB row chunks (tapering at the end),
   //   host threads pack chunk i+1 into a pinned bounce buffer  ||  DMA of chunk i (copy stream)  ||  K1 on chunk i-1,
   // two slots of pinned + device staging, events between the stages.  Small inputs, or a host that
   // refuses pinned memory, take the plain copy-then-compute loop.
   int64_t row_bytes = 0;
   for (int v = 0; v < n_views; ++v) row_bytes += views[v].cols * int64_t(es);
-  const int64_t chunk_mb = [] { const char* e = getenv("CCZ_H2D_CHUNK_MB"); return e ? std::max<int64_t>(1, atoll(e)) : 512LL; }();
+  const int64_t chunk_mb = [] { const char* e = getenv("CCZ_H2D_CHUNK_MB"); return e ? std::max<int64_t>(1, atoll(e)) : 1024LL; }();
   const int n_threads = [] {
     const char* e = getenv("CCZ_H2D_THREADS");
     if (e) return std::max(1, atoi(e));
@@ -1300,8 +1300,15 @@ void moments_impl(ccz_ctx* c, int dtype, const ccz_view* views, int n_views, int
     // the PCIe copy (47 GB/s against > 100 TF), needs no read-back, and a decision taken on the first chunk alone
     // would be wrong for data whose later rows drift away from zero (sorted / padded / time-ordered inputs).
     const int chunk_mode = pilot_mode == 1 ? 2 : pilot_mode;
-    for (int64_t r0 = 0; r0 < n_rows; r0 += chunk, ++ci) {
-      const int64_t rows = std::min(chunk, n_rows - r0);
+    // The pipeline is bound by the copy; what it cannot hide is the K1 of the LAST chunk.  So the chunks taper towards
+    // the end (each at most half of what is left, down to ~128 MiB): the drain shrinks from one full chunk's K1 to a
+    // few milliseconds, while the bulk still moves in large chunks on which K1 runs at its full rate.
+    const int64_t min_chunk = std::max<int64_t>(64, ((int64_t(128) << 20) / row_bytes) / 64 * 64);
+    int64_t rows = 0;
+    for (int64_t r0 = 0; r0 < n_rows; r0 += rows, ++ci) {
+      const int64_t left = n_rows - r0;
+      rows = std::min(chunk, left);
+      if (piped && left < 2 * chunk && left > min_chunk) rows = std::min(rows, std::max(min_chunk, (left / 2 + 63) / 64 * 64));
       const int sl = piped ? int(ci & 1) : 0;
       if (piped) {
         if (ci >= 2 && !src_pinned) CCZ_HIP(hipEventSynchronize(im->pipe_ev[sl]));   // DMA of chunk ci-2 has drained this bounce buffer
