@@ -52,6 +52,9 @@ struct BjStatus {       // device-resident
   int bad;              // non-finite input
   double hmax;          // max |A| (two-sided) / largest squared row norm (one-sided), as set by the prep kernels
   double maxoff;        // largest |s_pq| that was rotated in the sweep in flight (two-sided form)
+  long long g0;         // fused form: global round index of round 0 of the sweep in flight (buffers rotate with it)
+  long long direct_g;   // fused form: the global round whose pair kernels read their cross blocks directly (first round
+                        // of a solve, first round after a refresh: no previous round to re-apply)
 };
 
 __device__ __forceinline__ void atomic_max_nonneg(double* addr, double v) {   // v >= 0 or non-finite (NaN -> inf)
@@ -231,13 +234,22 @@ __device__ __forceinline__ Rot bj_rotation(double hpp, double hqq, double hpq, d
 template <int MODE>
 __global__ __launch_bounds__(BJ2_THREADS) void k_bj_inner2(double* __restrict__ A, int64_t lda, const double* __restrict__ G,
                                                            int nsplit, double* __restrict__ Rt_out, BjStatus* __restrict__ st,
-                                                           int nb, int round, int full, double tol, long long* __restrict__ dbg) {
+                                                           int nb, int round, int full, double tol, long long* __restrict__ dbg,
+                                                           int* __restrict__ ident) {
   __shared__ __attribute__((aligned(16))) double Hs[2][BJ_NH];
   __shared__ __attribute__((aligned(16))) double Rt[BJP * BJP];     // Rt[j][i] = R[i][j]
   __shared__ __attribute__((aligned(16))) jac_cs csn[2][BJB];
+  __shared__ __attribute__((aligned(16))) double Xs[MODE == 2 ? BJP * AP_SX + 2 * BJB * AP_SX : 2];   // fused form: old tile + two R parts
+  __shared__ int src_pair[4];                                       // fused form: (pair, member) of ba and of bb in the previous round
   const int tid = threadIdx.x;
   int ba, bb;
   pair_of(round, blockIdx.x, nb - 1, ba, bb);
+  // fused form (MODE 2): three rotating copies of A (state g in plane g % 3) and two of the rotations (plane g & 1)
+  const int64_t plane = lda * lda;
+  const long long g = MODE == 2 ? st->g0 + round : 0;
+  double* A_nxt = MODE == 2 ? A + ((g + 1) % 3) * plane : A;
+  if (MODE == 2) A += (g % 3) * plane;
+  if (MODE == 2) Rt_out += (g & 1) * int64_t(nb >> 1) * (BJP * BJP);
   // CCZ_BJ_DEBUG: shader-clock stamps of workgroup 0 (thread 0: the parameter wave; thread 64: an S wave; thread 640: an R wave)
   const bool stamp = dbg && blockIdx.x == 0 && (tid == 0 || tid == 64 || tid == 640);
   long long* my_dbg = dbg ? dbg + (tid == 0 ? 0 : (tid == 64 ? 64 : 128)) : nullptr;
@@ -246,12 +258,13 @@ __global__ __launch_bounds__(BJ2_THREADS) void k_bj_inner2(double* __restrict__ 
   mark();
   const double hmax = st->hmax;
   // ---- load S (coalesced: the two diagonal sub-blocks and the canonical cross block) ----
-  if (MODE == 0) {
+  const bool refuse = MODE == 2 && g != st->direct_g;               // the cross block is re-derived from the previous round
+  if (MODE != 1) {
     const int lo = min(ba, bb), hi = max(ba, bb), offlo = lo == ba ? 0 : BJB, offhi = hi == ba ? 0 : BJB;
     for (int e = tid; e < 3 * BJB * BJB; e += BJ2_THREADS) {
       const int blk = e >> 10, r = (e >> 5) & (BJB - 1), cc = e & (BJB - 1);
       if (blk == 2) {
-        Hs[0][tri_off(offlo + r, offhi + cc)] = A[(int64_t(lo) * BJB + r) * lda + hi * BJB + cc];
+        if (!refuse) Hs[0][tri_off(offlo + r, offhi + cc)] = A[(int64_t(lo) * BJB + r) * lda + hi * BJB + cc];
       } else if (cc <= r) {
         const int b = blk == 0 ? ba : bb, off = blk * BJB;
         Hs[0][tri_off(off + r, off + cc)] = A[(int64_t(b) * BJB + r) * lda + b * BJB + cc];
@@ -262,19 +275,121 @@ __global__ __launch_bounds__(BJ2_THREADS) void k_bj_inner2(double* __restrict__ 
       int i, j;
       tri_decode(e, i, j);
       double h = 0.0;
-      const double* g = G + int64_t(blockIdx.x) * nsplit * (BJP * BJP) + i * BJP + j;
-      for (int s = 0; s < nsplit; ++s) h += g[int64_t(s) * (BJP * BJP)];
+      const double* gp = G + int64_t(blockIdx.x) * nsplit * (BJP * BJP) + i * BJP + j;
+      for (int s = 0; s < nsplit; ++s) h += gp[int64_t(s) * (BJP * BJP)];
       Hs[0][e] = h;
     }
+  }
+  if (MODE == 2 && refuse) {
+    // The pair's cross block after the PREVIOUS round is one 32 x 32 piece of that round's tile (pair of ba, pair of bb):
+    //   S_ab = Rt_Ka[rows of ba] . X . Rt_Kb[rows of bb]'   with X the old tile (state g - 1) -- two small products on
+    // the matrix pipe here, so that this kernel depends on the previous PAIR kernel only and the previous round's
+    // O(d^2) tile update (k_bj_apply, on a second stream) runs underneath it instead of in front of it.
+    const int np_ = nb >> 1, rp = round == 0 ? nb - 2 : round - 1;
+    const long long go = g - 1;
+    const double* Ao = (A - (g % 3) * plane) + (go % 3) * plane;
+    const double* Rp = (Rt_out - (g & 1) * int64_t(np_) * (BJP * BJP)) + (go & 1) * int64_t(np_) * (BJP * BJP);
+    if (tid < np_) {
+      int x, y;
+      pair_of(rp, tid, nb - 1, x, y);
+      if (x == ba) { src_pair[0] = tid; src_pair[1] = 0; }
+      if (y == ba) { src_pair[0] = tid; src_pair[1] = 1; }
+      if (x == bb) { src_pair[2] = tid; src_pair[3] = 0; }
+      if (y == bb) { src_pair[2] = tid; src_pair[3] = 1; }
+    }
+    __syncthreads();
+    const int Ka = src_pair[0], ia = src_pair[1], Kb = src_pair[2], ib = src_pair[3];
+    int xb[2], yb[2];
+    pair_of(rp, Ka, nb - 1, xb[0], xb[1]);
+    pair_of(rp, Kb, nb - 1, yb[0], yb[1]);
+    double* PA = Xs + BJP * AP_SX;
+    double* PB = PA + BJB * AP_SX;
+    for (int e = tid; e < BJP * BJP / 2; e += BJ2_THREADS) {        // the old tile, 16-byte pieces, mirrored blocks transposed
+      const int sblk = e >> 9, piece = e & 511, row = piece >> 4, c2 = (piece & 15) * 2;
+      const int si = sblk >> 1, sj = sblk & 1, x = xb[si], y = yb[sj];
+      const bool direct = x < y;
+      const double* base = direct ? Ao + int64_t(x) * BJB * lda + y * BJB : Ao + int64_t(y) * BJB * lda + x * BJB;
+      const v2f64 v = *reinterpret_cast<const v2f64*>(base + int64_t(row) * lda + c2);
+      if (direct) {
+        *reinterpret_cast<v2f64*>(Xs + (BJB * si + row) * AP_SX + BJB * sj + c2) = v;
+      } else {
+        Xs[(BJB * si + c2) * AP_SX + BJB * sj + row] = v.x;
+        Xs[(BJB * si + c2 + 1) * AP_SX + BJB * sj + row] = v.y;
+      }
+    }
+    for (int e = tid; e < 2 * BJB * BJP / 2; e += BJ2_THREADS) {    // 32 rows of each of the two rotations
+      const int which = e >> 10, piece = e & 1023, row = piece >> 5, c2 = (piece & 31) * 2;
+      const double* src = Rp + int64_t(which ? Kb : Ka) * (BJP * BJP) + (BJB * (which ? ib : ia) + row) * BJP + c2;
+      *reinterpret_cast<v2f64*>((which ? PB : PA) + row * AP_SX + c2) = *reinterpret_cast<const v2f64*>(src);
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    double* Ys = Rt;                                                // 64 x 32, stride 48 (B-fragment reads); Rt is set up later
+    if (wave < 8) {                                                 // Y = X Rt_Kb[rows of bb]'  (64 x 32)
+      const int mt = wave >> 1, nt = wave & 1;
+      v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const double a = Xs[(16 * mt + l15) * AP_SX + 4 * ks + l4];
+        const double b = PB[(16 * nt + l15) * AP_SX + 4 * ks + l4];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Ys[(16 * mt + l4 + 4 * r) * 48 + 16 * nt + l15] = acc[r];
+    }
+    __syncthreads();
+    if (wave < 4) {                                                 // S_ab = Rt_Ka[rows of ba] Y  (32 x 32)
+      const int it = wave >> 1, jt = wave & 1;
+      v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const double a = PA[(16 * it + l15) * AP_SX + 4 * ks + l4];
+        const double b = Ys[(4 * ks + l4) * 48 + 16 * jt + l15];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Hs[0][tri_off(BJB + 16 * jt + l15, 16 * it + l4 + 4 * r)] = acc[r];
+    }
+    __syncthreads();
   }
   if (!(hmax > 0.0) || !(hmax < __builtin_inf())) {                 // zero or non-finite input: identity, nothing rotates
     for (int e = tid; e < BJP * BJP; e += BJ2_THREADS) Rt_out[int64_t(blockIdx.x) * (BJP * BJP) + e] = ((e >> 6) == (e & 63)) ? 1.0 : 0.0;
     if (tid == 0 && !(hmax < __builtin_inf())) st->bad = 1;
+    if (MODE == 2) {                                                // the next state's plane still gets this pair's blocks
+      __syncthreads();
+      const int lo = min(ba, bb), hi = max(ba, bb), offlo = lo == ba ? 0 : BJB, offhi = hi == ba ? 0 : BJB;
+      for (int e = tid; e < 3 * BJB * BJB; e += BJ2_THREADS) {
+        const int blk = e >> 10, r = (e >> 5) & (BJB - 1), cc = e & (BJB - 1);
+        if (blk == 2) A_nxt[(int64_t(lo) * BJB + r) * lda + hi * BJB + cc] = Hs[0][tri_off(offlo + r, offhi + cc)];
+        else { const int b = blk == 0 ? ba : bb, off = blk * BJB; A_nxt[(int64_t(b) * BJB + r) * lda + b * BJB + cc] = Hs[0][tri_off(off + r, off + cc)]; }
+      }
+    }
     return;
   }
   for (int e = tid; e < BJP * BJP; e += BJ2_THREADS) Rt[e] = ((e >> 6) == (e & 63)) ? 1.0 : 0.0;
-  const double thr = MODE == 0 ? BJ_EPS * hmax : 0.0, ih = 1.0 / hmax, half_ih = 0.5 * ih, floor2 = hmax * 1e-28;
+  const double thr = MODE != 1 ? BJ_EPS * hmax : 0.0, ih = 1.0 / hmax, half_ih = 0.5 * ih, floor2 = hmax * 1e-28;
   const int nr = full ? BJP - 1 : BJB;
+  if (MODE != 2) {
+    // Nothing to rotate in this pair (the rule in the last sweeps, and all of the final, verifying one)?  Then R = I, S
+    // stays as it is, and the tile update skips every tile whose two pairs are both at rest (ident[]).
+    __syncthreads();
+    int live = 0;
+    for (int e = tid; e < (full ? BJP * (BJP - 1) / 2 : BJB * BJB); e += BJ2_THREADS) {
+      int i, j;
+      if (full) { tri_decode(e, i, j); ++i; }                       // i > j: every pair of the 64
+      else { i = BJB + (e >> 5); j = e & (BJB - 1); }               // the cross block
+      const double hpq = Hs[0][tri_off(i, j)];
+      if (MODE == 0) live |= fabs(hpq) > thr;
+      else { const double hpp = Hs[0][tri_off(j, j)], hqq = Hs[0][tri_off(i, i)]; live |= hpp > floor2 && hqq > floor2 && hpq * hpq > tol * tol * hpp * hqq; }
+    }
+    live = __syncthreads_or(live);
+    if (tid == 0) ident[blockIdx.x] = live ? 0 : 1;
+    if (!live) {
+      v2f64* ro = reinterpret_cast<v2f64*>(Rt_out + int64_t(blockIdx.x) * (BJP * BJP));
+      for (int e = tid; e < BJP * BJP / 2; e += BJ2_THREADS) ro[e] = reinterpret_cast<const v2f64*>(Rt)[e];
+      return;
+    }
+  }
   // roles.  A wave issues one fp64 VALU instruction per 32 cycles whatever the dependencies (measured with the stamps
   // below: 2200 cycles for ~60 fp64 instructions of the parameter wave, 2100 for the 32 + LDS of an R wave), so the
   // round time is the LARGEST fp64 instruction count of any wave: parameters ~23, an S block 16, six R rotations 24.
@@ -300,11 +415,11 @@ __global__ __launch_bounds__(BJ2_THREADS) void k_bj_inner2(double* __restrict__ 
   int my_rot = 0;
   auto decide = [&]() {                                             // lanes 0..31: (hpp, hqq, hpq) -> cur_rot
     bool go;
-    if (MODE == 0) go = fabs(hpq) > thr;
+    if (MODE != 1) go = fabs(hpq) > thr;
     else go = hpp > floor2 && hqq > floor2 && hpq * hpq > tol * tol * hpp * hqq;
     cur_rot = Rot{1.0, 0.0, 0.0};
     if (go) {
-      cur_rot = bj_rotation<MODE>(hpp, hqq, hpq, half_ih, ih);
+      cur_rot = bj_rotation<(MODE == 1 ? 1 : 0)>(hpp, hqq, hpq, half_ih, ih);
       ++my_rot;
       my_max = fmax(my_max, fabs(hpq));
     }
@@ -400,15 +515,15 @@ __global__ __launch_bounds__(BJ2_THREADS) void k_bj_inner2(double* __restrict__ 
   __syncthreads();
   mark();
   const double* Sf = Hs[nr & 1];
-  if (MODE == 0) {
+  if (MODE != 1) {                                                  // (fused form: into the NEXT state's plane)
     const int lo = min(ba, bb), hi = max(ba, bb), offlo = lo == ba ? 0 : BJB, offhi = hi == ba ? 0 : BJB;
     for (int e = tid; e < 3 * BJB * BJB; e += BJ2_THREADS) {
       const int blk = e >> 10, r = (e >> 5) & (BJB - 1), cc = e & (BJB - 1);
       if (blk == 2) {
-        A[(int64_t(lo) * BJB + r) * lda + hi * BJB + cc] = Sf[tri_off(offlo + r, offhi + cc)];
+        A_nxt[(int64_t(lo) * BJB + r) * lda + hi * BJB + cc] = Sf[tri_off(offlo + r, offhi + cc)];
       } else {
         const int b = blk == 0 ? ba : bb, off = blk * BJB;
-        A[(int64_t(b) * BJB + r) * lda + b * BJB + cc] = Sf[tri_off(off + r, off + cc)];
+        A_nxt[(int64_t(b) * BJB + r) * lda + b * BJB + cc] = Sf[tri_off(off + r, off + cc)];
       }
     }
   }
@@ -422,7 +537,7 @@ __global__ __launch_bounds__(BJ2_THREADS) void k_bj_inner2(double* __restrict__ 
     }
     if (tid == 0 && my_rot > 0) {
       atomicAdd(&st->rotations, my_rot);
-      if (MODE == 0) atomic_max_nonneg(&st->maxoff, my_max);
+      if (MODE != 1) atomic_max_nonneg(&st->maxoff, my_max);
     }
   }
   mark();
@@ -439,8 +554,11 @@ struct BjRows {
   int64_t cols[2];
 };
 
+// part: 0 = both kinds of tile in one launch, 1 = the A tiles only, 2 = the row tiles only.  fused: A is three rotating
+// planes (read state g, write state g + 1) and Rt_all two (g & 1), g = st->g0 + round.
 __global__ __launch_bounds__(256, 2) void k_bj_apply(double* __restrict__ A, int64_t lda, BjRows rows, const double* __restrict__ Rt_all,
-                                                     int nb, int round, int nA) {
+                                                     int nb, int round, int nA, const BjStatus* __restrict__ st, int fused,
+                                                     const int* __restrict__ ident) {
   extern __shared__ __attribute__((aligned(16))) char bj_smem[];
   double* X = reinterpret_cast<double*>(bj_smem);                   // 64 x 80
   double* Rs = X + BJP * AP_SB;                                     // 64 x 66
@@ -450,11 +568,20 @@ __global__ __launch_bounds__(256, 2) void k_bj_apply(double* __restrict__ A, int
   v4f64 acc[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = v4f64{0.0, 0.0, 0.0, 0.0};
+  double* A_out = A;
+  if (fused) {
+    const long long g = st->g0 + round;
+    const int64_t plane = lda * lda;
+    A_out = A + ((g + 1) % 3) * plane;
+    A += (g % 3) * plane;
+    Rt_all += (g & 1) * int64_t(nb >> 1) * (BJP * BJP);
+  }
 
   if (int(blockIdx.x) < nA) {
     int ti, tj;
     tri_decode(blockIdx.x, ti, tj);
     const int K = tj, L = ti + 1;                                   // K < L
+    if (ident && ident[K] && ident[L]) return;                      // both pairs at rest: the tile does not change
     int bk[2], bl[2];
     pair_of(round, K, m1, bk[0], bk[1]);
     pair_of(round, L, m1, bl[0], bl[1]);
@@ -526,7 +653,7 @@ __global__ __launch_bounds__(256, 2) void k_bj_apply(double* __restrict__ A, int
     for (int s = 0; s < 4; ++s) {
       const int si = s >> 1, sj = s & 1, x = bk[si], y = bl[sj];
       const bool direct = x < y;
-      double* base = direct ? A + int64_t(x) * BJB * lda + y * BJB : A + int64_t(y) * BJB * lda + x * BJB;
+      double* base = direct ? A_out + int64_t(x) * BJB * lda + y * BJB : A_out + int64_t(y) * BJB * lda + x * BJB;
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
         const int piece = tid + 256 * it, row = piece >> 4, c2 = (piece & 15) * 2;
@@ -550,6 +677,7 @@ __global__ __launch_bounds__(256, 2) void k_bj_apply(double* __restrict__ A, int
   if (t >= np * rows.chunks[0]) { t -= np * rows.chunks[0]; which = 1; }
   const int nch = rows.chunks[which];
   const int K = t / nch, ch = t - K * nch;
+  if (ident && ident[K]) return;
   double* M = rows.M[which];
   const int64_t ld = rows.ld[which], c0 = int64_t(ch) * 64, ncol = rows.cols[which];
   int bk[2];
@@ -680,15 +808,23 @@ bool bj_inner_pipelined() {   // CCZ_BJ_INNER=1: the two-barrier pair kernel (A/
   return v;
 }
 
+bool bj_fused() {   // CCZ_BJ_FUSED=1: pair kernels and tile updates on two streams (A/B; measured: no gain, see syev_block)
+  static const bool v = [] { const char* e = getenv("CCZ_BJ_FUSED"); return e && atoi(e) == 1; }();
+  return v;
+}
+
 int bj_max_gram_split() {
   static const int v = [] { const char* e = getenv("CCZ_BJ_GRAM_SPLIT"); return e ? std::max(1, atoi(e)) : 0; }();
   return v;
 }
 
-struct StatusBuf {
+struct StatusBuf {     // BjStatus followed by one "pair at rest" flag per pair
   ccz_ctx* c;
   BjStatus* dev;
-  explicit StatusBuf(ccz_ctx* c_) : c(c_), dev(static_cast<BjStatus*>(dev_alloc(c_, sizeof(BjStatus)))) {}
+  int* ident;
+  StatusBuf(ccz_ctx* c_, int np) : c(c_), dev(static_cast<BjStatus*>(dev_alloc(c_, sizeof(BjStatus) + size_t(np) * sizeof(int)))) {
+    ident = reinterpret_cast<int*>(dev + 1);
+  }
   ~StatusBuf() { dev_free(c, dev); }
 };
 
@@ -718,14 +854,33 @@ int syev_block(ccz_ctx* c, const double* A, int64_t d, int64_t lda, double* w_de
   if (d < 1) fail(CCZ_EINVAL, "syev_block: d >= 1 required");
   static const int refresh_min = [] { const char* e = getenv("CCZ_EVD_REFRESH_MIN"); return e ? atoi(e) : 1536; }();
   const bool want_refresh = d >= refresh_min;
-  const int64_t dp = (d + BJP - 1) / BJP * BJP;
+  const int64_t dp = (d + BJP - 1) / BJP * BJP, plane = dp * dp;
   const int nb = int(dp / BJB), np = nb / 2;
-  DBuf Aw(c, dp * dp), Vt(c, dp * dp), Rt(c, int64_t(np) * BJP * BJP), A0(c, want_refresh ? dp * dp : 0);
-  StatusBuf sb(c);
+  // Fused schedule (default from 4 blocks on): the pair kernel of round g + 1 re-derives its cross block from the OLD tile
+  // and round g's rotations, so it depends on the pair kernel of round g only; round g's tile update (k_bj_apply) runs on a
+  // second stream underneath it.  A then lives in three rotating planes (state g in plane g % 3: read by the tile update of
+  // round g and by the pair kernels of round g + 1, written by those of round g - 1), the rotations in two.
+  Impl* im = impl(c);
   hipStream_t st = stream(c);
+  // MEASURED (round 4): no gain.  The pair kernel's workgroups (1024 threads, 134 KB of LDS: a whole CU each) do not get
+  // CUs while the tile update floods the chip with thousands of small workgroups -- 190 us per round at d = 4096 against
+  // 174 serial, 19.8 against 19.3 ms at d = 1024, with or without hipGraphs; a CU-masked stream for the tile updates
+  // (hipExtStreamCreateWithCUMask, every 8th / 4th CU left free) made d = 1024 slower still (29 ms).  The schedule is
+  // kept behind CCZ_BJ_FUSED=1 for A/B runs; the default is the serial alternation on one stream.
+  hipStream_t side = nullptr;
+  const bool fused = bj_fused() && nb >= 4 && bj_inner_pipelined() && st != nullptr;
+  if (fused) {
+    if (!im->aux_stream) CCZ_HIP(hipStreamCreateWithFlags(&im->aux_stream, hipStreamNonBlocking));
+    side = im->aux_stream;
+  }
+  const int nplanes = fused ? 3 : 1;
+  DBuf Aw(c, nplanes * plane), Vt(c, plane), Rt(c, int64_t(fused ? 2 : 1) * np * BJP * BJP), A0(c, want_refresh ? plane : 0);
+  StatusBuf sb(c, np);
   apply_attr_once();
-  CCZ_HIP(hipMemsetAsync(sb.dev, 0, sizeof(BjStatus), st));
-  const dim3 pgrid((unsigned)std::min<int64_t>((dp * dp + 255) / 256, 4096));
+  if (fused)
+    for (auto& e : im->bj_ev) if (!e) CCZ_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  CCZ_HIP(hipMemsetAsync(sb.dev, 0, sizeof(BjStatus) + size_t(np) * sizeof(int), st));
+  const dim3 pgrid((unsigned)std::min<int64_t>((plane + 255) / 256, 4096));
   hipLaunchKernelGGL(k_bj_prep_sym, pgrid, dim3(256), 0, st, A, lda, d, dp, Aw.get(), want_refresh ? A0.get() : (double*)nullptr, Vt.get(),
                      sb.dev);
   CCZ_LAUNCH_CHECK();
@@ -734,28 +889,53 @@ int syev_block(ccz_ctx* c, const double* A, int64_t d, int64_t lda, double* w_de
   rows.M[0] = Vt.get(); rows.ld[0] = dp; rows.chunks[0] = vch; rows.cols[0] = dp;
   rows.M[1] = nullptr; rows.ld[1] = 0; rows.chunks[1] = 0; rows.cols[1] = 0;
   const int nV = np * vch;
-  uint64_t key = graph_key_mix(graph_key_mix(0x424a5359ull, uint64_t(dp)), reinterpret_cast<uint64_t>(Aw.get()));
+  uint64_t key = graph_key_mix(graph_key_mix(0x424a5359ull + (fused ? 1 : 0), uint64_t(dp)), reinterpret_cast<uint64_t>(Aw.get()));
   key = graph_key_mix(graph_key_mix(key, reinterpret_cast<uint64_t>(Vt.get())), reinterpret_cast<uint64_t>(Rt.get()));
-  key = graph_key_mix(key, reinterpret_cast<uint64_t>(sb.dev));
+  key = graph_key_mix(graph_key_mix(key, reinterpret_cast<uint64_t>(sb.dev)), reinterpret_cast<uint64_t>(side));
   int sweeps = -1;
   bool refreshed = false;
+  long long g_total = 0, direct_g = 0;                    // (fused) global round counter; the round that reads its cross blocks directly
   static const bool dbg_on = getenv("CCZ_BJ_DEBUG") != nullptr;
   DBuf dbgb(c, dbg_on ? 192 : 0);
   for (int sweep = 1; sweep <= max_sweeps; ++sweep) {
     CCZ_HIP(hipMemsetAsync(&sb.dev->rotations, 0, sizeof(int), st));
     CCZ_HIP(hipMemsetAsync(&sb.dev->maxoff, 0, sizeof(double), st));
+    if (fused) {
+      const long long ctl[2] = {g_total, direct_g};
+      h2d_small(c, &sb.dev->g0, ctl, sizeof ctl);
+    }
     graph_run_fn(c, key, [&] {
-      for (int round = 0; round < nb - 1; ++round) {
-        if (bj_inner_pipelined())
-          hipLaunchKernelGGL(k_bj_inner2<0>, dim3(np), dim3(BJ2_THREADS), 0, st, Aw.get(), dp, (const double*)nullptr, 0, Rt.get(), sb.dev,
-                             nb, round, round == 0 ? 1 : 0, 0.0, dbg_on && round == 1 ? (long long*)dbgb.get() : (long long*)nullptr);
-        else
-          hipLaunchKernelGGL(k_bj_inner<0>, dim3(np), dim3(BJ_THREADS), 0, st, Aw.get(), dp, (const double*)nullptr, 0, Rt.get(), sb.dev, nb,
-                             round, round == 0 ? 1 : 0, 0.0);
-        hipLaunchKernelGGL(k_bj_apply, dim3(nA + nV), dim3(256), kApplyLds, st, Aw.get(), dp, rows, (const double*)Rt.get(), nb, round, nA);
+      if (!fused) {
+        for (int round = 0; round < nb - 1; ++round) {
+          if (bj_inner_pipelined())
+            hipLaunchKernelGGL(k_bj_inner2<0>, dim3(np), dim3(BJ2_THREADS), 0, st, Aw.get(), dp, (const double*)nullptr, 0, Rt.get(), sb.dev,
+                               nb, round, round == 0 ? 1 : 0, 0.0, dbg_on && round == 1 ? (long long*)dbgb.get() : (long long*)nullptr, sb.ident);
+          else
+            hipLaunchKernelGGL(k_bj_inner<0>, dim3(np), dim3(BJ_THREADS), 0, st, Aw.get(), dp, (const double*)nullptr, 0, Rt.get(), sb.dev, nb,
+                               round, round == 0 ? 1 : 0, 0.0);
+          hipLaunchKernelGGL(k_bj_apply, dim3(nA + nV), dim3(256), kApplyLds, st, Aw.get(), dp, rows, (const double*)Rt.get(), nb, round, nA,
+                             (const BjStatus*)sb.dev, 0, (const int*)sb.ident);
+        }
+      } else {
+        // main stream: the chain of pair kernels; side stream: the tile updates.  pair(r) waits for update(r - 2) (it
+        // overwrites the plane and the rotation buffer that update read); update(r) waits for pair(r).
+        hipEvent_t* evI = im->bj_ev;        // [4]: pair kernel r done
+        hipEvent_t* evU = im->bj_ev + 4;    // [4]: tile update r done
+        for (int round = 0; round < nb - 1; ++round) {
+          if (round >= 2) CCZ_HIP(hipStreamWaitEvent(st, evU[(round - 2) & 3], 0));
+          hipLaunchKernelGGL(k_bj_inner2<2>, dim3(np), dim3(BJ2_THREADS), 0, st, Aw.get(), dp, (const double*)nullptr, 0, Rt.get(), sb.dev,
+                             nb, round, round == 0 ? 1 : 0, 0.0, dbg_on && round == 1 ? (long long*)dbgb.get() : (long long*)nullptr, sb.ident);
+          CCZ_HIP(hipEventRecord(evI[round & 3], st));
+          CCZ_HIP(hipStreamWaitEvent(side, evI[round & 3], 0));
+          hipLaunchKernelGGL(k_bj_apply, dim3(nA + nV), dim3(256), kApplyLds, side, Aw.get(), dp, rows, (const double*)Rt.get(), nb, round, nA,
+                             (const BjStatus*)sb.dev, 1, (const int*)nullptr);
+          CCZ_HIP(hipEventRecord(evU[round & 3], side));
+        }
+        for (int round = std::max(0, nb - 3); round < nb - 1; ++round) CCZ_HIP(hipStreamWaitEvent(st, evU[round & 3], 0));   // join
       }
       CCZ_LAUNCH_CHECK();
     });
+    g_total += nb - 1;
     BjStatus h{};
     d2h(c, &h, sb.dev, sizeof(BjStatus));
     if (dbg_on && sweep == 2) {
@@ -771,17 +951,20 @@ int syev_block(ccz_ctx* c, const double* A, int64_t d, int64_t lda, double* w_de
     if (h.rotations == 0) { sweeps = sweep; break; }
     if (want_refresh && !refreshed && h.maxoff <= 1e-6 * h.hmax) {
       refreshed = true;
-      DBuf G(c, dp * dp), V2(c, dp * dp);
+      double* cur = Aw.get() + (fused ? (g_total % 3) * plane : 0);
+      DBuf G(c, plane), V2(c, plane);
       gemm(c, false, true, dp, dp, dp, 1.0, Vt, dp, Vt, dp, 0.0, G, dp);             // G = V' V
       gemm(c, false, false, dp, dp, dp, -0.5, G, dp, Vt, dp, 0.0, V2, dp);           // V2 = (1.5 I - 0.5 G) V'
       axpby2d(c, dp, dp, 1.0, V2, dp, 1.5, Vt, dp);
       gemm(c, false, false, dp, dp, dp, 1.0, V2, dp, A0, dp, 0.0, G, dp);            // G = V2 A0
-      gemm(c, false, true, dp, dp, dp, 1.0, G, dp, V2, dp, 0.0, Aw, dp);             // B = V2 A0 V2'
-      d2d(c, Vt, V2, size_t(dp) * dp * 8);
+      gemm(c, false, true, dp, dp, dp, 1.0, G, dp, V2, dp, 0.0, cur, dp);            // B = V2 A0 V2'
+      d2d(c, Vt, V2, size_t(plane) * 8);
+      direct_g = g_total;                                                            // no previous round to re-apply
     }
   }
   if (sweeps < 0) fail(CCZ_ENOCONV, "block Jacobi did not converge in %d sweeps (d=%lld)", max_sweeps, (long long)d);
-  hipLaunchKernelGGL(k_bj_diag, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st, (const double*)Aw.get(), dp, d, w_dev);
+  const double* fin = Aw.get() + (fused ? (g_total % 3) * plane : 0);
+  hipLaunchKernelGGL(k_bj_diag, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st, fin, dp, d, w_dev);
   CCZ_LAUNCH_CHECK();
   if (Vrows) copy2d(c, d, d, Vt.get(), dp, Vrows, ldv);
   return sweeps;
@@ -798,10 +981,10 @@ int jacobi_rows_block(ccz_ctx* c, int64_t p, int64_t q, double* W, int64_t ldw, 
     nsplit = int(std::max<int64_t>(1, std::min<int64_t>(nchunks / 4, (512 + np - 1) / np)));
   }
   DBuf Rt(c, int64_t(np) * BJP * BJP), G(c, int64_t(np) * nsplit * BJP * BJP);
-  StatusBuf sb(c);
+  StatusBuf sb(c, np);
   hipStream_t st = stream(c);
   apply_attr_once();
-  CCZ_HIP(hipMemsetAsync(sb.dev, 0, sizeof(BjStatus), st));
+  CCZ_HIP(hipMemsetAsync(sb.dev, 0, sizeof(BjStatus) + size_t(np) * sizeof(int), st));
   hipLaunchKernelGGL(k_bj_prep_rows, dim3((unsigned)p), dim3(64), 0, st, (const double*)W, ldw, q, sb.dev);
   CCZ_LAUNCH_CHECK();
   BjRows rows{};
@@ -822,12 +1005,12 @@ int jacobi_rows_block(ccz_ctx* c, int64_t p, int64_t q, double* W, int64_t ldw, 
         hipLaunchKernelGGL(k_bj_gram, dim3(np, nsplit), dim3(256), 0, st, (const double*)W, ldw, q, nb, round, nsplit, G.get());
         if (bj_inner_pipelined())
           hipLaunchKernelGGL(k_bj_inner2<1>, dim3(np), dim3(BJ2_THREADS), 0, st, (double*)nullptr, int64_t(0), (const double*)G.get(), nsplit,
-                             Rt.get(), sb.dev, nb, round, round == 0 ? 1 : 0, tol, (long long*)nullptr);
+                             Rt.get(), sb.dev, nb, round, round == 0 ? 1 : 0, tol, (long long*)nullptr, sb.ident);
         else
           hipLaunchKernelGGL(k_bj_inner<1>, dim3(np), dim3(BJ_THREADS), 0, st, (double*)nullptr, int64_t(0), (const double*)G.get(), nsplit,
                              Rt.get(), sb.dev, nb, round, round == 0 ? 1 : 0, tol);
         hipLaunchKernelGGL(k_bj_apply, dim3(nV), dim3(256), kApplyLds, st, (double*)nullptr, int64_t(0), rows, (const double*)Rt.get(), nb,
-                           round, 0);
+                           round, 0, (const BjStatus*)sb.dev, 0, (const int*)sb.ident);
       }
       CCZ_LAUNCH_CHECK();
     });
