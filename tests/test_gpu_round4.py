@@ -157,11 +157,22 @@ def test_c5_gcca_weights_against_the_oracle_at_full_dimensions(H):
         return lam[o], U[:, o]
 
     W_ref, _means, lam_ref = gf.gcca_from_moments(G, s, n_tot, dims, k, c=cs, view_weights=mu, topk=lanczos)
-    gaps = np.abs(np.diff(lam_ref)) / lam_ref[0]
-    assert gaps.min() > 1e-5, gaps.min()
+    # per column where the neighbouring eigenvalues are separated (relative gap > 1e-6: a backward error of 1e-12 moves
+    # such an eigenvector by 1e-6 at most); the remaining, nearly degenerate columns through the residual of the oracle's
+    # columns in the span of ours (principal angles where correlations coincide)
+    rel = np.abs(np.diff(lam_ref)) / lam_ref[0]
+    gap = np.full(k, np.inf)
+    gap[:-1] = np.minimum(gap[:-1], rel)
+    gap[1:] = np.minimum(gap[1:], rel)
+    sep = gap > 1e-6
     np.testing.assert_allclose(np.asarray(m.eigenvalues_)[:k], lam_ref, rtol=1e-9)
-    from conftest import col_rel_err
-
-    errs = [col_rel_err(w, r) for w, r in zip(m.weights_, W_ref)]
-    print("[c5 gcca] per-view max column errors vs the oracle:", errs, "min relative gap", gaps.min())
-    assert max(errs) < 1e-5, errs
+    col, sub = 0.0, 0.0
+    for w, r in zip(m.weights_, W_ref):
+        sgn = np.sign(np.sum(w * r, axis=0))
+        e = np.linalg.norm(w * sgn - r, axis=0) / np.linalg.norm(r, axis=0)
+        col = max(col, float(e[sep].max()))
+        coef, *_ = np.linalg.lstsq(w, r, rcond=None)
+        sub = max(sub, float(np.linalg.norm(r - w @ coef) / np.linalg.norm(r)))
+    print(f"[c5 gcca] separated columns {int(sep.sum())}/{k}: max column error {col:.2e}; subspace residual {sub:.2e}; min gap {gap.min():.1e}")
+    assert sep.sum() >= k // 2
+    assert col < 1e-5 and sub < 1e-5, (col, sub)
