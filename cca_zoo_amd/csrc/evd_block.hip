@@ -551,8 +551,16 @@ struct BjRows {
   double* M[2];
   int64_t ld[2];
   int chunks[2];          // ceil(cols / 64)
+  int groups[2];          // ceil(chunks / rg): workgroups per pair
   int64_t cols[2];
+  int rg;                 // 64-column chunks per row-tile workgroup: 1 while the grid is small (a tile's latency is the
+                          // launch's duration), 4 once the chip is full several times over (throughput: prefetch pays)
 };
+constexpr int BJ_AG = 4;  // tiles (K, L .. L + 3) per A-tile workgroup when the grid is large (rows.rg > 1)
+inline int bj_row_group(int np, int chunks_total) {
+  static const int64_t min_tiles = [] { const char* e = getenv("CCZ_BJ_GROUP_MIN_TILES"); return e ? atoll(e) : 2048LL; }();
+  return int64_t(np) * chunks_total >= min_tiles ? 4 : 1;
+}
 
 // part: 0 = both kinds of tile in one launch, 1 = the A tiles only, 2 = the row tiles only.  fused: A is three rotating
 // planes (read state g, write state g + 1) and Rt_all two (g & 1), g = st->g0 + round.
@@ -578,141 +586,227 @@ __global__ __launch_bounds__(256, 2) void k_bj_apply(double* __restrict__ A, int
   }
 
   if (int(blockIdx.x) < nA) {
-    int ti, tj;
-    tri_decode(blockIdx.x, ti, tj);
-    const int K = tj, L = ti + 1;                                   // K < L
-    if (ident && ident[K] && ident[L]) return;                      // both pairs at rest: the tile does not change
-    int bk[2], bl[2];
+    // one tile per workgroup while the grid is small; a run of up to four tiles (K, L .. L + 3) once the chip is full
+    // several times over: R_K stays in registers, the next tile's X and R_L travel global -> registers under the products
+    const int np_ = nb >> 1;
+    int K, L0, L1;
+    if (rows.rg == 1) {
+      int ti, tj;
+      tri_decode(blockIdx.x, ti, tj);
+      K = tj; L0 = ti + 1; L1 = L0 + 1;                             // K < L
+    } else {
+      int b = blockIdx.x;
+      K = 0;
+      for (;;) { const int ng = (np_ - 1 - K + BJ_AG - 1) / BJ_AG; if (b < ng) break; b -= ng; ++K; }
+      L0 = K + 1 + b * BJ_AG; L1 = min(np_, L0 + BJ_AG);
+    }
+    int Ls[BJ_AG], nl = 0;
+    for (int L = L0; L < L1; ++L)
+      if (!(ident && ident[K] && ident[L])) Ls[nl++] = L;           // both pairs at rest: the tile does not change
+    if (nl == 0) return;
+    int bk[2];
     pair_of(round, K, m1, bk[0], bk[1]);
-    pair_of(round, L, m1, bl[0], bl[1]);
-    // X (64 x 64, stride 66) <- the four sub-blocks, transposing the ones whose canonical copy is the mirrored one
+    v2f64 preX[8], preR[8], rk[8];
+    auto fetchA = [&](int L) {
+      int bl[2];
+      pair_of(round, L, m1, bl[0], bl[1]);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int si = s >> 1, sj = s & 1, x = bk[si], y = bl[sj];
-      const bool direct = x < y;
-      const double* base = direct ? A + int64_t(x) * BJB * lda + y * BJB : A + int64_t(y) * BJB * lda + x * BJB;
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int si = s4 >> 1, sj = s4 & 1, x = bk[si], y = bl[sj];
+        const double* base = x < y ? A + int64_t(x) * BJB * lda + y * BJB : A + int64_t(y) * BJB * lda + x * BJB;
 #pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int piece = tid + 256 * it, row = piece >> 4, c2 = (piece & 15) * 2;
-        const v2f64 v = *reinterpret_cast<const v2f64*>(base + int64_t(row) * lda + c2);
-        if (direct) {
-          *reinterpret_cast<v2f64*>(X + (BJB * si + row) * AP_SX + BJB * sj + c2) = v;
-        } else {
-          X[(BJB * si + c2) * AP_SX + BJB * sj + row] = v.x;
-          X[(BJB * si + c2 + 1) * AP_SX + BJB * sj + row] = v.y;
+        for (int it = 0; it < 2; ++it) {
+          const int piece = tid + 256 * it, row = piece >> 4, c2 = (piece & 15) * 2;
+          preX[2 * s4 + it] = *reinterpret_cast<const v2f64*>(base + int64_t(row) * lda + c2);
         }
       }
-    }
-    const double* rl = Rt_all + int64_t(L) * (BJP * BJP);
-    const double* rkp = Rt_all + int64_t(K) * (BJP * BJP);
-    v2f64 pre[8];
+      const double* rl = Rt_all + int64_t(L) * (BJP * BJP);
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int piece = tid + 256 * it, row = piece >> 5, c2 = (piece & 31) * 2;
-      *reinterpret_cast<v2f64*>(Rs + row * AP_SX + c2) = *reinterpret_cast<const v2f64*>(rl + row * BJP + c2);
-      pre[it] = *reinterpret_cast<const v2f64*>(rkp + row * BJP + c2);
-    }
-    __syncthreads();
-    // Y[:, cw .. cw+15] = X R_L :  A fragment X[m][k], B fragment R_L[k][n] = Rt_L[n][k]
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      const double b = Rs[(cw + l15) * AP_SX + 4 * ks + l4];
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        const double a = X[(16 * mt + l15) * AP_SX + 4 * ks + l4];
-        acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[mt], 0, 0, 0);
+      for (int it = 0; it < 8; ++it) {
+        const int piece = tid + 256 * it, row = piece >> 5, c2 = (piece & 31) * 2;
+        preR[it] = *reinterpret_cast<const v2f64*>(rl + row * BJP + c2);
       }
-    }
-    __syncthreads();
+    };
+    // X (64 x 64, stride 66) <- the four sub-blocks, transposing the ones whose canonical copy is the mirrored one; Rs <- R_L
+    auto stashA = [&](int L) {
+      int bl[2];
+      pair_of(round, L, m1, bl[0], bl[1]);
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int piece = tid + 256 * it, row = piece >> 5, c2 = (piece & 31) * 2;
-      *reinterpret_cast<v2f64*>(Rs + row * AP_SX + c2) = pre[it];
-    }
-    __syncthreads();
-    // Z[:, cw ..] = R_K' Y :  A fragment Rt_K[m][k]; B fragment of k-step ks = Y rows 4 ks .. 4 ks + 3 = accumulator
-    // register (ks & 3) of row tile (ks >> 2)  (C layout of v_mfma_f64_16x16x4: row = (lane >> 4) + 4 reg)
-    v4f64 z[4];
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int si = s4 >> 1, sj = s4 & 1;
+        const bool direct = bk[si] < bl[sj];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) z[t] = v4f64{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      const double b = acc[ks >> 2][ks & 3];
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        const double a = Rs[(16 * mt + l15) * AP_SX + 4 * ks + l4];
-        z[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, z[mt], 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) X[(16 * mt + l4 + 4 * r) * AP_SX + cw + l15] = z[mt][r];
-    __syncthreads();
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int si = s >> 1, sj = s & 1, x = bk[si], y = bl[sj];
-      const bool direct = x < y;
-      double* base = direct ? A_out + int64_t(x) * BJB * lda + y * BJB : A_out + int64_t(y) * BJB * lda + x * BJB;
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int piece = tid + 256 * it, row = piece >> 4, c2 = (piece & 15) * 2;
-        v2f64 v;
-        if (direct) {
-          v = *reinterpret_cast<const v2f64*>(X + (BJB * si + row) * AP_SX + BJB * sj + c2);
-        } else {
-          v.x = X[(BJB * si + c2) * AP_SX + BJB * sj + row];
-          v.y = X[(BJB * si + c2 + 1) * AP_SX + BJB * sj + row];
+        for (int it = 0; it < 2; ++it) {
+          const int piece = tid + 256 * it, row = piece >> 4, c2 = (piece & 15) * 2;
+          const v2f64 v = preX[2 * s4 + it];
+          if (direct) {
+            *reinterpret_cast<v2f64*>(X + (BJB * si + row) * AP_SX + BJB * sj + c2) = v;
+          } else {
+            X[(BJB * si + c2) * AP_SX + BJB * sj + row] = v.x;
+            X[(BJB * si + c2 + 1) * AP_SX + BJB * sj + row] = v.y;
+          }
         }
-        *reinterpret_cast<v2f64*>(base + int64_t(row) * lda + c2) = v;
+      }
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int piece = tid + 256 * it, row = piece >> 5, c2 = (piece & 31) * 2;
+        *reinterpret_cast<v2f64*>(Rs + row * AP_SX + c2) = preR[it];
+      }
+    };
+    fetchA(Ls[0]);
+    {
+      const double* rkp = Rt_all + int64_t(K) * (BJP * BJP);
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int piece = tid + 256 * it, row = piece >> 5, c2 = (piece & 31) * 2;
+        rk[it] = *reinterpret_cast<const v2f64*>(rkp + row * BJP + c2);
+      }
+    }
+    stashA(Ls[0]);
+    __syncthreads();
+    for (int i = 0; i < nl; ++i) {
+      const int L = Ls[i];
+      if (i + 1 < nl) fetchA(Ls[i + 1]);
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) acc[tt] = v4f64{0.0, 0.0, 0.0, 0.0};
+      // Y[:, cw .. cw+15] = X R_L :  A fragment X[m][k], B fragment R_L[k][n] = Rt_L[n][k]
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const double b = Rs[(cw + l15) * AP_SX + 4 * ks + l4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const double a = X[(16 * mt + l15) * AP_SX + 4 * ks + l4];
+          acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[mt], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int piece = tid + 256 * it, row = piece >> 5, c2 = (piece & 31) * 2;
+        *reinterpret_cast<v2f64*>(Rs + row * AP_SX + c2) = rk[it];
+      }
+      __syncthreads();
+      // Z[:, cw ..] = R_K' Y :  A fragment Rt_K[m][k]; B fragment of k-step ks = Y rows 4 ks .. 4 ks + 3 = accumulator
+      // register (ks & 3) of row tile (ks >> 2)  (C layout of v_mfma_f64_16x16x4: row = (lane >> 4) + 4 reg)
+      v4f64 z[4];
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) z[tt] = v4f64{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const double b = acc[ks >> 2][ks & 3];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const double a = Rs[(16 * mt + l15) * AP_SX + 4 * ks + l4];
+          z[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, z[mt], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) X[(16 * mt + l4 + 4 * r) * AP_SX + cw + l15] = z[mt][r];
+      __syncthreads();
+      int bl[2];
+      pair_of(round, L, m1, bl[0], bl[1]);
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int si = s4 >> 1, sj = s4 & 1, x = bk[si], y = bl[sj];
+        const bool direct = x < y;
+        double* base = direct ? A_out + int64_t(x) * BJB * lda + y * BJB : A_out + int64_t(y) * BJB * lda + x * BJB;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int piece = tid + 256 * it, row = piece >> 4, c2 = (piece & 15) * 2;
+          v2f64 v;
+          if (direct) {
+            v = *reinterpret_cast<const v2f64*>(X + (BJB * si + row) * AP_SX + BJB * sj + c2);
+          } else {
+            v.x = X[(BJB * si + c2) * AP_SX + BJB * sj + row];
+            v.y = X[(BJB * si + c2 + 1) * AP_SX + BJB * sj + row];
+          }
+          *reinterpret_cast<v2f64*>(base + int64_t(row) * lda + c2) = v;
+        }
+      }
+      if (i + 1 < nl) {
+        __syncthreads();                                            // X has been written out, Rs (R_K) has been read
+        stashA(Ls[i + 1]);
+        __syncthreads();
       }
     }
     return;
   }
 
-  // ---- row tile: M[rows of pair K, 64 columns] <- R_K' M[...] ----
+  // ---- row tiles: M[rows of pair K, a group of up to rows.rg 64-column chunks] <- R_K' M[...] ----
+  // One workgroup walks its group with R_K resident in LDS; the next chunk's 32 KB travel global -> registers while the
+  // current chunk is on the matrix pipe (with one chunk per workgroup and two workgroups per CU the load / product / store
+  // phases of a tile did not hide each other: 39 % MFMA busy at d = 4096, profiles/r04_syev_pmc.md).
   int t = int(blockIdx.x) - nA;
   const int np = nb >> 1;
   int which = 0;
-  if (t >= np * rows.chunks[0]) { t -= np * rows.chunks[0]; which = 1; }
-  const int nch = rows.chunks[which];
-  const int K = t / nch, ch = t - K * nch;
+  if (t >= np * rows.groups[0]) { t -= np * rows.groups[0]; which = 1; }
+  const int ngr = rows.groups[which], nch = rows.chunks[which];
+  const int K = t / ngr, ch0 = (t - K * ngr) * rows.rg, ch1 = min(nch, ch0 + rows.rg);
   if (ident && ident[K]) return;
   double* M = rows.M[which];
-  const int64_t ld = rows.ld[which], c0 = int64_t(ch) * 64, ncol = rows.cols[which];
+  const int64_t ld = rows.ld[which], ncol = rows.cols[which];
   int bk[2];
   pair_of(round, K, m1, bk[0], bk[1]);
   const double* rkp = Rt_all + int64_t(K) * (BJP * BJP);
+  v2f64 pre[8];
+  auto fetch = [&](int ch) {
+    const int64_t c0 = int64_t(ch) * 64;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int piece = tid + 256 * it, row = piece >> 5, c2 = (piece & 31) * 2;
+      const int64_t grow = int64_t(bk[row >> 5]) * BJB + (row & (BJB - 1));
+      v2f64 v = {0.0, 0.0};
+      if (c0 + c2 + 1 < ncol) v = *reinterpret_cast<const v2f64*>(M + grow * ld + c0 + c2);
+      else if (c0 + c2 < ncol) v.x = M[grow * ld + c0 + c2];
+      pre[it] = v;
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int piece = tid + 256 * it, row = piece >> 5, c2 = (piece & 31) * 2;
+      *reinterpret_cast<v2f64*>(X + row * AP_SB + c2) = pre[it];
+    }
+  };
+  fetch(ch0);
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
     const int piece = tid + 256 * it, row = piece >> 5, c2 = (piece & 31) * 2;
     *reinterpret_cast<v2f64*>(Rs + row * AP_SX + c2) = *reinterpret_cast<const v2f64*>(rkp + row * BJP + c2);
-    const int64_t grow = int64_t(bk[row >> 5]) * BJB + (row & (BJB - 1));
-    v2f64 v = {0.0, 0.0};
-    if (c0 + c2 + 1 < ncol) v = *reinterpret_cast<const v2f64*>(M + grow * ld + c0 + c2);
-    else if (c0 + c2 < ncol) v.x = M[grow * ld + c0 + c2];
-    *reinterpret_cast<v2f64*>(X + row * AP_SB + c2) = v;
   }
+  stash();
   __syncthreads();
+  for (int ch = ch0; ch < ch1; ++ch) {
+    if (ch + 1 < ch1) fetch(ch + 1);
 #pragma unroll
-  for (int ks = 0; ks < 16; ++ks) {
-    const double b = X[(4 * ks + l4) * AP_SB + cw + l15];
+    for (int tt = 0; tt < 4; ++tt) acc[tt] = v4f64{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      const double a = Rs[(16 * mt + l15) * AP_SX + 4 * ks + l4];
-      acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[mt], 0, 0, 0);
-    }
-  }
-  const int64_t gc = c0 + cw + l15;
-  if (gc < ncol) {
+    for (int ks = 0; ks < 16; ++ks) {
+      const double b = X[(4 * ks + l4) * AP_SB + cw + l15];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * mt + l4 + 4 * r;
-        const int64_t grow = int64_t(bk[row >> 5]) * BJB + (row & (BJB - 1));
-        M[grow * ld + gc] = acc[mt][r];
+      for (int mt = 0; mt < 4; ++mt) {
+        const double a = Rs[(16 * mt + l15) * AP_SX + 4 * ks + l4];
+        acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[mt], 0, 0, 0);
       }
+    }
+    const int64_t gc = int64_t(ch) * 64 + cw + l15;
+    if (gc < ncol) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * mt + l4 + 4 * r;
+          const int64_t grow = int64_t(bk[row >> 5]) * BJB + (row & (BJB - 1));
+          M[grow * ld + gc] = acc[mt][r];
+        }
+    }
+    if (ch + 1 < ch1) {
+      __syncthreads();                                              // every wave is done with this chunk's X
+      stash();
+      __syncthreads();
+    }
   }
 }
 
@@ -884,11 +978,14 @@ int syev_block(ccz_ctx* c, const double* A, int64_t d, int64_t lda, double* w_de
   hipLaunchKernelGGL(k_bj_prep_sym, pgrid, dim3(256), 0, st, A, lda, d, dp, Aw.get(), want_refresh ? A0.get() : (double*)nullptr, Vt.get(),
                      sb.dev);
   CCZ_LAUNCH_CHECK();
-  const int nA = np * (np - 1) / 2, vch = int(dp / 64);
+  const int vch = int(dp / 64);
+  int nA = np * (np - 1) / 2;
   BjRows rows{};
-  rows.M[0] = Vt.get(); rows.ld[0] = dp; rows.chunks[0] = vch; rows.cols[0] = dp;
-  rows.M[1] = nullptr; rows.ld[1] = 0; rows.chunks[1] = 0; rows.cols[1] = 0;
-  const int nV = np * vch;
+  rows.rg = bj_row_group(np, vch);
+  if (rows.rg > 1) { nA = 0; for (int K = 0; K < np; ++K) nA += (np - 1 - K + BJ_AG - 1) / BJ_AG; }
+  rows.M[0] = Vt.get(); rows.ld[0] = dp; rows.chunks[0] = vch; rows.cols[0] = dp; rows.groups[0] = (vch + rows.rg - 1) / rows.rg;
+  rows.M[1] = nullptr; rows.ld[1] = 0; rows.chunks[1] = 0; rows.cols[1] = 0; rows.groups[1] = 0;
+  const int nV = np * rows.groups[0];
   uint64_t key = graph_key_mix(graph_key_mix(0x424a5359ull + (fused ? 1 : 0), uint64_t(dp)), reinterpret_cast<uint64_t>(Aw.get()));
   key = graph_key_mix(graph_key_mix(key, reinterpret_cast<uint64_t>(Vt.get())), reinterpret_cast<uint64_t>(Rt.get()));
   key = graph_key_mix(graph_key_mix(key, reinterpret_cast<uint64_t>(sb.dev)), reinterpret_cast<uint64_t>(side));
@@ -990,7 +1087,9 @@ int jacobi_rows_block(ccz_ctx* c, int64_t p, int64_t q, double* W, int64_t ldw, 
   BjRows rows{};
   rows.M[0] = W; rows.ld[0] = ldw; rows.chunks[0] = int((q + 63) / 64); rows.cols[0] = q;
   rows.M[1] = Q; rows.ld[1] = ldq; rows.chunks[1] = Q ? int((qc + 63) / 64) : 0; rows.cols[1] = Q ? qc : 0;
-  const int nV = np * (rows.chunks[0] + rows.chunks[1]);
+  rows.rg = bj_row_group(np, rows.chunks[0] + rows.chunks[1]);
+  rows.groups[0] = (rows.chunks[0] + rows.rg - 1) / rows.rg; rows.groups[1] = (rows.chunks[1] + rows.rg - 1) / rows.rg;
+  const int nV = np * (rows.groups[0] + rows.groups[1]);
   const double tol = BJ_EPS * std::sqrt(double(q)) * 4.0;
   uint64_t key = graph_key_mix(graph_key_mix(0x424a4f53ull, uint64_t(p)), uint64_t(q));
   key = graph_key_mix(graph_key_mix(key, reinterpret_cast<uint64_t>(W)), reinterpret_cast<uint64_t>(Q));
