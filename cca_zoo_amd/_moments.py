@@ -46,8 +46,6 @@ def _common_float(views):
     return "f32" if all(k == "f32" for k in kinds) else "f64"
 
 
-#: reusable exchange buffers / side streams of the sharded path, keyed by (device, number of doubles)
-_EXCHANGE = {}
 
 #: bench.py: record (start, head done, tail unpacked) events around the two parts of the exchange -- no host waits added
 TIME_EXCHANGE = False
@@ -60,27 +58,28 @@ def exchange_events():
     return _last_events
 
 
-def _exchange_buffer(dev, count):
-    """The packed moments travel in ONE buffer per (device, size), kept for the life of the process: no second
-    D^2-sized allocation per fit (it is 1 GB at D = 16384)."""
+def _exchange_buffer(h, dev, count):
+    """The packed moments travel in ONE buffer per HANDLE and size, kept for the life of the handle: no second D^2-sized
+    allocation per fit (it is 1 GB at D = 16384).  Keyed by the handle (a handle is single-threaded): two fits of the same
+    size on one device from different handles / threads never share a payload."""
     import torch
 
-    key = (str(dev), int(count))
-    buf = _EXCHANGE.get(key)
+    store = h.__dict__.setdefault("_exchange", {})
+    buf = store.get(int(count))
     if buf is None:
-        for k in [k for k in _EXCHANGE if k[0] == str(dev) and not isinstance(_EXCHANGE[k], torch.cuda.Stream)]:
-            del _EXCHANGE[k]                                    # a different problem size: let the old buffer go
-        buf = _EXCHANGE[key] = torch.empty(int(count), dtype=torch.float64, device=dev)
+        for k in [k for k in store if isinstance(k, int)]:
+            del store[k]                                        # a different problem size: let the old buffer go
+        buf = store[int(count)] = torch.empty(int(count), dtype=torch.float64, device=dev)
     return buf
 
 
-def _side_stream(dev):
+def _side_stream(h, dev):
     import torch
 
-    key = (str(dev), "stream")
-    st = _EXCHANGE.get(key)
+    store = h.__dict__.setdefault("_exchange", {})
+    st = store.get("stream")
     if st is None:
-        st = _EXCHANGE[key] = torch.cuda.Stream(device=dev)
+        st = store["stream"] = torch.cuda.Stream(device=dev)
     return st
 
 
@@ -166,7 +165,7 @@ def compute_moments(views, handle=None, defer_offdiag=False):
         n_head = sum(d * (d + 1) // 2 for d in dims) + D + 1
         n_tail = D * (D + 1) // 2 + D + 1 - n_head
         cuda = mom_t.is_cuda
-        packed = _exchange_buffer(mom_t.device, n_head + n_tail) if cuda else torch.empty(n_head + n_tail, dtype=torch.float64)
+        packed = _exchange_buffer(h, mom_t.device, n_head + n_tail) if cuda else torch.empty(n_head + n_tail, dtype=torch.float64)
         h.moments_pack_blocks(mom_ptr, D, dims, packed.data_ptr(), h.BOTH)
         if cuda:
             h.release(stream_ptr)                        # the collective's stream follows libccz's on the device
@@ -194,7 +193,7 @@ def compute_moments(views, handle=None, defer_offdiag=False):
         h.moments_unpack_blocks(packed.data_ptr(), D, dims, mom_ptr, h.HEAD)
         if w_tail is not None:
             if cuda and defer_offdiag:
-                side = _side_stream(mom_t.device)
+                side = _side_stream(h, mom_t.device)
                 side.wait_stream(torch.cuda.current_stream(mom_t.device))
                 with torch.cuda.stream(side):
                     w_tail.wait()                        # the side stream waits for the collective, the host does not

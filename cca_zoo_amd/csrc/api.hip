@@ -145,7 +145,15 @@ static void stream_join(ccz_ctx* c, hipStream_t from, hipStream_t to, int slot) 
   const bool implicit = (from == im->own_stream && to == nullptr) || (from == nullptr && to == im->own_stream);
   if (implicit) return;                                                // legacy null-stream ordering
   if (!im->xs_ev[slot]) CCZ_HIP(hipEventCreateWithFlags(&im->xs_ev[slot], hipEventDisableTiming));
-  if (hipEventRecord(im->xs_ev[slot], from) != hipSuccess) { (void)hipGetLastError(); return; }
+  const hipError_t rec = hipEventRecord(im->xs_ev[slot], from);
+  if (rec != hipSuccess) {
+    (void)hipGetLastError();
+    // a DESTROYED source stream has nothing pending: no dependency to establish.  Anything else (a capturing stream, a
+    // caller's bug) must not silently drop the ordering -- fall back to a full wait
+    if (rec == hipErrorInvalidHandle || rec == hipErrorInvalidResourceHandle || rec == hipErrorContextIsDestroyed) return;
+    CCZ_HIP(hipDeviceSynchronize());
+    return;
+  }
   CCZ_HIP(hipStreamWaitEvent(to, im->xs_ev[slot], 0));
 }
 

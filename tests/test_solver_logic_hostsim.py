@@ -226,6 +226,34 @@ def test_syevj_two_sided_sizes_and_the_one_sided_path_beyond(H, d):
     assert 1 <= sw.value <= 30
 
 
+@pytest.mark.parametrize("kind,d", [("sym", 200), ("cov", 256), ("lowrank", 192), ("pm", 230)])
+def test_syevj_block_jacobi_structure_on_the_host_double(H, kind, d):
+    """Above d = 160 ccz_syevj runs the BLOCKED Jacobi (csrc/evd_block.hip); the host double restates its structure --
+    32-wide blocks, tournament over the blocks, cross-block rotation rounds (a full tournament in the first round of every
+    sweep), zero padding to a multiple of 64 -- so its convergence and bookkeeping are tested here without a GPU:
+    Wigner, graded covariance, rank-deficient (a 128-fold eigenvalue 0) and +/- paired spectra."""
+    rng = np.random.default_rng(d)
+    if kind == "sym":
+        A = rng.standard_normal((d, d)); A = A + A.T
+    elif kind == "cov":
+        X = rng.standard_normal((3 * d, d)) * np.linspace(2.0, 0.05, d); A = X.T @ X / (3 * d - 1)
+    elif kind == "lowrank":
+        X = rng.standard_normal((d // 3, d)); A = X.T @ X
+    else:
+        T = rng.standard_normal((d // 2, d - d // 2))
+        A = np.block([[np.zeros((d // 2, d // 2)), T], [T.T, np.zeros((d - d // 2, d - d // 2))]])
+    A0 = A.copy()
+    w, V = np.zeros(d), np.zeros((d, d))
+    sw = C.c_int(0)
+    _call(H, "ccz_syevj", _p(A), d, _p(w), _p(V), C.byref(sw))
+    np.testing.assert_array_equal(A, A0)                                            # the input is only read
+    nrm = np.abs(np.linalg.eigvalsh(A0)).max()
+    np.testing.assert_allclose(w, np.linalg.eigvalsh(A0)[::-1], atol=1e-12 * nrm)
+    assert np.linalg.norm(A0 @ V.T - V.T * w) < 1e-11 * np.linalg.norm(A0)
+    assert np.linalg.norm(V @ V.T - np.eye(d)) < 1e-11
+    assert 1 <= sw.value <= 40
+
+
 def test_syevj_rejects_non_finite_input(H):
     A = np.eye(40)
     A[3, 7] = A[7, 3] = np.inf
