@@ -62,6 +62,12 @@ __device__ __forceinline__ void atomic_max_nonneg(double* addr, double v) {   //
   atomicMax(reinterpret_cast<unsigned long long*>(addr), static_cast<unsigned long long>(__double_as_longlong(v)));
 }
 
+template <int FULL>
+__device__ __forceinline__ void bj_pair_c(int r, int k, int& p, int& q) {
+  if (FULL) { pair_of(r, k, BJP - 1, p, q); return; }
+  p = k;
+  q = BJB + ((k + r) & (BJB - 1));
+}
 __device__ __forceinline__ void bj_pair(int full, int r, int k, int& p, int& q) {
   if (full) { pair_of(r, k, BJP - 1, p, q); return; }
   p = k;
@@ -231,16 +237,19 @@ __device__ __forceinline__ Rot bj_rotation(double hpp, double hqq, double hpq, d
   return o;
 }
 
-template <int MODE>
+// FULL (compile time: the tournament's index arithmetic is a large share of every wave's instruction stream, and the CU
+// is VALU-issue bound -- 16 waves on 4 SIMDs, measured with the stamps below): 1 = 63-round full tournament, 0 = cross block.
+template <int MODE, int FULL>
 __global__ __launch_bounds__(BJ2_THREADS) void k_bj_inner2(double* __restrict__ A, int64_t lda, const double* __restrict__ G,
                                                            int nsplit, double* __restrict__ Rt_out, BjStatus* __restrict__ st,
-                                                           int nb, int round, int full, double tol, long long* __restrict__ dbg,
+                                                           int nb, int round, double tol, long long* __restrict__ dbg,
                                                            int* __restrict__ ident) {
   __shared__ __attribute__((aligned(16))) double Hs[2][BJ_NH];
   __shared__ __attribute__((aligned(16))) double Rt[BJP * BJP];     // Rt[j][i] = R[i][j]
   __shared__ __attribute__((aligned(16))) jac_cs csn[2][BJB];
   __shared__ __attribute__((aligned(16))) double Xs[MODE == 2 ? BJP * AP_SX + 2 * BJB * AP_SX : 2];   // fused form: old tile + two R parts
   __shared__ int src_pair[4];                                       // fused form: (pair, member) of ba and of bb in the previous round
+  __shared__ __attribute__((aligned(16))) double Xs_mail[2 * 4 * 64];  // cross-block rounds: the R column each wave hands to its neighbour
   const int tid = threadIdx.x;
   int ba, bb;
   pair_of(round, blockIdx.x, nb - 1, ba, bb);
@@ -368,15 +377,15 @@ __global__ __launch_bounds__(BJ2_THREADS) void k_bj_inner2(double* __restrict__ 
   }
   for (int e = tid; e < BJP * BJP; e += BJ2_THREADS) Rt[e] = ((e >> 6) == (e & 63)) ? 1.0 : 0.0;
   const double thr = MODE != 1 ? BJ_EPS * hmax : 0.0, ih = 1.0 / hmax, half_ih = 0.5 * ih, floor2 = hmax * 1e-28;
-  const int nr = full ? BJP - 1 : BJB;
+  constexpr int nr = FULL ? BJP - 1 : BJB;
   if (MODE != 2) {
     // Nothing to rotate in this pair (the rule in the last sweeps, and all of the final, verifying one)?  Then R = I, S
     // stays as it is, and the tile update skips every tile whose two pairs are both at rest (ident[]).
     __syncthreads();
     int live = 0;
-    for (int e = tid; e < (full ? BJP * (BJP - 1) / 2 : BJB * BJB); e += BJ2_THREADS) {
+    for (int e = tid; e < (FULL ? BJP * (BJP - 1) / 2 : BJB * BJB); e += BJ2_THREADS) {
       int i, j;
-      if (full) { tri_decode(e, i, j); ++i; }                       // i > j: every pair of the 64
+      if (FULL) { tri_decode(e, i, j); ++i; }                       // i > j: every pair of the 64
       else { i = BJB + (e >> 5); j = e & (BJB - 1); }               // the cross block
       const double hpq = Hs[0][tri_off(i, j)];
       if (MODE == 0) live |= fabs(hpq) > thr;
@@ -390,26 +399,50 @@ __global__ __launch_bounds__(BJ2_THREADS) void k_bj_inner2(double* __restrict__ 
       return;
     }
   }
-  // roles.  A wave issues one fp64 VALU instruction per 32 cycles whatever the dependencies (measured with the stamps
-  // below: 2200 cycles for ~60 fp64 instructions of the parameter wave, 2100 for the 32 + LDS of an R wave), so the
-  // round time is the LARGEST fp64 instruction count of any wave: parameters ~23, an S block 16, six R rotations 24.
+  // roles.  fp64 FMAs pipeline inside a wave (tools/probes/dp_issue_probe.hip: 2.4 cycles per instruction per SIMD with 4 waves x 8
+  // independent chains; 32-44 cycles for a dependent one), so only the parameter lanes' chain is latency-bound; the other
+  // waves are bound by what the CU ISSUES per round -- VALU index arithmetic and, above all, LDS traffic (a ds_write_b64
+  // costs ~6 LDS cycles): shader-clock stamps (CCZ_BJ_DEBUG) put the R waves of the LDS-resident form at 1850-2400 cycles per
+  // round against 1150 for the parameter chain.  Hence the tournament type as a template parameter (index arithmetic at
+  // compile time) and, for the cross-block rounds (all but the first round of a sweep), R in REGISTERS (below).
   const int sb = tid - 64;                                          // S block index on waves 1..9 (diagonal blocks included)
   int ka = 0, kb = 0;
   const bool son = sb >= 0 && sb < BJB * (BJB + 1) / 2;
   if (son) tri_decode(sb, ka, kb);                                  // ka >= kb
+  const int o0_cross = tri_off(ka, kb);
   const int rt0 = tid - 640;                                        // R rotations rt0 + 384 j (pair = id >> 6, row = id & 63)
+  int rk6[6], rrow6[6];
+  bool rok6[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int id = min(max(rt0, 0) + 384 * j, BJP * BJB - 1);
+    rok6[j] = rt0 >= 0 && rt0 + 384 * j < BJP * BJB;
+    rk6[j] = id >> 6;
+    rrow6[j] = id & 63;
+  }
   // parameter lanes: where next round's pair k takes its two indices from (pair, member), fixed for the whole pass
   int srcA = 0, srcB = 0;
   bool memA = false, memB = false;
   if (tid < BJB) {
     const int k = tid;
-    if (!full) { srcA = k; memA = false; srcB = (k + 1) & (BJB - 1); memB = true; }
+    if (!FULL) { srcA = k; memA = false; srcB = (k + 1) & (BJB - 1); memB = true; }
     else if (k == 0) { srcA = 0; memA = false; srcB = 1; memB = false; }
     else {
       if (k <= BJB - 2) { srcA = k + 1; memA = false; } else { srcA = BJB - 1; memA = true; }
       if (k >= 2) { srcB = k - 1; memB = true; } else { srcB = 0; memB = true; }
     }
   }
+  // Cross-block rounds: R lives in the registers of waves 10..13 -- lane = row, wave w holds the I-half columns 8 w .. 8 w + 7
+  // (rx) and the eight J-half columns currently paired with them (ry).  Round r pairs column k with 32 + (k + r) mod 32:
+  // from one round to the next the J columns move by ONE position, i.e. ry[j] <- ry[j + 1] inside the wave and one column
+  // per wave crosses to the neighbour through a 2 KB LDS mailbox.  No R traffic in LDS at all: one uniform (c, s) read per
+  // rotation, one 8-byte hand-off per lane and round.
+  const int rw = (tid >> 6) - 10, rrow = tid & 63;
+  const bool r_regs = !FULL && rw >= 0 && rw < 4;
+  double rx[8], ry[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { rx[j] = (rrow == 8 * rw + j) ? 1.0 : 0.0; ry[j] = (rrow == BJB + 8 * rw + j) ? 1.0 : 0.0; }
+  double* mail = Xs_mail;                                           // [2][4][64]
   double hpp = 0.0, hqq = 0.0, hpq = 0.0, my_max = 0.0;
   Rot cur_rot{1.0, 0.0, 0.0};
   int my_rot = 0;
@@ -427,7 +460,7 @@ __global__ __launch_bounds__(BJ2_THREADS) void k_bj_inner2(double* __restrict__ 
   __syncthreads();
   if (tid < BJB) {
     int a, b;
-    bj_pair(full, 0, tid, a, b);
+    bj_pair_c<FULL>(0, tid, a, b);
     hpq = Hs[0][tri_off(a, b)]; hqq = Hs[0][tri_off(b, b)]; hpp = Hs[0][tri_off(a, a)];
     decide();
     csn[0][tid] = jac_cs{cur_rot.c, cur_rot.s};
@@ -442,9 +475,9 @@ __global__ __launch_bounds__(BJ2_THREADS) void k_bj_inner2(double* __restrict__ 
       if (tid < BJB) {
         // the four cells of (source pair A, source pair B) in the current S: independent of this round's arithmetic
         int pA, qA, pB, qB, p, q;
-        bj_pair(full, r, srcA, pA, qA);
-        bj_pair(full, r, srcB, pB, qB);
-        bj_pair(full, r, tid, p, q);
+        bj_pair_c<FULL>(r, srcA, pA, qA);
+        bj_pair_c<FULL>(r, srcB, pB, qB);
+        bj_pair_c<FULL>(r, tid, p, q);
         const double m0 = Sc[tri_off(pA, pB)], m1 = Sc[tri_off(pA, qB)], m2 = Sc[tri_off(qA, pB)], m3 = Sc[tri_off(qA, qB)];
         // this round's own pair as STORED: the next angle's diagonal estimates need t only (the stored cells themselves
         // are rotated with the exact (c, s) by the S waves, like every other block)
@@ -469,9 +502,17 @@ __global__ __launch_bounds__(BJ2_THREADS) void k_bj_inner2(double* __restrict__ 
     } else if (tid < 640) {
       if (son) {
         int p1, q1, p2, q2;
-        bj_pair(full, r, ka, p1, q1);
-        bj_pair(full, r, kb, p2, q2);
-        const int o0 = tri_off(p1, p2), o1 = tri_off(p1, q2), o2 = tri_off(q1, p2), o3 = tri_off(q1, q2);
+        bj_pair_c<FULL>(r, ka, p1, q1);
+        bj_pair_c<FULL>(r, kb, p2, q2);
+        int o0, o1, o2, o3;
+        if (FULL) {
+          o0 = tri_off(p1, p2); o1 = tri_off(p1, q2); o2 = tri_off(q1, p2); o3 = tri_off(q1, q2);
+        } else {                                                    // cross block: p < 32 <= q, ka >= kb -- no max / min needed
+          o0 = o0_cross;
+          o1 = (__mul24(q2, q2 + 1) >> 1) + p1;
+          o2 = (__mul24(q1, q1 + 1) >> 1) + p2;
+          o3 = tri_off(q1, q2);
+        }
         const jac_cs ra = csn[cb_][ka], rb = csn[cb_][kb];
         const double m0 = Sc[o0], m1 = Sc[o1], m2 = Sc[o2], m3 = Sc[o3];
         const double ca = ra.x, sa = ra.y, cb = rb.x, sb2 = rb.y;
@@ -484,26 +525,39 @@ __global__ __launch_bounds__(BJ2_THREADS) void k_bj_inner2(double* __restrict__ 
         Sn[o1] = ca * n01 - sa * n11;
         Sn[o3] = sa * n01 + ca * n11;
       }
+    } else if (!FULL) {
+      if (r_regs) {
+        if (r > 0) ry[7] = mail[(((r - 1) & 1) * 4 + ((rw + 1) & 3)) * 64 + rrow];    // the neighbour's hand-off of the last round
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const jac_cs cs = csn[cb_][8 * rw + j];
+          const double x = rx[j], y = ry[j];
+          rx[j] = cs.x * x - cs.y * y;
+          ry[j] = cs.y * x + cs.x * y;
+        }
+        mail[((r & 1) * 4 + rw) * 64 + rrow] = ry[0];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) ry[j] = ry[j + 1];
+      }
     } else {
-      // all loads first (two LDS latencies for the six rotations, not twelve), then the arithmetic, then the stores
+      // all loads first (two LDS latencies for the six rotations, not twelve), then the arithmetic, then the stores; the
+      // rotation's pair index and row are fixed per thread (rk6 / rrow6 below), only the pair's two columns move with r
       int op[6], oq[6];
       jac_cs cs6[6];
       double x6[6], y6[6];
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
-        const int id = min(rt0 + 384 * j, BJP * BJB - 1);
-        const int k = id >> 6, row = id & 63;
         int p, q;
-        bj_pair(full, r, k, p, q);
-        op[j] = p * BJP + row;
-        oq[j] = q * BJP + row;
-        cs6[j] = csn[cb_][k];
+        bj_pair_c<FULL>(r, rk6[j], p, q);
+        op[j] = (p << 6) + rrow6[j];
+        oq[j] = (q << 6) + rrow6[j];
+        cs6[j] = csn[cb_][rk6[j]];
         x6[j] = Rt[op[j]];
         y6[j] = Rt[oq[j]];
       }
 #pragma unroll
       for (int j = 0; j < 6; ++j)
-        if (rt0 + 384 * j < BJP * BJB && cs6[j].y != 0.0) {
+        if (rok6[j] && cs6[j].y != 0.0) {
           Rt[op[j]] = cs6[j].x * x6[j] - cs6[j].y * y6[j];
           Rt[oq[j]] = cs6[j].y * x6[j] + cs6[j].x * y6[j];
         }
@@ -527,8 +581,21 @@ __global__ __launch_bounds__(BJ2_THREADS) void k_bj_inner2(double* __restrict__ 
       }
     }
   }
-  v2f64* ro = reinterpret_cast<v2f64*>(Rt_out + int64_t(blockIdx.x) * (BJP * BJP));
-  for (int e = tid; e < BJP * BJP / 2; e += BJ2_THREADS) ro[e] = reinterpret_cast<const v2f64*>(Rt)[e];
+  if (!FULL) {
+    // after 32 rounds the J columns are back home, except for the last hand-off that is still in the mailbox
+    if (r_regs) {
+      ry[7] = mail[(((nr - 1) & 1) * 4 + ((rw + 1) & 3)) * 64 + rrow];
+      double* ro = Rt_out + int64_t(blockIdx.x) * (BJP * BJP);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        ro[(8 * rw + j) * BJP + rrow] = rx[j];                      // Rt[col][row]
+        ro[(BJB + 8 * rw + j) * BJP + rrow] = ry[j];
+      }
+    }
+  } else {
+    v2f64* ro = reinterpret_cast<v2f64*>(Rt_out + int64_t(blockIdx.x) * (BJP * BJP));
+    for (int e = tid; e < BJP * BJP / 2; e += BJ2_THREADS) ro[e] = reinterpret_cast<const v2f64*>(Rt)[e];
+  }
   if (tid < 64) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -1005,8 +1072,9 @@ int syev_block(ccz_ctx* c, const double* A, int64_t d, int64_t lda, double* w_de
       if (!fused) {
         for (int round = 0; round < nb - 1; ++round) {
           if (bj_inner_pipelined())
-            hipLaunchKernelGGL(k_bj_inner2<0>, dim3(np), dim3(BJ2_THREADS), 0, st, Aw.get(), dp, (const double*)nullptr, 0, Rt.get(), sb.dev,
-                               nb, round, round == 0 ? 1 : 0, 0.0, dbg_on && round == 1 ? (long long*)dbgb.get() : (long long*)nullptr, sb.ident);
+            hipLaunchKernelGGL((round == 0 ? k_bj_inner2<0, 1> : k_bj_inner2<0, 0>), dim3(np), dim3(BJ2_THREADS), 0, st, Aw.get(), dp,
+                               (const double*)nullptr, 0, Rt.get(), sb.dev, nb, round, 0.0,
+                               dbg_on && round == 1 ? (long long*)dbgb.get() : (long long*)nullptr, sb.ident);
           else
             hipLaunchKernelGGL(k_bj_inner<0>, dim3(np), dim3(BJ_THREADS), 0, st, Aw.get(), dp, (const double*)nullptr, 0, Rt.get(), sb.dev, nb,
                                round, round == 0 ? 1 : 0, 0.0);
@@ -1020,8 +1088,9 @@ int syev_block(ccz_ctx* c, const double* A, int64_t d, int64_t lda, double* w_de
         hipEvent_t* evU = im->bj_ev + 4;    // [4]: tile update r done
         for (int round = 0; round < nb - 1; ++round) {
           if (round >= 2) CCZ_HIP(hipStreamWaitEvent(st, evU[(round - 2) & 3], 0));
-          hipLaunchKernelGGL(k_bj_inner2<2>, dim3(np), dim3(BJ2_THREADS), 0, st, Aw.get(), dp, (const double*)nullptr, 0, Rt.get(), sb.dev,
-                             nb, round, round == 0 ? 1 : 0, 0.0, dbg_on && round == 1 ? (long long*)dbgb.get() : (long long*)nullptr, sb.ident);
+          hipLaunchKernelGGL((round == 0 ? k_bj_inner2<2, 1> : k_bj_inner2<2, 0>), dim3(np), dim3(BJ2_THREADS), 0, st, Aw.get(), dp,
+                             (const double*)nullptr, 0, Rt.get(), sb.dev, nb, round, 0.0,
+                             dbg_on && round == 1 ? (long long*)dbgb.get() : (long long*)nullptr, sb.ident);
           CCZ_HIP(hipEventRecord(evI[round & 3], st));
           CCZ_HIP(hipStreamWaitEvent(side, evI[round & 3], 0));
           hipLaunchKernelGGL(k_bj_apply, dim3(nA + nV), dim3(256), kApplyLds, side, Aw.get(), dp, rows, (const double*)Rt.get(), nb, round, nA,
@@ -1103,8 +1172,8 @@ int jacobi_rows_block(ccz_ctx* c, int64_t p, int64_t q, double* W, int64_t ldw, 
       for (int round = 0; round < nb - 1; ++round) {
         hipLaunchKernelGGL(k_bj_gram, dim3(np, nsplit), dim3(256), 0, st, (const double*)W, ldw, q, nb, round, nsplit, G.get());
         if (bj_inner_pipelined())
-          hipLaunchKernelGGL(k_bj_inner2<1>, dim3(np), dim3(BJ2_THREADS), 0, st, (double*)nullptr, int64_t(0), (const double*)G.get(), nsplit,
-                             Rt.get(), sb.dev, nb, round, round == 0 ? 1 : 0, tol, (long long*)nullptr, sb.ident);
+          hipLaunchKernelGGL((round == 0 ? k_bj_inner2<1, 1> : k_bj_inner2<1, 0>), dim3(np), dim3(BJ2_THREADS), 0, st, (double*)nullptr,
+                             int64_t(0), (const double*)G.get(), nsplit, Rt.get(), sb.dev, nb, round, tol, (long long*)nullptr, sb.ident);
         else
           hipLaunchKernelGGL(k_bj_inner<1>, dim3(np), dim3(BJ_THREADS), 0, st, (double*)nullptr, int64_t(0), (const double*)G.get(), nsplit,
                              Rt.get(), sb.dev, nb, round, round == 0 ? 1 : 0, tol);

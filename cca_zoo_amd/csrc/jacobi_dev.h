@@ -47,7 +47,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 __device__ __forceinline__ int tri_off(int i, int j) {
   const int hi = max(i, j), lo = min(i, j);
-  return ((hi * (hi + 1)) >> 1) + lo;
+  return (__mul24(hi, hi + 1) >> 1) + lo;                   // (24-bit multiply: full rate; the indices are < 2^12)
 }
 __device__ __forceinline__ void tri_decode(int e, int& i, int& j) {   // e = i (i + 1) / 2 + j, j <= i
   i = int((sqrtf(8.0f * float(e) + 1.0f) - 1.0f) * 0.5f);
