@@ -39,7 +39,6 @@ namespace {
 constexpr int BJB = 32;                        // block edge
 constexpr int BJP = 64;                        // pair edge
 constexpr int BJ_NH = BJP * (BJP + 1) / 2;     // packed lower triangle of the pair matrix
-constexpr int BJ_THREADS = 576;                // 9 waves: 528 blocks of S in stage A; wave 0 parameters + waves 1..8 R in stage B
 constexpr int AP_SX = 66;                      // LDS row stride (doubles) for A-fragment reads  (= 2 mod 32)
 constexpr int AP_SB = 80;                      // LDS row stride for B-fragment reads            (= 16 mod 32)
 constexpr double BJ_EPS = 2.220446049250313e-16;
@@ -68,138 +67,15 @@ __device__ __forceinline__ void bj_pair_c(int r, int k, int& p, int& q) {
   p = k;
   q = BJB + ((k + r) & (BJB - 1));
 }
-__device__ __forceinline__ void bj_pair(int full, int r, int k, int& p, int& q) {
-  if (full) { pair_of(r, k, BJP - 1, p, q); return; }
-  p = k;
-  q = BJB + ((k + r) & (BJB - 1));
-}
 
 // MODE 0: two-sided; S gathered from the canonical symmetric A, written back; rotate when |s_pq| > eps * max|A|
 // MODE 1: one-sided; S = sum of the `nsplit` Gram partials of this pair, not written back; rotate when
 //         |g_pq| > tol * sqrt(g_pp g_qq) and both squared norms exceed the floor (numerically zero rows rest)
-template <int MODE>
-__global__ __launch_bounds__(BJ_THREADS) void k_bj_inner(double* __restrict__ A, int64_t lda, const double* __restrict__ G,
-                                                         int nsplit, double* __restrict__ Rt_out, BjStatus* __restrict__ st,
-                                                         int nb, int round, int full, double tol) {
-  __shared__ __attribute__((aligned(16))) double Hs[BJ_NH];
-  __shared__ __attribute__((aligned(16))) double Rt[BJP * BJP];     // Rt[j][i] = R[i][j]
-  __shared__ __attribute__((aligned(16))) jac_cs csn[2][BJB];
-  __shared__ int rot;
-  const int tid = threadIdx.x;
-  int ba, bb;
-  pair_of(round, blockIdx.x, nb - 1, ba, bb);
-  const double hmax = st->hmax;
-  if (!(hmax > 0.0) || !(hmax < __builtin_inf())) {                 // zero or non-finite input: identity, nothing rotates
-    for (int e = tid; e < BJP * BJP; e += BJ_THREADS) Rt_out[int64_t(blockIdx.x) * (BJP * BJP) + e] = ((e >> 6) == (e & 63)) ? 1.0 : 0.0;
-    if (tid == 0 && !(hmax < __builtin_inf())) st->bad = 1;
-    return;
-  }
-  for (int e = tid; e < BJ_NH; e += BJ_THREADS) {
-    int i, j;
-    tri_decode(e, i, j);                                            // j <= i
-    double h;
-    if (MODE == 0) {
-      const int bi = i < BJB ? ba : bb, bj = j < BJB ? ba : bb, ii = i & (BJB - 1), jj = j & (BJB - 1);
-      h = (bi <= bj) ? A[(int64_t(bi) * BJB + ii) * lda + bj * BJB + jj] : A[(int64_t(bj) * BJB + jj) * lda + bi * BJB + ii];
-    } else {
-      h = 0.0;
-      const double* g = G + int64_t(blockIdx.x) * nsplit * (BJP * BJP) + i * BJP + j;
-      for (int s = 0; s < nsplit; ++s) h += g[int64_t(s) * (BJP * BJP)];
-    }
-    Hs[e] = h;
-  }
-  for (int e = tid; e < BJP * BJP; e += BJ_THREADS) Rt[e] = ((e >> 6) == (e & 63)) ? 1.0 : 0.0;
-  if (tid == 0) rot = 0;
-  const double thr = MODE == 0 ? BJ_EPS * hmax : 0.0, ih = 1.0 / hmax, floor2 = hmax * 1e-28;
-  // roles: S blocks (ka >= kb) on threads 0..527; R items (pair k, rows 4 g .. 4 g + 3) on threads 64..575
-  int ka = 0, kb = 0;
-  const bool son = tid < BJB * (BJB + 1) / 2;
-  if (son) tri_decode(tid, ka, kb);
-  const int item = tid - 64, rk = item >> 4, rg = (item & 15) * 4;
-  const int nr = full ? BJP - 1 : BJB;
-  double my_max = 0.0;                                              // lanes 0..31: largest rotated |s_pq|
-
-  auto params = [&](int r, int buf) {                               // lanes 0..31 of wave 0
-    int a, b;
-    bj_pair(full, r, tid, a, b);
-    const double hpq = Hs[tri_off(a, b)], hqq = Hs[tri_off(b, b)], hpp = Hs[tri_off(a, a)];
-    jac_cs cs = {1.0, 0.0};
-    bool go;
-    if (MODE == 0) go = fabs(hpq) > thr;
-    else go = hpp > floor2 && hqq > floor2 && hpq * hpq > tol * tol * hpp * hqq;
-    if (go) {
-      cs = jac_rotation(hpp, hqq, hpq, ih);
-      atomicAdd(&rot, 1);
-      my_max = fmax(my_max, fabs(hpq));
-    }
-    csn[buf][tid] = cs;
-  };
-
-  __syncthreads();
-  if (tid < BJB) params(0, 0);
-  __syncthreads();
-  for (int r = 0; r < nr; ++r) {
-    const jac_cs* cur = csn[r & 1];
-    // ---- stage A: S <- J' S J on the packed lower triangle ----
-    if (son) {
-      int p1, q1, p2, q2;
-      bj_pair(full, r, ka, p1, q1);
-      bj_pair(full, r, kb, p2, q2);
-      const int o0 = tri_off(p1, p2), o1 = tri_off(p1, q2), o2 = tri_off(q1, p2), o3 = tri_off(q1, q2);
-      const jac_cs ra = cur[ka], rb = cur[kb];
-      const double m0 = Hs[o0], m1 = Hs[o1], m2 = Hs[o2], m3 = Hs[o3];
-      const double ca = ra.x, sa = ra.y, cb = rb.x, sb = rb.y;
-      const double n00 = cb * m0 - sb * m1, n01 = sb * m0 + cb * m1;
-      const double n10 = cb * m2 - sb * m3, n11 = sb * m2 + cb * m3;
-      double o00 = ca * n00 - sa * n10, o10 = sa * n00 + ca * n10;
-      double o01 = ca * n01 - sa * n11, o11 = sa * n01 + ca * n11;
-      if (ka == kb && sa != 0.0) { o01 = 0.0; o10 = 0.0; }          // the rotated pair itself (one storage cell)
-      Hs[o0] = o00; Hs[o1] = o01; Hs[o2] = o10; Hs[o3] = o11;
-    }
-    lds_barrier();
-    // ---- stage B: wave 0 derives the next round's rotations from the new S; waves 1..8 apply this round's to R ----
-    if (tid < 64) {
-      if (tid < BJB && r + 1 < nr) params(r + 1, (r & 1) ^ 1);
-    } else {
-      int p, q;
-      bj_pair(full, r, rk, p, q);
-      const jac_cs cs = cur[rk];
-      double* xp = Rt + p * BJP + rg;
-      double* xq = Rt + q * BJP + rg;
-      const v2f64 x0 = *reinterpret_cast<v2f64*>(xp), x1 = *reinterpret_cast<v2f64*>(xp + 2);
-      const v2f64 y0 = *reinterpret_cast<v2f64*>(xq), y1 = *reinterpret_cast<v2f64*>(xq + 2);
-      if (cs.y != 0.0) {
-        *reinterpret_cast<v2f64*>(xp) = cs.x * x0 - cs.y * y0;
-        *reinterpret_cast<v2f64*>(xp + 2) = cs.x * x1 - cs.y * y1;
-        *reinterpret_cast<v2f64*>(xq) = cs.y * x0 + cs.x * y0;
-        *reinterpret_cast<v2f64*>(xq + 2) = cs.y * x1 + cs.x * y1;
-      }
-    }
-    lds_barrier();
-  }
-  __syncthreads();
-  if (MODE == 0) {
-    for (int e = tid; e < BJP * BJP; e += BJ_THREADS) {             // whole diagonal sub-blocks + the canonical cross block
-      const int i = e >> 6, j = e & 63;
-      const int bi = i < BJB ? ba : bb, bj = j < BJB ? ba : bb;
-      if (bi > bj) continue;                                        // the mirrored cross block is not stored
-      A[(int64_t(bi) * BJB + (i & (BJB - 1))) * lda + bj * BJB + (j & (BJB - 1))] = Hs[tri_off(i, j)];
-    }
-  }
-  double* ro = Rt_out + int64_t(blockIdx.x) * (BJP * BJP);
-  for (int e = tid; e < BJP * BJP; e += BJ_THREADS) ro[e] = Rt[e];
-  if (tid == 0 && rot > 0) atomicAdd(&st->rotations, rot);
-  if (MODE == 0 && tid < 64) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) my_max = fmax(my_max, __shfl_xor(my_max, o, 64));
-    if (tid == 0 && my_max > 0.0) atomic_max_nonneg(&st->maxoff, my_max);
-  }
-}
-
-// ---- the pipelined form of the pair kernel (default) -----------------------------------------------------------
-// k_bj_inner above spends a round on  [all of S rotated | barrier | 3 LDS reads + the (c, s) chain | barrier].  A
-// dependent fp64 operation costs 32 cycles on gfx950 (profiles/r02c_clock_probe.md), so the chain IS the round.  Here
-// the 32 parameter lanes never wait for the bulk update:
+// MODE 2: MODE 0 on three rotating planes of A (the two-stream schedule of syev_block, off by default)
+// ---- the pair kernel ---------------------------------------------------------------------------------------------
+// The first form of this kernel (round 4, in the history) spent a round on  [all of S rotated | barrier | 3 LDS reads + the
+// (c, s) chain | barrier]: 25 us for a pass at rest, 35-41 us busy.  A dependent fp64 operation costs 32 cycles on gfx950
+// (profiles/r02c_clock_probe.md), so the chain IS the round.  Here the 32 parameter lanes never wait for the bulk update:
 //   * lane k carries (h_pp, h_qq, h_pq) of ITS pair in registers.  The next round's pair k takes its two indices from
 //     fixed (pair, member) sources -- the tournament only shifts positions -- so its new diagonal entries are the
 //     sources' rotated diagonals (h_pp - t h_pq, h_qq + t h_pq: shuffled from the source lanes) and its new off-diagonal
@@ -964,11 +840,6 @@ __global__ void k_bj_diag(const double* __restrict__ Aw, int64_t dp, int64_t d, 
   if (i < d) w[i] = Aw[i * dp + i];
 }
 
-bool bj_inner_pipelined() {   // CCZ_BJ_INNER=1: the two-barrier pair kernel (A/B)
-  static const bool v = [] { const char* e = getenv("CCZ_BJ_INNER"); return !(e && atoi(e) == 1); }();
-  return v;
-}
-
 bool bj_fused() {   // CCZ_BJ_FUSED=1: pair kernels and tile updates on two streams (A/B; measured: no gain, see syev_block)
   static const bool v = [] { const char* e = getenv("CCZ_BJ_FUSED"); return e && atoi(e) == 1; }();
   return v;
@@ -1029,7 +900,7 @@ int syev_block(ccz_ctx* c, const double* A, int64_t d, int64_t lda, double* w_de
   // (hipExtStreamCreateWithCUMask, every 8th / 4th CU left free) made d = 1024 slower still (29 ms).  The schedule is
   // kept behind CCZ_BJ_FUSED=1 for A/B runs; the default is the serial alternation on one stream.
   hipStream_t side = nullptr;
-  const bool fused = bj_fused() && nb >= 4 && bj_inner_pipelined() && st != nullptr;
+  const bool fused = bj_fused() && nb >= 4 && st != nullptr;
   if (fused) {
     if (!im->aux_stream) CCZ_HIP(hipStreamCreateWithFlags(&im->aux_stream, hipStreamNonBlocking));
     side = im->aux_stream;
@@ -1071,13 +942,9 @@ int syev_block(ccz_ctx* c, const double* A, int64_t d, int64_t lda, double* w_de
     graph_run_fn(c, key, [&] {
       if (!fused) {
         for (int round = 0; round < nb - 1; ++round) {
-          if (bj_inner_pipelined())
-            hipLaunchKernelGGL((round == 0 ? k_bj_inner2<0, 1> : k_bj_inner2<0, 0>), dim3(np), dim3(BJ2_THREADS), 0, st, Aw.get(), dp,
-                               (const double*)nullptr, 0, Rt.get(), sb.dev, nb, round, 0.0,
-                               dbg_on && round == 1 ? (long long*)dbgb.get() : (long long*)nullptr, sb.ident);
-          else
-            hipLaunchKernelGGL(k_bj_inner<0>, dim3(np), dim3(BJ_THREADS), 0, st, Aw.get(), dp, (const double*)nullptr, 0, Rt.get(), sb.dev, nb,
-                               round, round == 0 ? 1 : 0, 0.0);
+          hipLaunchKernelGGL((round == 0 ? k_bj_inner2<0, 1> : k_bj_inner2<0, 0>), dim3(np), dim3(BJ2_THREADS), 0, st, Aw.get(), dp,
+                             (const double*)nullptr, 0, Rt.get(), sb.dev, nb, round, 0.0,
+                             dbg_on && round == 1 ? (long long*)dbgb.get() : (long long*)nullptr, sb.ident);
           hipLaunchKernelGGL(k_bj_apply, dim3(nA + nV), dim3(256), kApplyLds, st, Aw.get(), dp, rows, (const double*)Rt.get(), nb, round, nA,
                              (const BjStatus*)sb.dev, 0, (const int*)sb.ident);
         }
@@ -1171,12 +1038,8 @@ int jacobi_rows_block(ccz_ctx* c, int64_t p, int64_t q, double* W, int64_t ldw, 
     graph_run_fn(c, key, [&] {
       for (int round = 0; round < nb - 1; ++round) {
         hipLaunchKernelGGL(k_bj_gram, dim3(np, nsplit), dim3(256), 0, st, (const double*)W, ldw, q, nb, round, nsplit, G.get());
-        if (bj_inner_pipelined())
-          hipLaunchKernelGGL((round == 0 ? k_bj_inner2<1, 1> : k_bj_inner2<1, 0>), dim3(np), dim3(BJ2_THREADS), 0, st, (double*)nullptr,
-                             int64_t(0), (const double*)G.get(), nsplit, Rt.get(), sb.dev, nb, round, tol, (long long*)nullptr, sb.ident);
-        else
-          hipLaunchKernelGGL(k_bj_inner<1>, dim3(np), dim3(BJ_THREADS), 0, st, (double*)nullptr, int64_t(0), (const double*)G.get(), nsplit,
-                             Rt.get(), sb.dev, nb, round, round == 0 ? 1 : 0, tol);
+        hipLaunchKernelGGL((round == 0 ? k_bj_inner2<1, 1> : k_bj_inner2<1, 0>), dim3(np), dim3(BJ2_THREADS), 0, st, (double*)nullptr,
+                           int64_t(0), (const double*)G.get(), nsplit, Rt.get(), sb.dev, nb, round, tol, (long long*)nullptr, sb.ident);
         hipLaunchKernelGGL(k_bj_apply, dim3(nV), dim3(256), kApplyLds, st, (double*)nullptr, int64_t(0), rows, (const double*)Rt.get(), nb,
                            round, 0, (const BjStatus*)sb.dev, 0, (const int*)sb.ident);
       }
