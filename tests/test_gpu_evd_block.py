@@ -158,6 +158,25 @@ def test_whitener_and_inv_sqrtm_at_seam_sizes(H, d):
         np.testing.assert_allclose(out, ref, atol=1e-9 * np.abs(ref).max())
 
 
+@pytest.mark.parametrize("d", [96, 100, 128, 160])
+def test_whitener_between_the_one_workgroup_kernels_and_the_block_sizes(H, d):
+    """PSD seams at 96 <= d <= 160: too wide for the one-workgroup ONE-sided kernel, and the two-sided one-workgroup kernel is
+    not used for PSD inputs -- they take the blocked Jacobi with only 4 or 6 blocks (one or three pairs per round)."""
+    rng = np.random.default_rng(d)
+    n = 3 * d
+    X = rng.standard_normal((n, d)) * np.linspace(1.5, 0.3, d)
+    X -= X.mean(0)
+    G = np.ascontiguousarray(X.T @ X)
+    Gd = H.to_device(G)
+    Wd, ld, r = H.alloc(d * d * 8), H.alloc(d * 8), C.c_int64(0)
+    call(H, "ccz_whitener", vp(Gd), d, n, 0.1, vp(Wd), vp(ld), C.byref(r))
+    W, lam = H.to_host(Wd, (d, d)), H.to_host(ld, (d,))
+    lr = np.linalg.eigvalsh(G / (n - 1))[::-1]
+    np.testing.assert_allclose(lam, lr, atol=1e-12 * lr[0])
+    R = 0.9 * G / (n - 1) + 0.1 * np.eye(d)
+    np.testing.assert_allclose(W.T @ R @ W, np.eye(d), atol=1e-11)
+
+
 def test_svd_whiten_on_a_config2_view(H):
     """svd_whiten on a 1e5 x 1024 fp32 view (configs[1]) against the oracle's reference-form thin-SVD whitener."""
     from cca_zoo_amd._utils import svd_whiten

@@ -93,3 +93,27 @@ def test_torchless_load_does_not_import_torch():
             "assert lib.ccz_version() >= 130; assert 'torch' not in sys.modules; print('ok')" % ROOT)
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert p.returncode == 0 and p.stdout.strip() == "ok", p.stderr[-2000:]
+
+
+def test_bench_weights_agreement_separated_and_clustered_columns():
+    """bench.py's comparator of two solutions: per column where the neighbouring correlations are
+    separated by more than 100 x tol, as a subspace where they are not -- a rotation INSIDE a cluster must pass, a
+    perturbed separated column and a wrong subspace must fail."""
+    import bench
+
+    rng = np.random.default_rng(0)
+    d, k = 40, 6
+    W = np.linalg.qr(rng.standard_normal((d, k)))[0]
+    vals = np.array([0.9, 0.7, 0.5, 0.3000, 0.3000 + 1e-7, 0.1])             # columns 3 and 4 form a cluster
+    th = 0.7
+    Rm = np.eye(k)
+    Rm[3:5, 3:5] = [[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]]
+    ok = bench.weights_agreement([W @ Rm * np.array([1, -1, 1, 1, 1, -1.0])], [W], vals, 1e-3)
+    assert ok["ok"] and ok["separated_columns"] == 4 and ok["max_col_rel_err_separated"] < 1e-12 and ok["subspace_residual"] < 1e-12
+    W2 = W.copy()
+    W2[:, 1] += 0.01 * rng.standard_normal(d)                                  # a separated column is off
+    bad = bench.weights_agreement([W2], [W], vals, 1e-3)
+    assert not bad["ok"] and bad["max_col_rel_err_separated"] > 1e-3
+    W3 = W.copy()
+    W3[:, 3] = rng.standard_normal(d)                                          # the cluster leaves the subspace
+    assert not bench.weights_agreement([W3], [W], vals, 1e-3)["ok"]
