@@ -141,9 +141,18 @@ def check_fit_properties(model, views, jd, seed, row0=0, sharded=False, n_check=
     # with the inertia count, on second moments of the timed views formed by a COMPARATOR (torch float64 products over
     # row chunks; summed over the ranks under sharding) -- not by the product's K1
     cert = topk_certificate(model, views, sharded)
-    rep.update(cert)
-    ok = ok and cert["pencil_residual"] < tol and cert["pencil_orthonormality"] < tol
-    ok = ok and cert["pencil_eigenvalues_above_lambda_k"] == k
+    if cert is not None:                                   # (under sharding only rank 0 evaluates it; the verdict is shared below)
+        rep.update(cert)
+        ok = ok and cert["pencil_residual"] < tol and cert["pencil_orthonormality"] < tol
+        ok = ok and cert["pencil_eigenvalues_above_lambda_k"] == k
+    if sharded:
+        # one verdict for all ranks: a rank that fails alone would leave the others waiting in the next collective
+        import torch
+        import torch.distributed as dist
+
+        flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=views[0].device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = bool(flag.item() > 0.5)
     rep["ok"] = bool(ok)
     return rep
 
@@ -151,7 +160,7 @@ def check_fit_properties(model, views, jd, seed, row0=0, sharded=False, n_check=
 def topk_certificate(model, views, sharded=False, chunk=32768):
     """Eigen-residual, B-orthonormality and the number of pencil eigenvalues above lambda_k (by inertia: one LDL'
     factorization on the host) for the two-view pencil of ``cca_zoo/linear/_rcca.py:92-100`` at c = 0, from float64
-    moments that torch accumulates here.  Every rank takes part; the factorization runs on every rank (same numbers)."""
+    moments that torch accumulates here.  Every rank takes part in the moments; rank 0 alone runs the factorization (returns ``None`` elsewhere)."""
     import numpy as np
     import torch
 
@@ -172,6 +181,11 @@ def topk_certificate(model, views, sharded=False, chunk=32768):
 
         for t in (G, sm, n_tot):
             dist.all_reduce(t)
+    if sharded:
+        import torch.distributed as dist
+
+        if dist.get_rank() != 0:                           # the host-side certificate is the same on every rank: rank 0 does it
+            return None
     Gh, sh, n = G.cpu().numpy(), sm.cpu().numpy(), int(round(float(n_tot.item())))
     del G, sm
     torch.cuda.empty_cache()
@@ -179,7 +193,20 @@ def topk_certificate(model, views, sharded=False, chunk=32768):
     V = np.vstack(model.weights_).astype(np.float64) / np.sqrt(2.0)
     lam = np.asarray(model.singular_values_, dtype=np.float64)
     f32 = views[0].element_size() == 4
-    r = ct.pencil_certificate(A, B, V, lam, delta=1e-4 if f32 else 1e-6, inertia=True)
+    limiter = None
+    if sharded:                                            # the other ranks sit in an all-reduce: their cores are free
+        try:
+            from threadpoolctl import threadpool_limits
+
+            affinity, quota = host_cores()
+            limiter = threadpool_limits(limits=max(1, int(min(affinity, quota) if quota else affinity) - 2))
+        except Exception:
+            limiter = None
+    try:
+        r = ct.pencil_certificate(A, B, V, lam, delta=1e-4 if f32 else 1e-6, inertia=True)
+    finally:
+        if limiter is not None:
+            limiter.restore_original_limits()
     return {"pencil_residual": float(r["residual"]), "pencil_orthonormality": float(r["orthonormality"]),
             "pencil_eigenvalues_above_lambda_k": int(r["n_above"]), "k": int(r["k"]),
             "moments_by": "torch float64 addmm over row chunks (comparator)"}
