@@ -108,7 +108,6 @@ int ccz_destroy(ccz_handle h) {
     if (im->copy_stream) (void)hipStreamDestroy(im->copy_stream);
     for (int i = 0; i < 2; ++i) if (im->aux_ev[i]) (void)hipEventDestroy(im->aux_ev[i]);
     for (auto& e : im->bj_ev) if (e) (void)hipEventDestroy(e);
-    for (auto& q : im->bj_side) if (q) (void)hipStreamDestroy(q);
     if (im->aux_stream) (void)hipStreamDestroy(im->aux_stream);
     for (int i = 0; i < 2; ++i) if (im->xs_ev[i]) (void)hipEventDestroy(im->xs_ev[i]);
     if (im->loss_status) (void)hipHostFree(im->loss_status);

@@ -49,9 +49,7 @@ struct Impl {
   // second stream + events for the look-ahead of the super-blocked Cholesky (ops_hip.hip), created on first use
   hipStream_t aux_stream = nullptr;
   hipEvent_t aux_ev[2] = {nullptr, nullptr};
-  hipEvent_t bj_ev[8] = {};           // evd_block.hip: pair kernel / tile update hand-overs of the fused schedule
-  hipStream_t bj_side[2] = {nullptr, nullptr};   // ... and its tile-update streams (CU mask: 7/8 and 3/4 of the chip)
-  bool bj_side_failed = false;
+  hipEvent_t bj_ev[8] = {};           // evd_block.hip: pair kernel / tile update hand-overs of the two-stream schedule (CCZ_BJ_FUSED=1)
   // device copies of recently used K1 tile tables (gram.hip): the table is a pure function of the views' pointers,
   // widths and strides, so a training loop (same pooled staging buffer every step) never copies one again
   struct TileTab { uint64_t hash; size_t bytes; void* dev; uint64_t tick; };
