@@ -249,3 +249,28 @@ def test_mcca_loss_and_inv_sqrtm():
     A = torch.tensor(g["inv_sqrtm/A"])
     np.testing.assert_allclose(ol.inv_sqrtm_eigh(A, 1e-5).numpy(), g["inv_sqrtm/out_eps1e-5"], atol=1e-9)
     np.testing.assert_allclose(ol.inv_sqrtm_eigh(A, 0.5).numpy(), g["inv_sqrtm/out_eps0.5"], atol=1e-10)
+
+
+def test_gcca_gram_form_topk_hook_matches_the_dense_solve():
+    """``oracle.gram_form.gcca_from_moments(topk=...)`` (used by the configs[4]-sized GPU test with a Lanczos solver) gives the dense
+    ``eigh`` result: weights, eigenvalues, non-uniform view weights and per-view ridge."""
+    import scipy.sparse.linalg as spla
+
+    from oracle import gram_form as gf
+    from oracle import reference_form as rf
+
+    views = rf.joint_data(3, 400, 4, [30, 24, 20], 2.0, 1)
+    G, s, n = gf.moments(views)
+    kw = dict(c=[0.1, 0.2, 0.05], view_weights=[1.0, 2.0, 0.5])
+    W0, _, l0 = gf.gcca_from_moments(G, s, n, [30, 24, 20], 4, **kw)
+
+    def lanczos(K, k):
+        lam, U = spla.eigsh(K, k=k, which="LA", tol=1e-13)
+        o = np.argsort(lam)[::-1]
+        return lam[o], U[:, o]
+
+    W1, _, l1 = gf.gcca_from_moments(G, s, n, [30, 24, 20], 4, topk=lanczos, **kw)
+    np.testing.assert_allclose(l1, l0, rtol=1e-11)
+    for a, b in zip(W0, W1):
+        sgn = np.sign(np.sum(a * b, axis=0))
+        np.testing.assert_allclose(b * sgn, a, atol=1e-10 * np.abs(a).max())
