@@ -8,21 +8,23 @@
 // blocking decides is where the O(d^3) of work per sweep runs.  Here a round of the OUTER tournament pairs the
 // d / 32 column blocks (32 wide) into d / 64 disjoint pairs and splits into two launches:
 //
-//   k_bj_inner   one workgroup per block pair: the pair's 64 x 64 symmetric matrix S (two-sided form: gathered from A;
+//   k_bj_inner2  one workgroup per block pair: the pair's 64 x 64 symmetric matrix S (two-sided form: gathered from A;
 //                one-sided form: the Gram matrix of the pair's 64 rows of W) lives in LDS as its packed lower
 //                triangle; 32 rounds of 32 simultaneous rotations annihilate the CROSS block only (pairs (i, 32 +
 //                (i + r) mod 32): every element pair of the two blocks exactly once) -- in the first outer round of a
 //                sweep a full 63-round tournament instead, which also covers the pairs inside each block.  The
-//                accumulated rotation R (64 x 64) is kept transposed in LDS and written out; no O(d) work here.
+//                accumulated rotation R (64 x 64) lives in registers (cross-block rounds) or transposed in LDS (full
+//                tournament) and is written out; a pair with nothing above the threshold rests (R = I, flag); no O(d) work here.
 //   k_bj_apply   every other tile of the matrix takes  A_KL <- R_K' A_KL R_L  (two 64^3 products on
 //                v_mfma_f64_16x16x4_f64, the second one with the first one's accumulators as its B fragments) and the
 //                eigenvector rows  V'[K] <- R_K' V'[K]: all of the O(d^3) work is MFMA work on 64-wide tiles, one
-//                launch per round, in place (block pairs are disjoint).
+//                launch per round, in place (block pairs are disjoint); tiles whose pairs both rest are skipped; on large
+//                grids a workgroup walks a run of four tiles with the next operands prefetched into registers.
 //
 // A is kept in "block-upper" canonical form: 32 x 32 sub-block (x, y), x < y, is stored at its natural place, the
 // mirrored one is never read or written (tiles transpose on load / store), diagonal sub-blocks are stored whole.
 // One sweep = d / 32 - 1 rounds = one hipGraph, replayed per sweep; the host reads one rotation counter per sweep.
-// The one-sided form (thin SVD: rows of W orthogonalised, ccz_gesvj) shares k_bj_inner and the row-tile half of
+// The one-sided form (thin SVD: rows of W orthogonalised, ccz_gesvj) shares k_bj_inner2 and the row-tile half of
 // k_bj_apply; its Gram blocks come from k_bj_gram (split over the row length, partials summed in a fixed order).
 #include <cmath>
 #include <cstdio>
@@ -81,8 +83,10 @@ __device__ __forceinline__ void bj_pair_c(int r, int k, int& p, int& q) {
 //     sources' rotated diagonals (h_pp - t h_pq, h_qq + t h_pq: shuffled from the source lanes) and its new off-diagonal
 //     entry is one element of the rotated 2 x 2 block (source pair A, source pair B) of the CURRENT S: four LDS reads
 //     that depend on nothing computed this round (issued first), the sources' (c, s) by shuffle;
-//   * S is double-buffered in LDS: waves 1..8 rotate the 496 off-diagonal blocks from S[cur] into S[nxt] and waves
-//     9..12 rotate R while lane k computes the next (c, s); the rotated pair's own three cells are written by lane k;
+//   * S is double-buffered in LDS: waves 1..9 rotate its 528 blocks (the rotated pairs' own blocks included: with the exact
+//     (c, s), so the transformation is an exact similarity whatever the angle's precision) from S[cur] into S[nxt] and
+//     waves 10..13 (cross-block rounds: R in registers) or 10..15 (full tournament: R in LDS) rotate R while lane k
+//     computes the next (c, s);
 //   * ONE barrier per round; the loop-carried chain is  t (fp32: the angle needs no more -- a float32-accurate rotation
 //     leaves a 1e-7 remainder that the next sweep removes) -> c = (1 + t^2)^-1/2 (fp32 seed, one third-order step in
 //     fp64: c^2 + s^2 = 1 to rounding) -> s = t c -> four multiply-adds for the next h_pq: ~13 dependent fp64 operations
