@@ -103,6 +103,9 @@ SIGNATURES = {
     "ccz_gemm_f64": (_int, [_vp, _int, _int, _i64, _i64, _i64, _dbl, _vp, _i64, _vp, _i64, _dbl, _vp, _i64]),
     "ccz_cca_loss": (_int, [_vp, _int, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _dbl, _vp, _vp, _vp, _i64, _i64]),
     "ccz_pair_loss": (_int, [_vp, _int, C.POINTER(View), _int, _i64, _dbl, _vp, C.POINTER(_vp), _pi64]),
+    "ccz_pair_loss_state_bytes": (_i64, [_int, _pi64, _int]),
+    "ccz_pair_loss_forward": (_int, [_vp, _int, C.POINTER(View), _int, _i64, _dbl, _vp, _vp]),
+    "ccz_pair_loss_backward": (_int, [_vp, _int, C.POINTER(View), _int, _i64, _vp, _vp, C.POINTER(_vp), _pi64]),
     "ccz_cca_loss_moments": (_int, [_vp, _vp, _i64, _i64, _i64, _dbl, C.POINTER(_dbl), _vp, _vp]),
     "ccz_pair_loss_moments": (_int, [_vp, _vp, _i64, _pi64, _int, _dbl, C.POINTER(_dbl), _vp, _vp]),
     "ccz_cholinv": (_int, [_vp, _int, C.POINTER(_vp), _pi64, C.POINTER(_vp), C.POINTER(_vp)]),

@@ -16,6 +16,10 @@ void cca_loss_impl(ccz_ctx* c, int dtype, const void* z1, const void* z2, int64_
                    int64_t ld2, double eps, void* loss_dev, void* g1, void* g2, int64_t ldg1, int64_t ldg2);
 void pair_loss_impl(ccz_ctx* c, int dtype, const ccz_view* z, int m, int64_t n, double eps, void* loss_dev, void* const* g,
                     const int64_t* ldg);
+int64_t pair_loss_state_bytes_impl(int dtype, const int64_t* dims, int m);
+void pair_loss_forward_impl(ccz_ctx* c, int dtype, const ccz_view* z, int m, int64_t n, double eps, void* loss_dev, void* state);
+void pair_loss_backward_impl(ccz_ctx* c, int dtype, const ccz_view* z, int m, int64_t n, const void* state, const void* grad_out,
+                             void* const* g, const int64_t* ldg);
 void cca_loss_moments_impl(ccz_ctx* c, const double* mom, int64_t n, int64_t d1, int64_t d2, double eps, double* loss_host,
                            double* gamma_dev, double* mean_dev);
 void pair_loss_moments_impl(ccz_ctx* c, const double* mom, int64_t n, const int64_t* dims, int m, double eps,
@@ -98,6 +102,8 @@ int ccz_destroy(ccz_handle h) {
     if (im->own_stream) (void)hipStreamDestroy(im->own_stream);
     for (auto& b : im->pool) (void)hipFree(b.p);
     for (auto& t : im->tile_tabs) if (t.dev) (void)hipFree(t.dev);
+    for (auto& e : im->chain_sync) if (e.second) (void)hipFree(e.second);
+    if (im->colsum_counters) (void)hipFree(im->colsum_counters);
     for (int i = 0; i < 4; ++i) (void)hipEventDestroy(im->ev[i]);
     for (int i = 0; i < 4; ++i) if (im->pipe_ev[i]) (void)hipEventDestroy(im->pipe_ev[i]);
     for (int i = 0; i < 2; ++i) if (im->pin_buf[i]) (void)hipHostFree(im->pin_buf[i]);
@@ -354,6 +360,20 @@ int ccz_cca_loss(ccz_handle h, int dtype, const void* z1_dev, const void* z2_dev
 int ccz_pair_loss(ccz_handle h, int dtype, const ccz_view* z_dev, int n_views, int64_t n, double eps, void* loss_dev,
                   void* const* g_dev, const int64_t* ldg) {
   CCZ_GUARD(h, ccz::pair_loss_impl(h, dtype, z_dev, n_views, n, eps, loss_dev, g_dev, ldg));
+}
+
+int64_t ccz_pair_loss_state_bytes(int dtype, const int64_t* dims, int n_views) {
+  return ccz::pair_loss_state_bytes_impl(dtype, dims, n_views);
+}
+
+int ccz_pair_loss_forward(ccz_handle h, int dtype, const ccz_view* z_dev, int n_views, int64_t n, double eps, void* loss_dev,
+                          void* state_dev) {
+  CCZ_GUARD(h, ccz::pair_loss_forward_impl(h, dtype, z_dev, n_views, n, eps, loss_dev, state_dev));
+}
+
+int ccz_pair_loss_backward(ccz_handle h, int dtype, const ccz_view* z_dev, int n_views, int64_t n, const void* state_dev,
+                           const void* grad_out_dev, void* const* g_dev, const int64_t* ldg) {
+  CCZ_GUARD(h, ccz::pair_loss_backward_impl(h, dtype, z_dev, n_views, n, state_dev, grad_out_dev, g_dev, ldg));
 }
 
 int ccz_cca_loss_moments(ccz_handle h, const double* moments_dev, int64_t n_rows, int64_t d1, int64_t d2, double eps,

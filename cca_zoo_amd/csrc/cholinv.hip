@@ -31,7 +31,9 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 constexpr int CB = 64;          // block edge
 constexpr int CLD = CB + 1;     // LDS tile stride (doubles): row and column walks both conflict-free for the wave code
 constexpr int CTILE = CB * CLD; // doubles per LDS tile
-constexpr size_t CHOLINV_LDS = (size_t(3) * CTILE + 2 * CB + 8 + 4 * CB) * sizeof(double);   // 3 tiles, Rd, flags, 64 x 4 panel
+constexpr int CPLD = 17;        // row stride (doubles) of the 64 x 16 panel image of the 16-column form
+constexpr size_t CHOLINV_LDS = (size_t(3) * CTILE + 2 * CB + 8 + CPLD * CB) * sizeof(double);   // 3 tiles, Rd, flags, panel image
+constexpr size_t CHAIN_LDS = (size_t(4) * CTILE + 2 * CB + 8 + CPLD * CB) * sizeof(double);     // + a fourth tile (k_cholinv_chain)
 
 // ---------------------------------------------------------------------------
 // 64 x 64 tile products on the fp64 matrix pipe, operands in LDS tiles (stride CLD).
@@ -127,6 +129,18 @@ __device__ __forceinline__ double rsqrt_newton(double x) {
     y = __builtin_fma(0.5 * y, e, y);
   }
   return y;
+}
+
+// v_rsq_f64 seed + ONE third-order step (y (1 + e/2 + 3 e^2/8), e = 1 - x y^2): five dependent operations instead of
+// the seven of two Newton steps -- a dependent fp64 operation costs 32 cycles on this chip (profiles/r02c_clock_probe.md)
+// and this is the pivot chain of every 64 x 64 block.  Relative error ~ (5/16) e0^3 with e0 the seed's (~2^-26): rounding.
+__device__ __forceinline__ double rsqrt_cubic(double x) {
+  const double y0 = __builtin_amdgcn_rsq(x);
+  const double t = x * y0;
+  const double e = __builtin_fma(-t, y0, 1.0);
+  const double p = __builtin_fma(e, 0.375, 0.5);
+  const double q = y0 * e;
+  return __builtin_fma(q, p, y0);
 }
 
 // 16-byte reads of a buffer that is written through plain `double` lvalues: may_alias, or type-based alias analysis
@@ -332,6 +346,85 @@ __device__ __forceinline__ int chol64_mfma(const double* In, double* Ls, double*
   return first_bad;
 }
 
+// ---------------------------------------------------------------------------
+// MFMA form with 16-COLUMN panels (round 5, the default).  The 4-column form above makes 15 accumulator -> LDS -> lane
+// = row -> LDS -> MFMA-fragment round trips per block (~500 cycles each) around a pivot chain of ~290 cycles per pivot;
+// here a panel is a whole tile column: ONE trip through LDS brings it into lane = row registers (16 values per lane),
+// all 16 pivots run in registers -- the update of the panel's remaining columns by pivot t is (15 - t) readlane + FMA
+// pairs that are independent of each other and fill the latency shadow of the NEXT pivot's rsqrt chain -- and the
+// trailing tiles (strictly right of the panel) take the panel as FOUR k-steps of v_mfma_f64_16x16x4_f64 whose operand
+// fragments are read straight from the column-major factor image.  3 + 3 LDS trips per block instead of 31, and the
+// tile column of panel 0 never visits the accumulators at all.
+// ---------------------------------------------------------------------------
+template <int P>
+__device__ __forceinline__ void chol_panel16(v4f64 (&acc)[4][4], int lane, const double* In, double* Ls, double* Rd, double* PL,
+                                             int& first_bad) {
+  constexpr int C0 = 16 * P;
+  double pv[16], l[16];
+  if (P == 0) {
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) pv[cc] = In[lane * CLD + cc];
+  } else {
+    // the panel's tile column: accumulators -> PL[row][0..15] (rows >= C0 only: rows above the panel are never used)
+#pragma unroll
+    for (int ti = P; ti < 4; ++ti)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) PL[(16 * ti + (lane >> 4) + 4 * r) * CPLD + (lane & 15)] = acc[ti][P][r];
+    wave_lds_sync();
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) pv[cc] = PL[lane * CPLD + cc];
+  }
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    double piv = bcast_lane(pv[t], C0 + t);
+    const bool bad = !(piv > 0.0);                     // wave-uniform; NaN counts as bad
+    first_bad = bad ? min(first_bad, C0 + t) : first_bad;
+    piv = bad ? 1.0 : piv;
+    const double rs = rsqrt_cubic(piv);
+    l[t] = lane >= C0 + t ? pv[t] * rs : 0.0;          // select, not multiply: lanes above hold stale / foreign values
+    if (lane == 0) Rd[C0 + t] = rs;                    // 1 / L_jj for the substitution of the inverse
+#pragma unroll
+    for (int u = t + 1; u < 16; ++u) pv[u] = __builtin_fma(-l[t], bcast_lane(l[t], C0 + u), pv[u]);
+  }
+  // column-major factor image Ls[col][row] (whole columns, zeros above the diagonal) -- also the MFMA operand image
+#pragma unroll
+  for (int t = 0; t < 16; ++t) Ls[(C0 + t) * CLD + lane] = l[t];
+  if (P == 3) return;
+  wave_lds_sync();
+  // acc[ti][tj] -= L[rows of ti][panel] L[rows of tj][panel]'  for the tiles right of the panel: A fragment of k-step ks
+  // = L[16 ti + (lane & 15)][C0 + 4 ks + (lane >> 4)]; the B fragment of tile column tj is the A fragment of tile row tj
+  double a[4][4];
+#pragma unroll
+  for (int ti = P + 1; ti < 4; ++ti)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) a[ti][ks] = Ls[(C0 + 4 * ks + (lane >> 4)) * CLD + 16 * ti + (lane & 15)];
+#pragma unroll
+  for (int tj = P + 1; tj < 4; ++tj)
+#pragma unroll
+    for (int ti = tj; ti < 4; ++ti)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[ti][ks], a[tj][ks], acc[ti][tj], 0, 0, 0);
+}
+
+// wave 0: In (row-major, stride CLD, symmetric, identity-padded) -> Ls[col * CLD + row] = L[row][col], Rd[j] = 1 / L_jj
+__device__ __forceinline__ int chol64_p16(const double* In, double* Ls, double* Rd, double* PL, int lane) {
+  v4f64 acc[4][4];
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        acc[ti][tj][r] = (tj >= 1 && tj <= ti) ? In[(16 * ti + (lane >> 4) + 4 * r) * CLD + 16 * tj + (lane & 15)] : 0.0;
+  int first_bad = 0x7fffffff;
+  chol_panel16<0>(acc, lane, In, Ls, Rd, PL, first_bad);
+  chol_panel16<1>(acc, lane, In, Ls, Rd, PL, first_bad);
+  chol_panel16<2>(acc, lane, In, Ls, Rd, PL, first_bad);
+  chol_panel16<3>(acc, lane, In, Ls, Rd, PL, first_bad);
+  return first_bad;
+}
+
 // all four waves: Xs[col * CLD + row] = (L^-1)[row][col]  (== row-major L^-T) from Ls / Rd
 __device__ __forceinline__ void inv64_mfma(const double* Ls, const double* Rd, double* Xs, int tid) {
   const int lane = tid & 63, w = tid >> 6;
@@ -385,7 +478,9 @@ __device__ __forceinline__ void inv64_mfma(const double* Ls, const double* Rd, d
 
 // Whole workgroup (256 threads), input tile in LDS tile 1 (identity-padded): factor (tile 0 <- L, column-major),
 // invert (tile 2 <- L^-T, row-major), publish the L block and T = L^-T to global memory.
-template <bool MFMA_FORM>
+// FORM: 0 shift-register recurrence on two waves, 1 MFMA form with 4-column panels (rounds 2-4), 2 MFMA form with
+// 16-column panels (default)
+template <int FORM>
 __device__ __forceinline__ void factor_and_publish_t(double* lds, int tid, int nbv, double* __restrict__ Lblk, int64_t ldl,
                                                      double* __restrict__ Tblk, int* __restrict__ info, int64_t col0) {
   double* Ls = lds;
@@ -394,10 +489,10 @@ __device__ __forceinline__ void factor_and_publish_t(double* lds, int tid, int n
   double* Rd = lds + 3 * CTILE;
   int* progress = reinterpret_cast<int*>(Rd + CB);
   double* PL = Rd + CB + 8;
-  if (MFMA_FORM) {
+  if (FORM != 0) {
     __syncthreads();
     if (tid < 64) {
-      const int bad = chol64_mfma(In, Ls, Rd, PL, tid);
+      const int bad = FORM == 2 ? chol64_p16(In, Ls, Rd, PL, tid) : chol64_mfma(In, Ls, Rd, PL, tid);
       if (tid == 0 && bad != 0x7fffffff) atomicMin(info, int(col0 + bad + 1));
     }
     __syncthreads();
@@ -419,7 +514,7 @@ __device__ __forceinline__ void factor_and_publish_t(double* lds, int tid, int n
 }
 
 // first diagonal block of every matrix
-template <bool MFMA_FORM>
+template <int FORM>
 __global__ __launch_bounds__(256) void k_cholinv_first(CholInvBatch bt, int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) char ci_smem[];
   double* lds = reinterpret_cast<double*>(ci_smem);
@@ -434,11 +529,11 @@ __global__ __launch_bounds__(256) void k_cholinv_first(CholInvBatch bt, int* __r
     if (r < nbv && c < nbv) v = c <= r ? bt.A[b][int64_t(r) * bt.lda[b] + c] : bt.A[b][int64_t(c) * bt.lda[b] + r];
     Xs[r * CLD + c] = v;
   }
-  factor_and_publish_t<MFMA_FORM>(lds, tid, nbv, bt.L[b], bt.ldl[b], bt.T[b], info + b, 0);
+  factor_and_publish_t<FORM>(lds, tid, nbv, bt.L[b], bt.ldl[b], bt.T[b], info + b, 0);
 }
 
 // step j: trailing update (+ look-ahead factorization of block j + 1) and row j of the inverse
-template <bool MFMA_FORM>
+template <int FORM>
 __global__ __launch_bounds__(256) void k_cholinv_step(CholInvBatch bt, int j, int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) char ci_smem[];
   double* lds = reinterpret_cast<double*>(ci_smem);
@@ -519,7 +614,7 @@ __global__ __launch_bounds__(256) void k_cholinv_step(CholInvBatch bt, int j, in
         }
         Q[rr * CLD + cc] = v;                             // tile 1 = Xs of the wave factorization
       }
-    factor_and_publish_t<MFMA_FORM>(lds, tid, rows_i, L + ri * ldl + ri, ldl, bt.T[b] + int64_t(j + 1) * CB * CB, info + b, ri);
+    factor_and_publish_t<FORM>(lds, tid, rows_i, L + ri * ldl + ri, ldl, bt.T[b] + int64_t(j + 1) * CB * CB, info + b, ri);
     return;
   }
 
@@ -570,17 +665,421 @@ struct MultiGemm;
 __global__ void k_gemm_f64_multi(MultiGemm g);
 constexpr size_t MG_LDS_FWD = size_t(4) * CTILE * sizeof(double);
 
+// ---------------------------------------------------------------------------
+// ONE persistent launch for the whole factor + inverse (round 5).
+//
+// The launch-per-link form above pays, per 64-column link, a kernel launch, a reload of T_j and of the two tiles the
+// diagonal recurrence needs, and the trailing tiles' latency in FRONT of the next factorization (34 us per link, of which
+// the 64 x 64 factorization is ~20).  Here the work items of ALL links are handed out through a ticket counter to a
+// fixed set of workgroups, and device-side progress counters order them:
+//
+//   * chain workgroup b (ticket b < count) stays with matrix b for the whole launch: factor block j, invert it (T_j
+//     stays in its LDS), form L_{j+1,j} = A_{j+1,j} T_j and S = A_{j+1,j+1} - L_{j+1,j} L_{j+1,j}' from tiles that the
+//     helpers brought up to date while block j was being factored, factor S, ...  -- its link is two tile products and
+//     the factorization, nothing else;
+//   * helper items (tickets in link-major order): trailing tile (i, k) of link j (all but the chain's own tile);
+//     XS(i, k): the partial sums  S_ik = sum_{t=k}^{i-1} L_it X_tk  of row i of X = L^-1, which need rows < i and the
+//     panel L_{i,i-1} but NOT T_i -- they run while block i is being factored; XT(j, k): X_jk = -T_j' S_jk (X_jj = T_j'),
+//     one tile product once T_j is published.
+//
+// Deadlock freedom without co-residency: a helper item only waits for items with LOWER tickets (tickets are taken in
+// start order, so those have started) and for chain progress that the chain reaches without waiting for that item's
+// link; the chain only waits for helpers of link j - 1, which wait for nothing the chain has not published already.
+// Spin waits poll one word with agent-scope atomics and sleep in between; a watchdog (~2 s) turns a protocol bug into a
+// reported failure (info = 0x7ffffff0) instead of a hung device.  The sync block is zero between launches: the last
+// workgroup to finish clears it.
+// ---------------------------------------------------------------------------
+constexpr int CH_MAXNB = 64;        // block columns per matrix the chain kernel serves (d <= 4096)
+constexpr int CH_WATCHDOG = 1 << 22;
+constexpr int CH_TIMEOUT_INFO = 0x7ffffff0;
+
+struct ChainSync {
+  unsigned ticket;                  // next work item
+  unsigned done;                    // workgroups that have left the item loop
+  unsigned abort;                   // a wait ran into the watchdog
+  unsigned pad_;
+  unsigned F[CMAXB];                // diagonal blocks factored and published: T_0 .. T_{F-1}, L_jj
+  unsigned G[CMAXB];                // panel blocks L_{g,g-1} written for all g <= G
+  unsigned U[CMAXB][CH_MAXNB];      // finished trailing-tile items of link j (the chain's own tile is not counted)
+  unsigned XS[CMAXB][CH_MAXNB];     // finished partial-sum items of row i of X
+  unsigned XR[CMAXB][CH_MAXNB];     // finished items of row j of X
+};
+
+struct ChainPlan {
+  int link_first[CH_MAXNB + 1];     // helper items of the links before j, all matrices; [nbmax] = all helper items
+  int nbmax;
+  int total;                        // count chain items + helper items
+};
+
+// helper items of matrix (nb block columns, with / without X) at link j: trailing tiles without the chain's, XT row j, XS row j + 1
+__host__ __device__ __forceinline__ void chain_counts(int nb, bool with_x, int j, int& hU, int& nXT, int& nXS) {
+  const int r = nb - 1 - j;
+  const int nU = r > 0 ? r * (r + 1) / 2 : 0;
+  hU = nU > 0 ? nU - 1 : 0;
+  nXT = (with_x && j < nb) ? j + 1 : 0;
+  nXS = (with_x && j + 1 < nb) ? j + 1 : 0;
+}
+
+// Thread 0 polls *p (agent scope) until it reaches `target`; the workgroup follows through a barrier and acquires.
+// flag: one LDS int.  Returns false after the watchdog / an abort raised elsewhere (the caller goes on with whatever is
+// in memory: the launch must terminate, its result is reported as failed).
+__device__ __forceinline__ bool chain_wait(unsigned* p, unsigned target, ChainSync* sy, int* flag, int tid) {
+  if (tid == 0) {
+    int good = 1, spins = 0;
+    while (int(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+      __builtin_amdgcn_s_sleep(8);
+      ++spins;
+      if ((spins & 63) == 0 && __hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { good = 0; break; }
+      if (spins > CH_WATCHDOG) {
+        __hip_atomic_store(&sy->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        good = 0;
+        break;
+      }
+    }
+    *flag = good;
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  const bool ok = *flag != 0;
+  __syncthreads();                     // the next wait may overwrite the flag
+  return ok;
+}
+
+// every thread's global stores of this item -> visible device-wide, then one counter update
+__device__ __forceinline__ void chain_publish_add(unsigned* p, int tid) {
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void chain_publish_set(unsigned* p, unsigned v, int tid) {
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// lds: tiles 0..2, Rd, flags, panel image (the layout factor_and_publish_t expects)
+template <int FORM>
+__device__ __forceinline__ void chain_matrix(const CholInvBatch& bt, int b, ChainSync* sy, int* __restrict__ info, double* lds, int* flag,
+                                             int tid) {
+  const int64_t d = bt.d[b];
+  const int nb = int((d + CB - 1) / CB);
+  const bool with_x = bt.X[b] != nullptr;
+  const int64_t lda = bt.lda[b], ldl = bt.ldl[b];
+  double* A = bt.A[b];
+  double* L = bt.L[b];
+  double* T = bt.T[b];
+  double* P = lds;               // tile 0: becomes Ls of the factorization
+  double* Q = lds + CTILE;       // tile 1: input of the factorization
+  double* TT = lds + 2 * CTILE;  // tile 2: T_j = L_jj^-T, left there by the factorization of block j
+  const int lane = tid & 63, w = tid >> 6;
+  bool ok = true;
+  {
+    const int nbv = int(min<int64_t>(CB, d));
+    if (tid == 0) info[b] = 0x7fffffff;
+    const int c = tid & 63;
+    for (int r = tid >> 6; r < CB; r += 4) {
+      double v = (r == c) ? 1.0 : 0.0;
+      if (r < nbv && c < nbv) v = c <= r ? A[int64_t(r) * lda + c] : A[int64_t(c) * lda + r];
+      Q[r * CLD + c] = v;
+    }
+    factor_and_publish_t<FORM>(lds, tid, nbv, L, ldl, T, info + b, 0);
+    chain_publish_set(&sy->F[b], 1u, tid);
+  }
+  for (int j = 0; j + 1 < nb; ++j) {
+    if (j >= 1) {                                        // tiles (j+1, j) and (j+1, j+1) carry the updates of the links < j
+      int hU, nXT, nXS;
+      chain_counts(nb, with_x, j - 1, hU, nXT, nXS);
+      if (hU > 0) ok = chain_wait(&sy->U[b][j - 1], unsigned(hU), sy, flag, tid) && ok;
+    }
+    const int i = j + 1;
+    const int64_t ri = int64_t(i) * CB, cj = int64_t(j) * CB;
+    const int rows_i = int(min<int64_t>(CB, d - ri));
+    load_tile<false>(P, A + ri * lda + cj, lda, rows_i, CB, tid);
+    __syncthreads();
+    v4f64 a1[4];
+    acc_zero(a1);
+    tile_mm<false, false>(P, TT, w, lane, a1);            // L_ij = A_ij T_j
+    __syncthreads();
+    acc_to_lds(a1, P, w, lane, 1.0);
+    __syncthreads();
+    {
+      const int c = tid & 63;
+      for (int rr = tid >> 6; rr < rows_i; rr += 4) L[(ri + rr) * ldl + cj + c] = P[rr * CLD + c];
+    }
+    chain_publish_set(&sy->G[b], unsigned(i), tid);       // row i of X may start its partial sums
+    v4f64 u[4];
+    acc_zero(u);
+    tile_mm<false, true>(P, P, w, lane, u);               // L_ij L_ij'
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int rr = 16 * w + (lane >> 4) + 4 * rg, cc = 16 * t + (lane & 15);
+        double v = (rr == cc) ? 1.0 : 0.0;
+        if (rr < rows_i && cc < rows_i) {
+          const double base = cc <= rr ? A[(ri + rr) * lda + ri + cc] : A[(ri + cc) * lda + ri + rr];
+          v = base - u[t][rg];
+        }
+        Q[rr * CLD + cc] = v;
+      }
+    // (the barrier at the head of factor_and_publish_t separates the reads of P above from the factor image written there)
+    factor_and_publish_t<FORM>(lds, tid, rows_i, L + ri * ldl + ri, ldl, T + int64_t(i) * CB * CB, info + b, ri);
+    chain_publish_set(&sy->F[b], unsigned(i + 1), tid);
+  }
+  if (!ok && tid == 0) atomicMin(info + b, CH_TIMEOUT_INFO);
+}
+
+// lds4: FOUR tiles (extra tile first), then Rd / flags / panel image
+__device__ __forceinline__ void chain_helper(const CholInvBatch& bt, const ChainPlan& plan, int q, ChainSync* sy, int* __restrict__ info,
+                                             double* lds4, int* flag, int tid) {
+  int j = 0;
+  while (j + 1 < plan.nbmax && q >= plan.link_first[j + 1]) ++j;
+  q -= plan.link_first[j];
+  int b = 0, hU = 0, nXT = 0, nXS = 0, nb = 0;
+  for (;; ++b) {
+    nb = int((bt.d[b] + CB - 1) / CB);
+    chain_counts(nb, bt.X[b] != nullptr, j, hU, nXT, nXS);
+    const int tot = hU + nXT + nXS;
+    if (q < tot || b + 1 >= bt.count) break;
+    q -= tot;
+  }
+  const bool with_x = bt.X[b] != nullptr;
+  const int64_t d = bt.d[b];
+  const int64_t lda = bt.lda[b], ldl = bt.ldl[b], ldx = bt.ldx[b];
+  double* A = bt.A[b];
+  double* L = bt.L[b];
+  double* X = bt.X[b];
+  const double* Tj = bt.T[b] + int64_t(j) * CB * CB;
+  const int64_t cj = int64_t(j) * CB;
+  const int lane = tid & 63, w = tid >> 6;
+  double* P = lds4 + CTILE;
+  double* Q = lds4 + 2 * CTILE;
+  double* TT = lds4 + 3 * CTILE;
+  bool ok = true;
+
+  if (q < hU) {
+    // ---- trailing tile (i, k) of link j, j < k <= i, (i, k) != (j+1, j+1) ----
+    ok = chain_wait(&sy->F[b], unsigned(j + 1), sy, flag, tid) && ok;
+    if (j >= 1) {
+      int pU, a_, b_;
+      chain_counts(nb, with_x, j - 1, pU, a_, b_);
+      if (pU > 0) ok = chain_wait(&sy->U[b][j - 1], unsigned(pU), sy, flag, tid) && ok;
+    }
+    const int item = q + 1;
+    int ii = int((sqrtf(8.0f * float(item) + 1.0f) - 1.0f) * 0.5f);
+    while (ii * (ii + 1) / 2 > item) --ii;
+    while ((ii + 1) * (ii + 2) / 2 <= item) ++ii;
+    const int kk = item - ii * (ii + 1) / 2;
+    const int i = j + 1 + ii, k = j + 1 + kk;
+    const int64_t ri = int64_t(i) * CB, rk = int64_t(k) * CB;
+    const int rows_i = int(min<int64_t>(CB, d - ri)), rows_k = int(min<int64_t>(CB, d - rk));
+    load_tile<false>(P, A + ri * lda + cj, lda, rows_i, CB, tid);
+    if (k != i) load_tile<false>(Q, A + rk * lda + cj, lda, rows_k, CB, tid);
+    load_tile<false>(TT, Tj, CB, CB, CB, tid);
+    __syncthreads();
+    v4f64 a1[4], a2[4];
+    acc_zero(a1);
+    tile_mm<false, false>(P, TT, w, lane, a1);            // L_ij = A_ij T_j
+    if (k != i) {
+      acc_zero(a2);
+      tile_mm<false, false>(Q, TT, w, lane, a2);          // L_kj = A_kj T_j
+    }
+    __syncthreads();
+    acc_to_lds(a1, P, w, lane, 1.0);
+    if (k != i) acc_to_lds(a2, Q, w, lane, 1.0);
+    __syncthreads();
+    if (k == j + 1) {                                     // exactly one tile per block row writes L_ij
+      const int c = tid & 63;
+      for (int rr = tid >> 6; rr < rows_i; rr += 4) L[(ri + rr) * ldl + cj + c] = P[rr * CLD + c];
+    }
+    v4f64 u[4];
+    acc_zero(u);
+    tile_mm<false, true>(P, k != i ? Q : P, w, lane, u);  // L_ij L_kj'
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int rr = 16 * w + (lane >> 4) + 4 * rg, cc = 16 * t + (lane & 15);
+        if (rr < rows_i && cc < rows_k) {
+          double* p = A + (ri + rr) * lda + rk + cc;
+          *p -= u[t][rg];
+        }
+      }
+    chain_publish_add(&sy->U[b][j], tid);
+  } else if (q < hU + nXT) {
+    // ---- XT(j, k): X_jk = -T_j' S_jk, X_jj = T_j' ----
+    const int k = q - hU;
+    const int rows_j = int(min<int64_t>(CB, d - cj));
+    ok = chain_wait(&sy->F[b], unsigned(j + 1), sy, flag, tid) && ok;
+    if (k == j) {
+      load_tile<true>(P, Tj, CB, CB, CB, tid);
+      __syncthreads();
+      const int c = tid & 63;
+      for (int rr = tid >> 6; rr < rows_j; rr += 4)
+        if (c < rows_j) X[(cj + rr) * ldx + cj + c] = P[rr * CLD + c];
+    } else {
+      ok = chain_wait(&sy->XS[b][j], unsigned(j), sy, flag, tid) && ok;
+      load_tile<false>(P, X + cj * ldx + int64_t(k) * CB, ldx, rows_j, CB, tid);     // S_jk
+      load_tile<false>(TT, Tj, CB, CB, CB, tid);
+      __syncthreads();
+      v4f64 o[4];
+      acc_zero(o);
+      tile_mm<true, false>(TT, P, w, lane, o);            // T_j' S
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int rr = 16 * w + (lane >> 4) + 4 * rg, cc = 16 * t + (lane & 15);
+          if (rr < rows_j) X[(cj + rr) * ldx + int64_t(k) * CB + cc] = -o[t][rg];
+        }
+    }
+    chain_publish_add(&sy->XR[b][j], tid);
+  } else {
+    // ---- XS(i, k), i = j + 1: S_ik = sum_{t=k}^{i-1} L_it X_tk, stored where X_ik will be ----
+    const int k = q - hU - nXT;
+    const int i = j + 1;
+    const int64_t ri = int64_t(i) * CB;
+    const int rows_i = int(min<int64_t>(CB, d - ri));
+    ok = chain_wait(&sy->G[b], unsigned(i), sy, flag, tid) && ok;           // L_{i,i-1} (and, through the chain, every L_it)
+    ok = chain_wait(&sy->XR[b][j], unsigned(j + 1), sy, flag, tid) && ok;   // rows <= j of X
+    v4f64 sacc[4];
+    acc_zero(sacc);
+    TileRegs ra, rb;
+    auto fetch = [&](int t) {
+      fetch_tile(ra, L + ri * ldl + int64_t(t) * CB, ldl, rows_i, CB, tid);                      // L_it
+      fetch_tile(rb, X + int64_t(t) * CB * ldx + int64_t(k) * CB, ldx, CB, CB, tid);             // X_tk
+    };
+    auto stash = [&](int buf) {
+      store_tile<false>(lds4 + buf * 2 * CTILE, ra, tid);
+      store_tile<false>(lds4 + buf * 2 * CTILE + CTILE, rb, tid);
+    };
+    fetch(k);
+    stash(0);
+    __syncthreads();
+    int buf = 0;
+    for (int t = k; t < i; ++t) {
+      const bool more = t + 1 < i;
+      if (more) fetch(t + 1);
+      tile_mm<false, false>(lds4 + buf * 2 * CTILE, lds4 + buf * 2 * CTILE + CTILE, w, lane, sacc);
+      if (more) stash(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int rr = 16 * w + (lane >> 4) + 4 * rg, cc = 16 * t + (lane & 15);
+        if (rr < rows_i) X[(ri + rr) * ldx + int64_t(k) * CB + cc] = sacc[t][rg];
+      }
+    chain_publish_add(&sy->XS[b][i], tid);
+  }
+  if (!ok && tid == 0) atomicMin(info + b, CH_TIMEOUT_INFO);
+}
+
+template <int FORM>
+__global__ __launch_bounds__(256) void k_cholinv_chain(CholInvBatch bt, ChainPlan plan, ChainSync* __restrict__ sy, int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) char ci_smem[];
+  double* lds4 = reinterpret_cast<double*>(ci_smem);          // extra tile, then the step kernels' layout
+  double* lds = lds4 + CTILE;
+  int* flags = reinterpret_cast<int*>(lds + 3 * CTILE + CB);   // [0] progress word of the shift-register form, [2] wait flag, [3] ticket
+  const int tid = threadIdx.x;
+  for (;;) {
+    __syncthreads();                                           // everyone is done with the previous item (LDS, flags)
+    if (tid == 0) flags[3] = int(__hip_atomic_fetch_add(&sy->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    __syncthreads();
+    const int ticket = flags[3];
+    if (ticket >= plan.total) break;
+    if (ticket < bt.count) chain_matrix<FORM>(bt, ticket, sy, info, lds, flags + 2, tid);
+    else chain_helper(bt, plan, ticket - bt.count, sy, info, lds4, flags + 2, tid);
+  }
+  // the last workgroup to leave clears the sync block for the next launch (nobody reads or writes it any more)
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) flags[3] = __hip_atomic_fetch_add(&sy->done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
+  __syncthreads();
+  if (flags[3]) {
+    unsigned* wds = reinterpret_cast<unsigned*>(sy);
+    for (int e = tid; e < int(sizeof(ChainSync) / sizeof(unsigned)); e += 256) wds[e] = 0u;
+  }
+}
+
+template <int FORM>
+static void cholinv_attr_form() {
+  CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholinv_first<FORM>), hipFuncAttributeMaxDynamicSharedMemorySize, int(CHOLINV_LDS)));
+  CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholinv_step<FORM>), hipFuncAttributeMaxDynamicSharedMemorySize, int(CHOLINV_LDS)));
+}
+
 static void cholinv_attr_once() {
   static thread_local int done_for_device = -1;
   int dev = -1;
   CCZ_HIP(hipGetDevice(&dev));
   if (done_for_device == dev) return;
-  CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholinv_first<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(CHOLINV_LDS)));
-  CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholinv_step<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(CHOLINV_LDS)));
-  CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholinv_first<false>), hipFuncAttributeMaxDynamicSharedMemorySize, int(CHOLINV_LDS)));
-  CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholinv_step<false>), hipFuncAttributeMaxDynamicSharedMemorySize, int(CHOLINV_LDS)));
+  cholinv_attr_form<0>();
+  cholinv_attr_form<1>();
+  cholinv_attr_form<2>();
+  CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholinv_chain<1>), hipFuncAttributeMaxDynamicSharedMemorySize, int(CHAIN_LDS)));
+  CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cholinv_chain<2>), hipFuncAttributeMaxDynamicSharedMemorySize, int(CHAIN_LDS)));
   CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_f64_multi), hipFuncAttributeMaxDynamicSharedMemorySize, int(MG_LDS_FWD)));
   done_for_device = dev;
+}
+
+// CCZ_CHOLINV_MFMA: 0 shift-register (two-wave) form of the 64 x 64 factorization, 1 MFMA form with 4-column panels
+// (rounds 2-4), 2 (default) MFMA form with 16-column panels
+static int cholinv_form() {
+  static const int form = [] { const char* e = getenv("CCZ_CHOLINV_MFMA"); const int v = e ? atoi(e) : 2; return v < 0 || v > 2 ? 2 : v; }();
+  return form;
+}
+
+// The sync block of the chain kernel belongs to the STREAM the launch goes into: launches on one stream are ordered, so
+// they can share a block (it is zero again when a launch ends); launches on different streams of one handle (the
+// factorization's look-ahead stream, a caller's adopted streams) get blocks of their own.
+static ChainSync* chain_sync_for(ccz_ctx* c) {
+  Impl* im = impl(c);
+  hipStream_t st = stream(c);
+  for (auto& e : im->chain_sync)
+    if (e.first == static_cast<void*>(st)) return static_cast<ChainSync*>(e.second);
+  if (im->chain_sync.size() >= 32) return nullptr;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (cs != hipStreamCaptureStatusNone) return nullptr;      // no allocation inside a capture: the launch-per-link form runs
+  void* p = nullptr;
+  if (hipMalloc(&p, sizeof(ChainSync)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (hipMemsetAsync(p, 0, sizeof(ChainSync), st) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); return nullptr; }
+  im->chain_sync.emplace_back(static_cast<void*>(st), p);
+  return static_cast<ChainSync*>(p);
+}
+
+// CCZ_CHOLINV_CHAIN=0: the launch-per-link form (rounds 2-4).  CCZ_CHAIN_WGS: workgroups of the persistent launch
+// (default 128; Impl::chain_cap overrides it for callers that share the chip with throughput work on another stream).
+static bool chain_launch(ccz_ctx* c, const CholInvBatch& bt, int nbmax, int* info_dev) {
+  static const int on = [] { const char* e = getenv("CCZ_CHOLINV_CHAIN"); return e ? atoi(e) : 1; }();
+  static const int wgs_env = [] { const char* e = getenv("CCZ_CHAIN_WGS"); return e ? atoi(e) : 128; }();
+  const int form = cholinv_form();
+  if (!on || form == 0 || bt.inv_only || nbmax > CH_MAXNB) return false;
+  ChainPlan plan{};
+  plan.nbmax = nbmax;
+  int total = 0;
+  for (int j = 0; j < nbmax; ++j) {
+    plan.link_first[j] = total;
+    for (int b = 0; b < bt.count; ++b) {
+      int hU, nXT, nXS;
+      chain_counts(int((bt.d[b] + CB - 1) / CB), bt.X[b] != nullptr, j, hU, nXT, nXS);
+      total += hU + nXT + nXS;
+    }
+  }
+  plan.link_first[nbmax] = total;
+  plan.total = total + bt.count;
+  ChainSync* sy = chain_sync_for(c);
+  if (!sy) return false;
+  Impl* im = impl(c);
+  const int cap = im->chain_cap > 0 ? im->chain_cap : std::max(wgs_env, 2);
+  // at least one helper workgroup next to the chain workgroups (they never leave their matrix)
+  const int grid = std::min(plan.total, std::max(cap, bt.count + 1));
+  if (form == 2) hipLaunchKernelGGL(k_cholinv_chain<2>, dim3(grid), dim3(256), CHAIN_LDS, stream(c), bt, plan, sy, info_dev);
+  else hipLaunchKernelGGL(k_cholinv_chain<1>, dim3(grid), dim3(256), CHAIN_LDS, stream(c), bt, plan, sy, info_dev);
+  CCZ_LAUNCH_CHECK();
+  return true;
 }
 
 // Factor `count` (<= 8) SPD matrices and (X != null) invert the factors, all in d_max / 64 + 1 launches on the
@@ -601,10 +1100,11 @@ void cholinv_batched(ccz_ctx* c, int count, double* const* A, const int64_t* lda
     bt.lda[b] = lda[b]; bt.ldl[b] = ldl[b]; bt.ldx[b] = X ? ldx[b] : 0; bt.d[b] = d[b];
     nbmax = std::max(nbmax, int((d[b] + CB - 1) / CB));
   }
-  // CCZ_CHOLINV_MFMA=0 selects the shift-register (two-wave) form of the 64 x 64 factorization
-  static const int mfma_form = [] { const char* e = getenv("CCZ_CHOLINV_MFMA"); return e ? atoi(e) : 1; }();
-  if (mfma_form) hipLaunchKernelGGL(k_cholinv_first<true>, dim3(count), dim3(256), CHOLINV_LDS, st, bt, info_dev);
-  else hipLaunchKernelGGL(k_cholinv_first<false>, dim3(count), dim3(256), CHOLINV_LDS, st, bt, info_dev);
+  const int form = cholinv_form();
+  if (chain_launch(c, bt, nbmax, info_dev)) return;        // ONE persistent launch (below); false: not applicable / switched off
+  if (form == 2) hipLaunchKernelGGL(k_cholinv_first<2>, dim3(count), dim3(256), CHOLINV_LDS, st, bt, info_dev);
+  else if (form == 1) hipLaunchKernelGGL(k_cholinv_first<1>, dim3(count), dim3(256), CHOLINV_LDS, st, bt, info_dev);
+  else hipLaunchKernelGGL(k_cholinv_first<0>, dim3(count), dim3(256), CHOLINV_LDS, st, bt, info_dev);
   for (int j = 0; j < nbmax; ++j) {
     int total = 0;
     for (int b = 0; b < count; ++b) {
@@ -617,8 +1117,9 @@ void cholinv_batched(ccz_ctx* c, int count, double* const* A, const int64_t* lda
     }
     bt.first[count] = total;
     if (total == 0) continue;
-    if (mfma_form) hipLaunchKernelGGL(k_cholinv_step<true>, dim3(total), dim3(256), CHOLINV_LDS, st, bt, j, info_dev);
-    else hipLaunchKernelGGL(k_cholinv_step<false>, dim3(total), dim3(256), CHOLINV_LDS, st, bt, j, info_dev);
+    if (form == 2) hipLaunchKernelGGL(k_cholinv_step<2>, dim3(total), dim3(256), CHOLINV_LDS, st, bt, j, info_dev);
+    else if (form == 1) hipLaunchKernelGGL(k_cholinv_step<1>, dim3(total), dim3(256), CHOLINV_LDS, st, bt, j, info_dev);
+    else hipLaunchKernelGGL(k_cholinv_step<0>, dim3(total), dim3(256), CHOLINV_LDS, st, bt, j, info_dev);
   }
   CCZ_LAUNCH_CHECK();
 }
@@ -648,7 +1149,7 @@ void trinv_batched(ccz_ctx* c, int count, const double* const* L, const int64_t*
     }
     bt.first[count] = total;
     if (total == 0) continue;
-    hipLaunchKernelGGL(k_cholinv_step<true>, dim3(total), dim3(256), CHOLINV_LDS, st, bt, j, static_cast<int*>(nullptr));
+    hipLaunchKernelGGL(k_cholinv_step<2>, dim3(total), dim3(256), CHOLINV_LDS, st, bt, j, static_cast<int*>(nullptr));
   }
   CCZ_LAUNCH_CHECK();
 }
@@ -686,6 +1187,10 @@ struct MultiGemm {
   int k_lower[MG_MAX];     // op(A) = X', op(B) = X with X lower triangular: only k >= max(m0, n0) contributes
   int ksplit[MG_MAX];      // > 1: the K range is cut into this many slices, C += alpha * (slice product) atomically
   double alpha[MG_MAX], beta[MG_MAX];
+  const double* dotB[MG_MAX];   // optional: *dot_acc += dot_scale * sum_ij (alpha op(A) op(B))_ij dotB_ij (ld lddot) -- linear in the
+  int64_t lddot[MG_MAX];        // product, so split-K slices simply add their shares (the DCCA loss value rides on the Gamma_ab stage)
+  double dot_scale[MG_MAX];
+  double* dot_acc;
   int first[MG_MAX + 1];
   int count;
 };
@@ -755,6 +1260,24 @@ __global__ __launch_bounds__(256) void k_gemm_f64_multi(MultiGemm g) {
   double* C = g.C[p];
   double* Ct = g.Ct[p];
   const int64_t ldc = g.ldc[p], ldct = g.ldct[p];
+  const double* dotB = g.dotB[p];
+  if (dotB) {                                                // uniform per workgroup
+    const int64_t lddot = g.lddot[p];
+    double dsum = 0.0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int rr = 16 * w + (lane >> 4) + 4 * rg, cc = 16 * t + (lane & 15);
+        if (rr < rows_m && cc < cols_n) dsum += alpha * acc[t][rg] * dotB[int64_t(m0 + rr) * lddot + n0 + cc];
+      }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dsum += __shfl_xor(dsum, o, 64);
+    __syncthreads();                                         // every wave is done with the operand tiles: reuse their first doubles
+    if (lane == 0) lds[w] = dsum;
+    __syncthreads();
+    if (tid == 0) unsafeAtomicAdd(g.dot_acc, g.dot_scale[p] * (lds[0] + lds[1] + lds[2] + lds[3]));
+  }
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -794,6 +1317,12 @@ void gemm_f64_multi(ccz_ctx* c, int count, const MultiGemmArgs* pr) {
     g.ksplit[i] = std::max(1, a.ksplit);
     if (g.ksplit[i] > 1 && (a.beta != 1.0 || a.Ct || !a.C)) fail(CCZ_EINVAL, "gemm_f64_multi: split-K accumulates into C (beta = 1, no Ct)");
     g.alpha[i] = a.alpha; g.beta[i] = a.beta;
+    g.dotB[i] = a.dotB; g.lddot[i] = a.lddot; g.dot_scale[i] = a.dot_scale;
+    if (a.dotB) {
+      if (!a.dot_acc || (g.dot_acc && g.dot_acc != a.dot_acc)) fail(CCZ_EINVAL, "gemm_f64_multi: one dot accumulator per launch");
+      if (g.ksplit[i] <= 1 && a.beta != 0.0) fail(CCZ_EINVAL, "gemm_f64_multi: the dot rider needs beta = 0 or split-K");
+      g.dot_acc = a.dot_acc;
+    }
     g.first[i] = total;
     total += int((a.M + CB - 1) / CB) * int((a.N + CB - 1) / CB) * g.ksplit[i];
   }

@@ -161,13 +161,20 @@ __device__ __forceinline__ void wait_vmcnt_12() { asm volatile("s_waitcnt vmcnt(
 __device__ __forceinline__ void wait_vmcnt_11() { asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); }
 __device__ __forceinline__ void wait_vmcnt_0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-template <int NTI>
+// TWO (the lazy backward of the DCCA loss, loss.hip): the A operand is [A | A2] -- columns [0, K1) from A (ld lda), columns
+// [K1, K) from A2 (ld lda2), K1 a multiple of the ring period (32) -- so two views are multiplied where they lie instead of
+// through a gathered copy; alpha is multiplied by *alpha_dev (the upstream gradient, a device scalar) and the centring row
+// is read as float64 (bias64) and rounded on load.
+template <int NTI, bool TWO>
 __device__ __forceinline__ void gemm_f32_nn_fifo_body(int64_t M, int64_t N, int64_t K, float alpha,
                                                       const float* __restrict__ A, int64_t lda,
                                                       const float* __restrict__ B, int64_t ldb, float beta,
                                                       float* __restrict__ C, int64_t ldc,
                                                       const float* __restrict__ bias,
-                                                      float* __restrict__ C2, int64_t ldc2, int64_t nsplit) {
+                                                      float* __restrict__ C2, int64_t ldc2, int64_t nsplit,
+                                                      const float* __restrict__ A2 = nullptr, int64_t lda2 = 0, int64_t K1 = 0,
+                                                      const float* __restrict__ alpha_dev = nullptr,
+                                                      const double* __restrict__ bias64 = nullptr) {
   // C2 != null: output columns [nsplit, N) go to C2 (columns renumbered from 0), nsplit a multiple of 256
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BTM = 64 * NTI;                         // rows per workgroup tile
@@ -185,12 +192,20 @@ __device__ __forceinline__ void gemm_f32_nn_fifo_body(int64_t M, int64_t N, int6
 
   const int64_t mw = m0 + wr * (32 * NTI);                        // first sample row of this wave's slab
   const int64_t rows_valid = min<int64_t>(32 * NTI, M - mw);      // <= 0: slab entirely past M (nothing stored)
-  const __amdgpu_buffer_rsrc_t srcA = make_rsrc(A + (rows_valid > 0 ? mw : 0) * lda,
-                                                rows_valid > 0 ? ((rows_valid - 1) * lda + K) * 4 : 0);
+  const int64_t KA = TWO ? K1 : K;                                // columns served by the first source
+  const __amdgpu_buffer_rsrc_t srcA1 = make_rsrc(A + (rows_valid > 0 ? mw : 0) * lda,
+                                                 rows_valid > 0 ? ((rows_valid - 1) * lda + KA) * 4 : 0);
+  const __amdgpu_buffer_rsrc_t srcA2 = TWO ? make_rsrc(A2 + (rows_valid > 0 ? mw : 0) * lda2,
+                                                       rows_valid > 0 ? ((rows_valid - 1) * lda2 + (K - K1)) * 4 : 0)
+                                           : srcA1;
   const __amdgpu_buffer_rsrc_t srcB = make_rsrc(B + n0 + wc * 128, ((K - 1) * ldb + 128) * 4);
-  int voffA[NTI];
+  int voffA[NTI], voffA2[NTI];
 #pragma unroll
-  for (int ti = 0; ti < NTI; ++ti) voffA[ti] = int(((32 * ti + (lane & 31)) * lda + 4 * (lane >> 5)) * 4);
+  for (int ti = 0; ti < NTI; ++ti) {
+    voffA[ti] = int(((32 * ti + (lane & 31)) * lda + 4 * (lane >> 5)) * 4);
+    voffA2[ti] = TWO ? int(((32 * ti + (lane & 31)) * lda2 + 4 * (lane >> 5)) * 4) : voffA[ti];
+  }
+  const int swapA = TWO ? __builtin_amdgcn_readfirstlane(int(K1 * 4)) : 0x7fffffff;   // soffA at which the second source takes over
   const int voffB = int(((4 * (lane >> 5)) * ldb + 4 * (lane & 31)) * 4);
   const int rowB = __builtin_amdgcn_readfirstlane(int(ldb * 4));   // bytes per k row of B
   int soffA = 0, soffB = 0;
@@ -208,8 +223,12 @@ __device__ __forceinline__ void gemm_f32_nn_fifo_body(int64_t M, int64_t N, int6
   for (int s = 0; s < 3; ++s) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      if (u < NTI)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(srcA, (lds_ptr)(ring + s * GFSLOT + u * 1024), 16, voffA[u < NTI ? u : 0], soffA, 0, 0);
+      if (u < NTI) {
+        if (TWO && soffA >= swapA)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(srcA2, (lds_ptr)(ring + s * GFSLOT + u * 1024), 16, voffA2[u < NTI ? u : 0], soffA - swapA, 0, 0);
+        else
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(srcA1, (lds_ptr)(ring + s * GFSLOT + u * 1024), 16, voffA[u < NTI ? u : 0], soffA, 0, 0);
+      }
       __builtin_amdgcn_raw_ptr_buffer_load_lds(srcB, (lds_ptr)(ring + s * GFSLOT + GFSLAB + u * 1024), 16, voffB, soffB, 0, 0);
       soffB += rowB;
     }
@@ -250,8 +269,12 @@ __device__ __forceinline__ void gemm_f32_nn_fifo_body(int64_t M, int64_t N, int6
           acc[0][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[bb & 1][0][u], b4[tj], acc[0][tj], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         // -- gap 1: DMA of A tile u of block b+3
-        if (u < NTI)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(srcA, (lds_ptr)(ring + wsl * GFSLOT + u * 1024), 16, voffA[u < NTI ? u : 0], soffA, 0, 0);
+        if (u < NTI) {
+          if (TWO && soffA >= swapA)          // wave-uniform: the k-block lies in the second source
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srcA2, (lds_ptr)(ring + wsl * GFSLOT + u * 1024), 16, voffA2[u < NTI ? u : 0], soffA - swapA, 0, 0);
+          else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srcA1, (lds_ptr)(ring + wsl * GFSLOT + u * 1024), 16, voffA[u < NTI ? u : 0], soffA, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj)
@@ -280,6 +303,11 @@ __device__ __forceinline__ void gemm_f32_nn_fifo_body(int64_t M, int64_t N, int6
   const int64_t nbase = n0 + wc * 128 + 4 * (lane & 31);
   v4f32 bias4 = {0.f, 0.f, 0.f, 0.f};
   if (bias) bias4 = *reinterpret_cast<const v4f32*>(bias + nbase);
+  if (TWO && bias64) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bias4[e] = float(bias64[nbase + e]);
+  }
+  if (TWO && alpha_dev) alpha *= *alpha_dev;
   float* Cout = C;
   int64_t ldo = ldc, ncol = nbase;
   if (C2 && n0 >= nsplit) { Cout = C2; ldo = ldc2; ncol = nbase - nsplit; }
@@ -305,7 +333,18 @@ __global__ __launch_bounds__(256, 1) void k_gemm_f32_nn_fifo(int64_t M, int64_t 
                                                              int64_t lda, const float* __restrict__ B, int64_t ldb, float beta,
                                                              float* __restrict__ C, int64_t ldc, const float* __restrict__ bias,
                                                              float* __restrict__ C2, int64_t ldc2, int64_t nsplit) {
-  gemm_f32_nn_fifo_body<NTI>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, C2, ldc2, nsplit);
+  gemm_f32_nn_fifo_body<NTI, false>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, C2, ldc2, nsplit);
+}
+
+// [A | A2] form (see the body): the lazy backward of the two-view DCCA loss
+template <int NTI>
+__global__ __launch_bounds__(256, 1) void k_gemm_f32_nn_fifo2(int64_t M, int64_t N, int64_t K, float alpha, const float* __restrict__ A,
+                                                              int64_t lda, const float* __restrict__ A2, int64_t lda2, int64_t K1,
+                                                              const float* __restrict__ B, int64_t ldb, float* __restrict__ C, int64_t ldc,
+                                                              float* __restrict__ C2, int64_t ldc2, int64_t nsplit,
+                                                              const float* __restrict__ alpha_dev, const double* __restrict__ bias64) {
+  gemm_f32_nn_fifo_body<NTI, true>(M, N, K, alpha, A, lda, B, ldb, 0.0f, C, ldc, static_cast<const float*>(nullptr), C2, ldc2, nsplit, A2, lda2,
+                                   K1, alpha_dev, bias64);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -542,6 +581,39 @@ void gemm_f32_fifo_split(ccz_ctx* c, int64_t M, int64_t N, int64_t K, float alph
     CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_f32_nn_fifo<4>), hipFuncAttributeMaxDynamicSharedMemorySize, int(fifo_bytes)));
     hipLaunchKernelGGL(k_gemm_f32_nn_fifo<4>, dim3((unsigned)((tmb + 7) / 8 * 8 * tnb)), dim3(256), fifo_bytes, stream(c), M, N, K, alpha, A,
                        lda, B32, N, 0.0f, C1, ldc1, bias32, C2, ldc2, nsplit);
+  }
+  CCZ_LAUNCH_CHECK();
+}
+
+// [C1 | C2] = alpha (*alpha_dev) ([A1 | A2] B32 - bias64): the two-view DCCA gradient with the views where they lie.
+// A1: M x K1 (ld lda1), A2: M x (K - K1) (ld lda2), B32: K x N fp32 (ld N), C1: columns [0, nsplit), C2: the rest.
+bool gemm_f32_fifo_pair_eligible(int64_t M, int64_t N, int64_t K, int64_t K1, int64_t nsplit, const void* A1, int64_t lda1, const void* A2,
+                                 int64_t lda2, const void* C1, int64_t ldc1, const void* C2, int64_t ldc2) {
+  if (!gemm_f32_fifo_split_eligible(M, N, K, nsplit, C1, ldc1, C2, ldc2)) return false;
+  if (K1 <= 0 || K1 >= K || K1 % 32 != 0 || (K - K1) % 32 != 0) return false;
+  if (lda1 % 4 != 0 || lda2 % 4 != 0 || lda1 < K1 || lda2 < K - K1) return false;
+  if (reinterpret_cast<uintptr_t>(A1) % 16 != 0 || reinterpret_cast<uintptr_t>(A2) % 16 != 0) return false;
+  if (int64_t(128) * lda1 * 4 >= (int64_t(1) << 31) || int64_t(128) * lda2 * 4 >= (int64_t(1) << 31)) return false;
+  return true;
+}
+
+void gemm_f32_fifo_pair(ccz_ctx* c, int64_t M, int64_t N, int64_t K, int64_t K1, float alpha, const float* alpha_dev, const float* A1,
+                        int64_t lda1, const float* A2, int64_t lda2, const float* B32, const double* bias64, float* C1, int64_t ldc1,
+                        float* C2, int64_t ldc2, int64_t nsplit) {
+  const int64_t tnb = N / BT;
+  const size_t fifo_bytes = size_t(4) * GFR * GFSLOT;
+  const int ncu = std::max(1, impl(c)->props.multiProcessorCount);
+  const bool half = (M + BT - 1) / BT * tnb < int64_t(ncu);
+  if (half) {
+    const int64_t tmb = (M + 127) / 128;
+    CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_f32_nn_fifo2<2>), hipFuncAttributeMaxDynamicSharedMemorySize, int(fifo_bytes)));
+    hipLaunchKernelGGL(k_gemm_f32_nn_fifo2<2>, dim3((unsigned)((tmb + 7) / 8 * 8 * tnb)), dim3(256), fifo_bytes, stream(c), M, N, K, alpha, A1, lda1,
+                       A2, lda2, K1, B32, N, C1, ldc1, C2, ldc2, nsplit, alpha_dev, bias64);
+  } else {
+    const int64_t tmb = (M + BT - 1) / BT;
+    CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_f32_nn_fifo2<4>), hipFuncAttributeMaxDynamicSharedMemorySize, int(fifo_bytes)));
+    hipLaunchKernelGGL(k_gemm_f32_nn_fifo2<4>, dim3((unsigned)((tmb + 7) / 8 * 8 * tnb)), dim3(256), fifo_bytes, stream(c), M, N, K, alpha, A1, lda1,
+                       A2, lda2, K1, B32, N, C1, ldc1, C2, ldc2, nsplit, alpha_dev, bias64);
   }
   CCZ_LAUNCH_CHECK();
 }

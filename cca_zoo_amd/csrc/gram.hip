@@ -35,16 +35,6 @@
 
 namespace ccz {
 
-struct GramTile {
-  const void* a;
-  const void* b;
-  int64_t lda, ldb;
-  int64_t out_row, out_col;
-  int32_t wa, wb;
-  int32_t diag;
-  int32_t pad_;
-};
-
 typedef float v16f32 __attribute__((ext_vector_type(16)));
 typedef float v4f32 __attribute__((ext_vector_type(4)));
 typedef double v4f64 __attribute__((ext_vector_type(4)));
@@ -800,6 +790,62 @@ __global__ __launch_bounds__(256) void k_colsum(const T* __restrict__ X, int64_t
   if (SQ) unsafeAtomicAdd(out_sq + col, q0 + q1);
 }
 
+// ---------------------------------------------------------------------------
+// Loss fast path (loss.hip): exact fp64 column sums of ALL views and the fp32 pilot (column mean) in ONE launch, no
+// atomics on data, nothing to clear beforehand.  grid = (column blocks of 256 over the stacked width, row blocks); a
+// block writes its partial sums to part[row block][D]; the LAST row block of a column block to arrive (one counter per
+// column block, left at zero again) adds the row blocks up in a fixed order -- the sums do not depend on the arrival
+// order -- and writes sums[j] and pilot[j] = fl32(sums[j] / n).
+// ---------------------------------------------------------------------------
+struct ColsumViews {
+  const float* data[8];
+  int64_t ld[8];
+  int off[9];
+  int m;
+};
+
+__global__ __launch_bounds__(256) void k_colsum_pilot(ColsumViews cv, int64_t n, int64_t D, int64_t rows_per_block, double* __restrict__ part,
+                                                      unsigned* __restrict__ counters, double* __restrict__ sums, float* __restrict__ pilot) {
+  __shared__ int last;
+  const int64_t j = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  const int64_t r0 = int64_t(blockIdx.y) * rows_per_block;
+  const int64_t r1 = min(n, r0 + rows_per_block);
+  if (j < D) {
+    int a = 0;
+    while (a + 1 < cv.m && j >= cv.off[a + 1]) ++a;
+    const float* X = cv.data[a] + (j - cv.off[a]);
+    const int64_t ld = cv.ld[a];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int64_t r = r0;
+    for (; r + 3 < r1; r += 4) {
+      a0 += double(X[(r + 0) * ld]); a1 += double(X[(r + 1) * ld]);
+      a2 += double(X[(r + 2) * ld]); a3 += double(X[(r + 3) * ld]);
+    }
+    for (; r < r1; ++r) a0 += double(X[r * ld]);
+    part[int64_t(blockIdx.y) * D + j] = (a0 + a1) + (a2 + a3);
+  }
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0)
+    last = __hip_atomic_fetch_add(counters + blockIdx.x, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.y - 1 ? 1 : 0;
+  __syncthreads();
+  if (!last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (threadIdx.x == 0) counters[blockIdx.x] = 0u;           // ready for the next launch
+  if (j >= D) return;
+  double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+  int rb = 0;
+  const int nrb = int(gridDim.y);
+  for (; rb + 3 < nrb; rb += 4) {
+    t0 += part[int64_t(rb) * D + j]; t1 += part[int64_t(rb + 1) * D + j];
+    t2 += part[int64_t(rb + 2) * D + j]; t3 += part[int64_t(rb + 3) * D + j];
+  }
+  for (; rb < nrb; ++rb) t0 += part[int64_t(rb) * D + j];
+  const double sj = (t0 + t1) + (t2 + t3);
+  sums[j] = sj;
+  pilot[j] = float(sj / double(n));
+}
+
 // pilot[j] = fl32(colsum[j] / n): the fp32 value closest to the mean of this launch's rows
 __global__ void k_pilot_from_sums(const double* __restrict__ s, int64_t D, double inv_n, float* __restrict__ pilot) {
   const int64_t j = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -847,11 +893,15 @@ struct Panel {
   int64_t col0, width, gcol0;
 };
 
-// pilot_mode (fp32 only): 0 = never, 1 = automatic (column sums and sums of squares are inspected on the host: one small
-// read-back), 2 = always (device-side only, no host synchronisation).  Returns whether the pilot path ran.
+// The tile table of a launch (device copy, cached) and what the kernels need to know about it.
+struct TileTable {
+  GramTile* dev = nullptr;
+  int ntiles = 0;
+  bool fast = true;      // every view: width a multiple of the tile, 16-byte aligned rows -> the buffer-descriptor kernels
+};
+
 template <typename T>
-bool launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, double* G, double* s, int64_t D,
-                    bool time_it, void** tile_cache = nullptr, int pilot_mode = 0) {
+TileTable build_tile_table(ccz_ctx* c, const ccz_view* views, int n_views, void** tile_cache) {
   Impl* im = impl(c);
   hipStream_t st = stream(c);
   constexpr bool is32 = sizeof(T) == 4;
@@ -987,6 +1037,27 @@ bool launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
     *tile_cache = d_tiles;
   }
 
+  TileTable tt;
+  tt.dev = d_tiles;
+  tt.ntiles = ntiles;
+  tt.fast = fast;
+  (void)tiles_from_handle_cache;          // handle-cached tables stay with the handle
+  return tt;
+}
+
+// Row-chunk length and grid of a launch over n rows (see the cost model inside).
+struct RowPlan {
+  int64_t rows_per_wg = 0, ksplit = 0, nblocks = 0;
+  int per_xcd = 0;
+  bool sliced = false;
+  bool fast = true;      // false: a view's rows do not fit the 32-bit buffer descriptor any more
+};
+
+template <typename T>
+RowPlan plan_rows(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, int ntiles, bool fast) {
+  Impl* im = impl(c);
+  constexpr bool is32 = sizeof(T) == 4;
+  static const int map_mode = [] { const char* e = getenv("CCZ_GRAM_MAP"); return e ? atoi(e) : 1; }();
   const int ncu = std::max(1, im->props.multiProcessorCount);
   static const int64_t rows_env = [] { const char* e = getenv("CCZ_GRAM_ROWS"); return e ? atoll(e) : 0LL; }();
   int64_t max_rows = rows_env > 0 ? rows_env : 16384;
@@ -1028,8 +1099,36 @@ bool launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
   const int per_xcd = xchunks ? -1 : (sliced ? (ntiles + 7) / 8 : 0);
   const int64_t nblocks = xchunks ? int64_t(ntiles) * ksplit : (sliced ? int64_t(8) * per_xcd * ksplit : int64_t(ntiles) * ksplit);
   if (nblocks > 0x7fffffffLL) fail(CCZ_EUNSUP, "gram: grid too large");
-  const size_t lds_bytes = size_t(2) * 2 * BK * tile * sizeof(T);  // 64 KiB either way
 
+  RowPlan rp;
+  rp.rows_per_wg = rows_per_wg;
+  rp.ksplit = ksplit;
+  rp.nblocks = nblocks;
+  rp.per_xcd = per_xcd;
+  rp.sliced = sliced;
+  rp.fast = fast;
+  return rp;
+}
+
+// pilot_mode (fp32 only): 0 = never, 1 = automatic (column sums and sums of squares are inspected on the host: one small
+// read-back), 2 = always (device-side only, no host synchronisation).  Returns whether the pilot path ran.
+template <typename T>
+bool launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, double* G, double* s, int64_t D,
+                    bool time_it, void** tile_cache = nullptr, int pilot_mode = 0) {
+  Impl* im = impl(c);
+  hipStream_t st = stream(c);
+  constexpr bool is32 = sizeof(T) == 4;
+  const int tile = is32 ? T32 : T64;
+  const TileTable tt = build_tile_table<T>(c, views, n_views, tile_cache);
+  GramTile* d_tiles = tt.dev;
+  const int ntiles = tt.ntiles;
+  const RowPlan rp = plan_rows<T>(c, views, n_views, n, ntiles, tt.fast);
+  const bool fast = rp.fast;
+  const int64_t rows_per_wg = rp.rows_per_wg, ksplit = rp.ksplit, nblocks = rp.nblocks;
+  const int per_xcd = rp.per_xcd;
+  const bool sliced = rp.sliced;
+  const int ncu = std::max(1, im->props.multiProcessorCount);
+  const size_t lds_bytes = size_t(2) * 2 * BK * tile * sizeof(T);  // 64 KiB either way
   // ---- column sums first: they are the means, and for fp32 views they decide (and define) the pilot shift ----
   // (Round 3 tried to hide this 5.4 ms HBM-bound pass under the MFMA-bound K1 on a second stream, with the pilot decided
   // from a strided sample: K1 then ran 7 ms LONGER -- the column-sum workgroups share the CUs' issue slots with K1's one
@@ -1163,7 +1262,6 @@ bool launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
   // allocation that reuses a block can only touch it after the kernels enqueued above
   if (pilot) dev_free(c, pilot);
   if (s_launch != s) dev_free(c, s_launch);
-  (void)tiles_from_handle_cache;          // handle-cached tables stay with the handle
   return use_pilot;
 }
 
@@ -1217,6 +1315,73 @@ void pack_rows(char* dst, const ccz_view* views, int n_views, size_t es, int64_t
 }
 
 }  // namespace
+
+// Loss fast path: the pilot-shifted batch Gram of a DCCA batch as per-(row chunk, tile) fp32 partial sums + the exact column
+// sums, in TWO launches (k_colsum_pilot, k_gram_f32 on the views where they lie: no gathered copy, no atomics, no fills,
+// no read-back).  The consumer (loss.hip: k_loss_prep_partials) adds the chunks up in fp64 and undoes the shift.
+// Returns false -- nothing enqueued -- when the shape does not suit (a grid that fills the chip several times, or partial
+// sums beyond the cap): the caller takes the general route through ccz_moments.
+bool gram_partials_f32(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, GramPartials* out) {
+  Impl* im = impl(c);
+  hipStream_t st = stream(c);
+  if (n_views < 1 || n_views > 8 || n < 2) return false;
+  int64_t D = 0;
+  for (int v = 0; v < n_views; ++v) D += views[v].cols;
+  const TileTable tt = build_tile_table<float>(c, views, n_views, nullptr);
+  const RowPlan rp = plan_rows<float>(c, views, n_views, n, tt.ntiles, tt.fast);
+  static const int64_t partial_cap = [] { const char* e = getenv("CCZ_GRAM_PARTIAL_MB"); return (e ? atoll(e) : 192LL) << 20; }();
+  const int64_t bytes = rp.ksplit * int64_t(tt.ntiles) * T32 * T32 * 4;
+  if (rp.sliced || bytes > partial_cap) return false;
+  const int ncu = std::max(1, im->props.multiProcessorCount);
+  // column sums + pilot
+  const int64_t colblocks = (D + 255) / 256;
+  if (colblocks > 64) return false;
+  int64_t rpb = 2048;
+  while (rpb > 32 && colblocks * ((n + rpb - 1) / rpb) < int64_t(ncu)) rpb /= 2;
+  const int64_t rowblocks = (n + rpb - 1) / rpb;
+  if (!im->colsum_counters) {
+    CCZ_HIP(hipMalloc(reinterpret_cast<void**>(&im->colsum_counters), 64 * sizeof(unsigned)));
+    CCZ_HIP(hipMemsetAsync(im->colsum_counters, 0, 64 * sizeof(unsigned), st));
+  }
+  out->colsum = static_cast<double*>(dev_alloc(c, size_t(D) * 8));
+  out->pilot = static_cast<float*>(dev_alloc(c, size_t(D) * 4));
+  out->partial = static_cast<float*>(dev_alloc(c, size_t(bytes)));
+  double* part = static_cast<double*>(dev_alloc(c, size_t(rowblocks) * D * 8));
+  ColsumViews cv{};
+  cv.m = n_views;
+  cv.off[0] = 0;
+  for (int v = 0; v < n_views; ++v) {
+    cv.data[v] = static_cast<const float*>(views[v].data);
+    cv.ld[v] = views[v].ld;
+    cv.off[v + 1] = cv.off[v] + int(views[v].cols);
+  }
+  hipLaunchKernelGGL(k_colsum_pilot, dim3((unsigned)colblocks, (unsigned)rowblocks), dim3(256), 0, st, cv, n, D, rpb, part, im->colsum_counters,
+                     out->colsum, out->pilot);
+  const size_t lds_bytes = size_t(2) * 2 * BK * T32 * sizeof(float);
+  if (rp.fast) {
+    CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_f32<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
+    hipLaunchKernelGGL(k_gram_f32<true>, dim3((unsigned)rp.nblocks), dim3(256), lds_bytes, st, tt.dev, tt.ntiles, rp.per_xcd, rp.ksplit, n, rp.rows_per_wg,
+                       static_cast<double*>(nullptr), D, out->pilot, out->partial, int64_t(0));
+  } else {
+    CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_f32<false>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
+    hipLaunchKernelGGL(k_gram_f32<false>, dim3((unsigned)rp.nblocks), dim3(256), lds_bytes, st, tt.dev, tt.ntiles, rp.per_xcd, rp.ksplit, n, rp.rows_per_wg,
+                       static_cast<double*>(nullptr), D, out->pilot, out->partial, int64_t(0));
+  }
+  CCZ_LAUNCH_CHECK();
+  dev_free(c, part);                    // stream-ordered pool: reused only behind the kernels above
+  out->tiles = tt.dev;
+  out->ntiles = tt.ntiles;
+  out->ksplit = rp.ksplit;
+  c->last_pilot = 1;
+  return true;
+}
+
+void gram_partials_release(ccz_ctx* c, GramPartials* gp) {
+  if (gp->partial) dev_free(c, gp->partial);
+  if (gp->pilot) dev_free(c, gp->pilot);
+  if (gp->colsum) dev_free(c, gp->colsum);
+  gp->partial = nullptr; gp->pilot = nullptr; gp->colsum = nullptr;
+}
 
 void moments_impl(ccz_ctx* c, int dtype, const ccz_view* views, int n_views, int64_t n_rows, bool on_device,
                   double* moments, bool accumulate, int pilot_mode, bool time_it) {

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <utility>
 #include <vector>
 
 #include "ops.h"
@@ -68,6 +69,11 @@ struct Impl {
                                     // handle's own event behind an unpack on a foreign stream)
   hipEvent_t defer_own_ev = nullptr;
   bool adopted = false;             // c->stream is a caller's stream (ccz_stream_adopt) until the next acquire
+  // cholinv.hip: per-stream sync blocks of the persistent chain kernel (stream, device block); chain_cap > 0 limits its
+  // workgroups (set by callers that run throughput work on another stream next to the chain)
+  std::vector<std::pair<void*, void*>> chain_sync;
+  int chain_cap = 0;
+  unsigned* colsum_counters = nullptr;   // gram.hip: arrival counters of k_colsum_pilot (64 words, zero between launches)
   // comm.hip: the RCCL communicator of this handle's device (ncclComm_t), its size and this handle's rank
   void* comm = nullptr;
   int comm_world = 0, comm_rank = -1;
@@ -94,6 +100,31 @@ void sync_short(ccz_ctx* c);   // polled wait for the handle's stream (short wai
 // evd_block.hip: one-sided block Jacobi on the rows of W (p a multiple of 64, even leading dimensions)
 int jacobi_rows_block(ccz_ctx* c, int64_t p, int64_t q, double* W, int64_t ldw, double* Q, int64_t qc, int64_t ldq, int max_sweeps);
 
+// gram.hip: one entry of a launch's tile table -- the two column panels (of one or two views) whose product is one
+// 256 x 256 (fp32) / 128 x 128 (fp64) tile of the stacked Gram matrix
+struct GramTile {
+  const void* a;
+  const void* b;
+  int64_t lda, ldb;
+  int64_t out_row, out_col;
+  int32_t wa, wb;
+  int32_t diag;
+  int32_t pad_;
+};
+
+// gram.hip, loss fast path: per-(row chunk, tile) fp32 partial sums of the pilot-shifted batch Gram (partial[(chunk * ntiles +
+// tile) * 65536 + 256 i + j]), the exact fp64 column sums and the fp32 pilot they were shifted by -- all pooled scratch
+struct GramPartials {
+  const GramTile* tiles = nullptr;
+  int ntiles = 0;
+  int64_t ksplit = 0;
+  float* partial = nullptr;
+  float* pilot = nullptr;
+  double* colsum = nullptr;
+};
+bool gram_partials_f32(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, GramPartials* out);
+void gram_partials_release(ccz_ctx* c, GramPartials* gp);
+
 // gram.hip
 // pilot_mode: 0 never / 1 automatic (one small host read-back) / 2 always (no host sync) -- fp32 views only;
 // time_it: record HIP events around the Gram and column-sum kernels (costs a host wait at the end)
@@ -119,6 +150,14 @@ bool gemm_f32_fifo_split_eligible(int64_t M, int64_t N, int64_t K, int64_t nspli
                                   int64_t ldc2);
 void gemm_f32_fifo_split(ccz_ctx* c, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda, const float* B32,
                          const float* bias32, float* C1, int64_t ldc1, float* C2, int64_t ldc2, int64_t nsplit);
+
+// the same with the A operand as two column ranges [A1 | A2] (two views where they lie), a device-side factor on alpha and
+// a float64 centring row: the lazy backward of the two-view DCCA loss
+bool gemm_f32_fifo_pair_eligible(int64_t M, int64_t N, int64_t K, int64_t K1, int64_t nsplit, const void* A1, int64_t lda1, const void* A2,
+                                 int64_t lda2, const void* C1, int64_t ldc1, const void* C2, int64_t ldc2);
+void gemm_f32_fifo_pair(ccz_ctx* c, int64_t M, int64_t N, int64_t K, int64_t K1, float alpha, const float* alpha_dev, const float* A1,
+                        int64_t lda1, const float* A2, int64_t lda2, const float* B32, const double* bias64, float* C1, int64_t ldc1,
+                        float* C2, int64_t ldc2, int64_t nsplit);
 
 // gemm64_big.hip: 128x128-tile fp64 GEMM (solver stage)
 bool gemm_f64_big_eligible(bool tA, bool tB, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
@@ -150,6 +189,11 @@ struct MultiGemmArgs {
   double alpha, beta;
   bool k_lower = false;    // op(A) = X', op(B) = X, X lower triangular (blocks above the diagonal are never read)
   int ksplit = 1;          // > 1: K cut into slices over extra workgroups, C += alpha * product atomically (beta must be 1)
+  // optional rider: *dot_acc += dot_scale * sum_ij (alpha op(A) op(B))_ij dotB_ij (one accumulator per launch)
+  const double* dotB = nullptr;
+  int64_t lddot = 0;
+  double dot_scale = 0.0;
+  double* dot_acc = nullptr;
 };
 void gemm_f64_multi(ccz_ctx* c, int count, const MultiGemmArgs* problems);
 

@@ -70,6 +70,54 @@ __global__ void k_loss_prep(const double* __restrict__ G, const double* __restri
   }
 }
 
+// The same preparation straight from K1's per-(row chunk, tile) fp32 partial sums (gram.hip: gram_partials_f32) -- the
+// loss fast path never forms the moments [G | s]: the chunks are added up in fp64, the pilot shift is undone in the
+// centred form
+//   sum_r (x_ri - m_i)(x_rj - m_j) = sum_r (x_ri - p_i)(x_rj - p_j) - n (m_i - p_i)(m_j - p_j)       (m = s / n)
+// and Ce, the views' diagonal blocks, the mean, the cleared split-K destinations and accumulators all leave this ONE
+// launch (it replaces k_gram_reduce, k_pilot_fixup, k_vec_add, two fills and k_loss_prep).  grid (256, ntiles) x 256:
+// one thread per element of a 256 x 256 tile; tiles cover the upper triangle, every value is written to (i, j) and (j, i).
+__global__ __launch_bounds__(256) void k_loss_prep_partials(const float* __restrict__ partial, const GramTile* __restrict__ tiles, int ntiles,
+                                                            int64_t ksplit, const double* __restrict__ s, const float* __restrict__ pilot,
+                                                            int64_t D, double n_rows, double inv_nm1, double eps, double* __restrict__ Ce,
+                                                            double* __restrict__ mean, PrepArgs pa, double* __restrict__ acc,
+                                                            double* __restrict__ bias) {
+  const int tile = blockIdx.y;
+  const int e = blockIdx.x * 256 + threadIdx.x;            // element of the 256 x 256 tile
+  if (tile == 0) {
+    if (e < D) {
+      mean[e] = s[e] / n_rows;
+      if (bias) bias[e] = 0.0;
+    }
+    if (e == 0) acc[0] = 0.0;
+  }
+  const GramTile t = tiles[tile];
+  const int i = e >> 8, j = e & 255;
+  if (i >= t.wa || j >= t.wb) return;
+  if (t.diag && j < i) return;                             // diagonal tiles hold both halves: the upper one is used
+  double g = 0.0;
+  const float* p = partial + int64_t(tile) * 65536 + e;
+  for (int64_t ch = 0; ch < ksplit; ++ch) g += double(p[ch * int64_t(ntiles) * 65536]);
+  const int64_t gi = t.out_row + i, gj = t.out_col + j;
+  const double di = s[gi] / n_rows - double(pilot[gi]), dj = s[gj] / n_rows - double(pilot[gj]);
+  double v = (g - n_rows * di * dj) * inv_nm1;
+  if (gi == gj) v += eps;
+  const int64_t e1 = gi * D + gj, e2 = gj * D + gi;
+  Ce[e1] = v;
+  Ce[e2] = v;
+  if (pa.zero_a) { pa.zero_a[e1] = 0.0; pa.zero_a[e2] = 0.0; }
+  if (pa.zero_b) { pa.zero_b[e1] = 0.0; pa.zero_b[e2] = 0.0; }
+  int a = 0;
+  while (a + 1 < pa.m && gi >= pa.off[a + 1]) ++a;
+  if (gj < pa.off[a + 1]) {                                // gi <= gj: same view block
+    const int64_t da = pa.off[a + 1] - pa.off[a];
+    const int64_t q1 = (gi - pa.off[a]) * da + (gj - pa.off[a]), q2 = (gj - pa.off[a]) * da + (gi - pa.off[a]);
+    pa.work[a][q1] = v;
+    pa.work[a][q2] = v;
+    if (pa.zero_v[a]) { pa.zero_v[a][q1] = 0.0; pa.zero_v[a][q2] = 0.0; }
+  }
+}
+
 // acc += sum over (i, j) in DIFFERENT view blocks of A_ij A_ji  = 2 sum_{a<b} tr(A_ab A_ba)
 // (the diagonal blocks of A are the identity up to cond * eps rounding: leaving them out keeps that noise out of the loss)
 __global__ void k_trace_sq(const double* __restrict__ A, int64_t D, PrepArgs pa, double* __restrict__ acc) {
@@ -106,23 +154,42 @@ __global__ void k_loss_finish(const double* __restrict__ acc, int dtype, void* _
   if (out64) *out64 = l;
 }
 
-// bias[j] += sum over a 64-row slab of mean_i Gamma_ij  (bias zeroed by k_loss_prep); grid (D / 64, D / 64)
-__global__ __launch_bounds__(256) void k_bias_row(const double* __restrict__ Gm, const double* __restrict__ mean, int64_t D,
-                                                  double* __restrict__ bias) {
+// Everything between the last product stage and the sample-side GEMM in ONE launch (rounds 2-4: k_bias_row, k_cvt_f32 and
+// k_loss_finish): bias[j] += sum over a 64-row slab of mean_i Gamma_ij (bias zeroed by the prep kernel), Gamma -> fp32
+// (G32 != null), and -- workgroup (0, 0) -- the loss value -1/2 acc with the pivot check of k_loss_finish.
+// grid (D / 64, D / 64) x 256.
+__global__ __launch_bounds__(256) void k_loss_tail(const double* __restrict__ Gm, const double* __restrict__ mean, int64_t D,
+                                                   double* __restrict__ bias, float* __restrict__ G32, const double* __restrict__ acc, int dtype,
+                                                   void* __restrict__ out, const int* __restrict__ info, int m, int* __restrict__ status) {
   __shared__ double red[4][64];
   const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int64_t j = int64_t(blockIdx.x) * 64 + c, i0 = int64_t(blockIdx.y) * 64;
   double a = 0.0;
   if (j < D)
-    for (int64_t i = i0 + rg; i < min(D, i0 + 64); i += 4) a += mean[i] * Gm[i * D + j];
+    for (int64_t i = i0 + rg; i < min(D, i0 + 64); i += 4) {
+      const double g = Gm[i * D + j];
+      a += mean[i] * g;
+      if (G32) G32[i * D + j] = float(g);
+    }
   red[rg][c] = a;
   __syncthreads();
   if (rg == 0 && j < D) unsafeAtomicAdd(bias + j, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    double l = -0.5 * acc[0];
+    for (int v = 0; v < m; ++v)
+      if (info[v] != 0x7fffffff) {
+        l = __builtin_nan("");
+        if (status && status[0] == 0) { status[1] = info[v] - 1; __threadfence_system(); status[0] = v + 1; }
+        break;
+      }
+    if (dtype == CCZ_F32) *static_cast<float*>(out) = float(l); else *static_cast<double*>(out) = l;
+  }
 }
 
-// fp64 -> fp32, elementwise (Gamma and, appended as one more row, the bias mean' Gamma)
-__global__ void k_cvt_f32(const double* __restrict__ in, int64_t total, float* __restrict__ out) {
-  for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += int64_t(gridDim.x) * blockDim.x) out[e] = float(in[e]);
+// dst = (*scale) * src, elementwise; scale: one element of `dtype` on the device (the upstream gradient of the loss)
+__global__ void k_scale_by_dev(const double* __restrict__ src, int64_t total, int dtype, const void* __restrict__ scale, double* __restrict__ dst) {
+  const double f = dtype == CCZ_F32 ? double(*static_cast<const float*>(scale)) : *static_cast<const double*>(scale);
+  for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += int64_t(gridDim.x) * blockDim.x) dst[e] = f * src[e];
 }
 
 __global__ void k_neg_sum(const double* __restrict__ v, int64_t n, int dtype, void* __restrict__ out) {
@@ -157,7 +224,11 @@ bool narrow_ok(const int64_t* dims, int m) {
 // device).  Wide views: the super-blocked factorization reads its pivot flags on the host and throws CCZ_ENOTSPD
 // itself; info_dev is then set to "succeeded" for the caller's device-side check.
 void pair_core(ccz_ctx* c, const double* mom, int64_t n, const int64_t* dims, int m, double eps, bool want_grad,
-               double* acc_dev, double* gamma_dev, double* mean_dev, int* info_dev, double* bias_dev = nullptr) {
+               double* acc_dev, double* gamma_dev, double* mean_dev, int* info_dev, double* bias_dev = nullptr,
+               const GramPartials* gp = nullptr, bool ride_loss = false) {
+  // gp != null (mom unused): Ce comes straight from K1's partial sums (k_loss_prep_partials).
+  // ride_loss (with want_grad): the loss accumulator is filled by the Gamma_ab stage (tr(A_ab A_ba) = sum_ij M_ab_ij Ce_ab_ij,
+  // M_ab = -(n-1)/2 Gamma_ab) instead of a pass of its own over A.
   if (m < 2 || m > LMAXV) fail(CCZ_EUNSUP, "pairwise CCA loss: 2 .. %d views are supported, got %d", LMAXV, m);
   hipStream_t st = stream(c);
   std::vector<int64_t> off(m + 1, 0);
@@ -186,8 +257,12 @@ void pair_core(ccz_ctx* c, const double* mom, int64_t n, const int64_t* dims, in
     pa.zero_a = Am.get();
     pa.zero_b = want_grad ? gamma_dev : nullptr;
   }
-  hipLaunchKernelGGL(k_loss_prep, dim3((unsigned)std::min<int64_t>((D * D + 255) / 256, 4096)), dim3(256), 0, st, mom, mom + D * D, D,
-                     1.0 / double(n), inv, eps, Ce.get(), mean_dev, pa, acc_dev, want_grad ? bias_dev : nullptr);
+  if (gp)
+    hipLaunchKernelGGL(k_loss_prep_partials, dim3(256, (unsigned)gp->ntiles), dim3(256), 0, st, gp->partial, gp->tiles, gp->ntiles, gp->ksplit,
+                       gp->colsum, gp->pilot, D, double(n), inv, eps, Ce.get(), mean_dev, pa, acc_dev, want_grad ? bias_dev : nullptr);
+  else
+    hipLaunchKernelGGL(k_loss_prep, dim3((unsigned)std::min<int64_t>((D * D + 255) / 256, 4096)), dim3(256), 0, st, mom, mom + D * D, D,
+                       1.0 / double(n), inv, eps, Ce.get(), mean_dev, pa, acc_dev, want_grad ? bias_dev : nullptr);
   CCZ_LAUNCH_CHECK();
   if (narrow) {
     std::vector<double*> Ap(m), Lp(m), Xp(m), Tp(m);
@@ -243,16 +318,28 @@ void pair_core(ccz_ctx* c, const double* mom, int64_t n, const int64_t* dims, in
         pr.push_back(MultiGemmArgs{Sinv[a], Ce.get() + off[a] * D + off[b], Am.get() + off[a] * D + off[b], nullptr, dims[a], D, D, 0,
                                    dims[a], dims[b], dims[a], false, false, false, 1.0, 0.0});
   launch(pr);
-  hipLaunchKernelGGL(k_trace_sq, dim3((unsigned)std::min<int64_t>((D * D + 255) / 256, 1024)), dim3(256), 0, st, Am.get(), D, pa, acc_dev);
-  CCZ_LAUNCH_CHECK();
+  const bool ride = ride_loss && want_grad && narrow;
+  if (!ride) {
+    hipLaunchKernelGGL(k_trace_sq, dim3((unsigned)std::min<int64_t>((D * D + 255) / 256, 1024)), dim3(256), 0, st, Am.get(), D, pa, acc_dev);
+    CCZ_LAUNCH_CHECK();
+  }
   if (!want_grad) return;
-  // Gamma_ab = -2/(n-1) A_ab Sinv_b   (a != b)
+  // Gamma_ab = -2/(n-1) A_ab Sinv_b   (a != b); with `ride` every tile also adds its share of
+  // sum_ij M_ab_ij Ce_ab_ij = tr(A_ab A_ba) to the loss accumulator (M_ab = -(n-1)/2 Gamma_ab)
   pr.clear();
   for (int a = 0; a < m; ++a)
     for (int b = 0; b < m; ++b)
-      if (a != b)
+      if (a != b) {
         pr.push_back(MultiGemmArgs{Am.get() + off[a] * D + off[b], Sinv[b], gamma_dev + off[a] * D + off[b], nullptr, D, dims[b], D, 0,
                                    dims[a], dims[b], dims[b], false, false, false, -2.0 * inv, 0.0});
+        if (ride) {
+          MultiGemmArgs& g = pr.back();
+          g.dotB = Ce.get() + off[a] * D + off[b];
+          g.lddot = D;
+          g.dot_scale = -0.5 * double(n - 1);
+          g.dot_acc = acc_dev;
+        }
+      }
   launch(pr);
   // Gamma_aa = -sum_{b != a} A_ab Gamma_ba : one launch per offset s (b = a + s mod m), so that no two problems of a
   // launch write the same block; the first one overwrites, the others accumulate
@@ -265,9 +352,7 @@ void pair_core(ccz_ctx* c, const double* mom, int64_t n, const int64_t* dims, in
     }
     launch(pr);
   }
-  if (bias_dev)
-    hipLaunchKernelGGL(k_bias_row, dim3((unsigned)((D + 63) / 64), (unsigned)((D + 63) / 64)), dim3(256), 0, st, gamma_dev, mean_dev, D, bias_dev);
-  CCZ_LAUNCH_CHECK();
+  // (the centring row mean' Gamma: k_loss_tail, or k_bias_row for the callers that keep their own tail)
 }
 
 void check_info(ccz_ctx* c, const int* info_dev, int m, const char* what) {
@@ -323,76 +408,154 @@ static int* loss_status_dev(ccz_ctx* c) {
   return im->loss_status_dev;
 }
 
-// Sum over all pairs a < b of the CCA loss of views a and b of ONE batch, and its gradient with respect to every view:
-// K1 on [z_1 .. z_m] -> pair_core -> loss -> sample-side products.  m = 2 is CCALoss (deep/objectives.py:61-102),
-// m > 2 MCCALoss (:138-153).  Everything is enqueued on the handle's stream; on the narrow path the host never waits.
-void pair_loss_impl(ccz_ctx* c, int dtype, const ccz_view* z, int m, int64_t n, double eps, void* loss_dev, void* const* g,
-                    const int64_t* ldg) {
-  if (dtype != CCZ_F32 && dtype != CCZ_F64) fail(CCZ_EUNSUP, "cca_loss: dtype must be CCZ_F32 or CCZ_F64");
-  if (!z || !loss_dev) fail(CCZ_EINVAL, "cca_loss: null argument");
-  if (m < 2 || m > LMAXV) fail(CCZ_EUNSUP, "cca_loss: 2 .. %d views are supported, got %d", LMAXV, m);
-  if (n < 2) fail(CCZ_EINVAL, "cca_loss: bad shape (at least 2 rows are required)");
-  int64_t dims[LMAXV], off[LMAXV + 1];
-  off[0] = 0;
-  bool want = false, all = g != nullptr;
+// ---------------------------------------------------------------------------------------------------------------------
+// The pairwise loss in two phases (ccz_pair_loss_forward / ccz_pair_loss_backward; ccz_pair_loss = both with a unit
+// upstream gradient).  m = 2 is CCALoss (deep/objectives.py:61-102), m > 2 MCCALoss (:138-153).
+//
+// forward:  K1 on [z_1 .. z_m] -> pair_core -> loss on the device; with `state`: Gamma (D x D, fp64), the centring row
+//           mean' Gamma (row D of the same buffer) and, for fp32 views, Gamma rounded to fp32 behind it.
+// backward: dz_a = (*grad_out) sum_b (z_b - mean_b) Gamma_ba from the SAME views -- for two aligned fp32 views ONE product
+//           on the fp32 MFMA pipe that reads the views where they lie (gemm_f32_fifo_pair), else one gemm_mixed per block.
+// Why two phases: an autograd caller only learns the upstream gradient in its backward; with the gradient formed in the
+// forward it had to multiply both n x d gradients by it afterwards (two more passes over them per step).
+//
+// Launches of a fp32 DCCA batch (the fast path; rounds 2-4 took 32 dispatches for the same work):
+//   k_colsum_pilot, k_gram_f32 (partial sums), k_loss_prep_partials, k_cholinv_chain, 4 x k_gemm_f64_multi (the loss value
+//   rides on the third), k_loss_tail | k_gemm_f32_nn_fifo2.
+// Everything is enqueued on the handle's stream; on the narrow path the host never waits.
+// ---------------------------------------------------------------------------------------------------------------------
+struct LossShape {
+  int64_t dims[LMAXV], off[LMAXV + 1], D;
+};
+
+static LossShape loss_shape(const ccz_view* z, int m, int64_t n, int dtype, const char* what) {
+  if (dtype != CCZ_F32 && dtype != CCZ_F64) fail(CCZ_EUNSUP, "%s: dtype must be CCZ_F32 or CCZ_F64", what);
+  if (!z) fail(CCZ_EINVAL, "%s: null argument", what);
+  if (m < 2 || m > LMAXV) fail(CCZ_EUNSUP, "%s: 2 .. %d views are supported, got %d", what, LMAXV, m);
+  if (n < 2) fail(CCZ_EINVAL, "%s: bad shape (at least 2 rows are required)", what);
+  LossShape sh{};
   for (int a = 0; a < m; ++a) {
-    if (!z[a].data || z[a].cols < 1 || z[a].ld < z[a].cols) fail(CCZ_EINVAL, "cca_loss: bad shape (view %d)", a);
-    dims[a] = z[a].cols;
-    off[a + 1] = off[a] + dims[a];
-    if (g && g[a]) {
-      if (!ldg || ldg[a] < dims[a]) fail(CCZ_EINVAL, "cca_loss: bad gradient stride (view %d)", a);
-      want = true;
+    if (!z[a].data || z[a].cols < 1 || z[a].ld < z[a].cols) fail(CCZ_EINVAL, "%s: bad shape (view %d)", what, a);
+    sh.dims[a] = z[a].cols;
+    sh.off[a + 1] = sh.off[a] + sh.dims[a];
+  }
+  sh.D = sh.off[m];
+  return sh;
+}
+
+// state: [Gamma fp64 (D x D) | centring row (D) | Gamma fp32 (D x D)]
+int64_t pair_loss_state_bytes_impl(int dtype, const int64_t* dims, int m) {
+  if (!dims || m < 2 || m > LMAXV) return -1;
+  int64_t D = 0;
+  for (int a = 0; a < m; ++a) {
+    if (dims[a] < 1) return -1;
+    D += dims[a];
+  }
+  (void)dtype;
+  return (D + 1) * D * 8 + D * D * 4;
+}
+
+void pair_loss_forward_impl(ccz_ctx* c, int dtype, const ccz_view* z, int m, int64_t n, double eps, void* loss_dev, void* state) {
+  const LossShape sh = loss_shape(z, m, n, dtype, "cca_loss");
+  if (!loss_dev) fail(CCZ_EINVAL, "cca_loss: null argument");
+  const int64_t D = sh.D;
+  hipStream_t st = stream(c);
+  const bool narrow = narrow_ok(sh.dims, m);
+  const bool want = state != nullptr;
+  double* gamma = static_cast<double*>(state);
+  double* bias = want ? gamma + D * D : nullptr;
+  float* g32 = (want && dtype == CCZ_F32) ? reinterpret_cast<float*>(gamma + (D + 1) * D) : nullptr;
+  DBuf mean(c, D), acc(c, 1);
+  PoolPtr info(c, LMAXV * sizeof(int));
+  // fp32 DCCA batch: K1's partial sums feed the preparation directly (no moments, no gather, no fills, no atomics).
+  // Embeddings (post-ReLU, un-normalised) routinely sit far from zero, so the Gram is always pilot-shifted here.
+  static const int fast_env = [] { const char* e = getenv("CCZ_LOSS_FAST"); return e ? atoi(e) : 1; }();
+  GramPartials gp;
+  bool fast = false;
+  if (fast_env && narrow && dtype == CCZ_F32) fast = gram_partials_f32(c, z, m, n, &gp);
+  struct Release {
+    ccz_ctx* c; GramPartials* gp; bool on;
+    ~Release() { if (on) gram_partials_release(c, gp); }
+  } rel{c, &gp, fast};
+  if (fast) {
+    pair_core(c, nullptr, n, sh.dims, m, eps, want, acc, gamma, mean, info.as<int>(), bias, &gp, true);
+  } else {
+    // general route: the moments [G | s] through ccz_moments' machinery.  Wide views (n ~ 1e6 rows x 8192): the automatic
+    // pilot choice (one 2 D-double read-back) keeps centred data on the faster FIFO kernel.
+    DBuf mom(c, D * D + D);
+    moments_impl(c, dtype, z, m, n, true, mom, false, dtype == CCZ_F32 ? (narrow ? 2 : 1) : 0, false);
+    pair_core(c, mom, n, sh.dims, m, eps, want, acc, gamma, mean, info.as<int>(), bias, nullptr, narrow);
+  }
+  if (want) {
+    hipLaunchKernelGGL(k_loss_tail, dim3((unsigned)((D + 63) / 64), (unsigned)((D + 63) / 64)), dim3(256), 0, st, gamma, mean.get(), D, bias, g32,
+                       acc.get(), dtype, loss_dev, info.as<int>(), m, loss_status_dev(c));
+  } else {
+    hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(1), 0, st, acc.get(), dtype, loss_dev, static_cast<double*>(nullptr), info.as<int>(), m,
+                       loss_status_dev(c));
+  }
+  CCZ_LAUNCH_CHECK();
+}
+
+void pair_loss_backward_impl(ccz_ctx* c, int dtype, const ccz_view* z, int m, int64_t n, const void* state, const void* grad_out,
+                             void* const* g, const int64_t* ldg) {
+  const LossShape sh = loss_shape(z, m, n, dtype, "cca_loss backward");
+  if (!state || !g || !ldg) fail(CCZ_EINVAL, "cca_loss backward: null argument");
+  const int64_t D = sh.D;
+  bool any = false, all = true;
+  for (int a = 0; a < m; ++a) {
+    if (g[a]) {
+      if (ldg[a] < sh.dims[a]) fail(CCZ_EINVAL, "cca_loss: bad gradient stride (view %d)", a);
+      any = true;
     } else {
       all = false;
     }
   }
-  const int64_t D = off[m];
+  if (!any) return;
   hipStream_t st = stream(c);
-  const bool narrow = narrow_ok(dims, m);
-
-  // two fp32 views whose widths suit the 256-column tiles of the FIFO GEMM are gathered into one n x D matrix: the
-  // gradient is then ONE product (Z - mean) Gamma whose column ranges land in g1 / g2
-  const size_t es = dtype == CCZ_F32 ? 4 : 8;
-  const bool fifo = m == 2 && narrow && dtype == CCZ_F32 && all &&
-                    gemm_f32_fifo_split_eligible(n, D, D, dims[0], g[0], ldg[0], g[1], ldg[1]);
-  PoolPtr zcat(c, fifo ? size_t(n) * D * es : 0);
-  ccz_view gathered{zcat.p, D, D};
-  if (fifo) {
-    for (int a = 0; a < 2; ++a)
-      CCZ_HIP(hipMemcpy2DAsync(zcat.as<char>() + size_t(off[a]) * es, size_t(D) * es, z[a].data, size_t(z[a].ld) * es, size_t(dims[a]) * es,
-                               size_t(n), hipMemcpyDeviceToDevice, st));
-  }
-  // Gamma and, as row D of the same buffer, the bias row mean' Gamma (the centring of the batch)
-  DBuf mom(c, D * D + D), gamma(c, want ? (D + 1) * D : 0), mean(c, D), acc(c, 1);
-  PoolPtr info(c, LMAXV * sizeof(int));
-  // narrow (a DCCA batch): embeddings (post-ReLU, un-normalised) routinely sit far from zero -- always take the
-  // pilot-shifted Gram for fp32: no host read-back, and at batch sizes the staged kernel costs the same as the FIFO
-  // one.  Wide (n ~ 1e6 rows x 8192): the automatic choice (one 2 D-double read-back) keeps centred data on the
-  // faster FIFO kernel.
-  moments_impl(c, dtype, fifo ? &gathered : z, fifo ? 1 : m, n, true, mom, false, dtype == CCZ_F32 ? (narrow ? 2 : 1) : 0, false);
-  pair_core(c, mom, n, dims, m, eps, want, acc, gamma, mean, info.as<int>(), want ? gamma.get() + D * D : nullptr);
-  hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(1), 0, st, acc.get(), dtype, loss_dev, static_cast<double*>(nullptr), info.as<int>(), m,
-                     loss_status_dev(c));
-  CCZ_LAUNCH_CHECK();
-  if (!want) return;
-  const double* bias = gamma.get() + D * D;
-  if (fifo) {
-    PoolPtr G32(c, size_t(D + 1) * D * 4);
-    hipLaunchKernelGGL(k_cvt_f32, dim3((unsigned)std::min<int64_t>(((D + 1) * D + 255) / 256, 2048)), dim3(256), 0, st, gamma.get(),
-                       (D + 1) * D, G32.as<float>());
-    CCZ_LAUNCH_CHECK();
-    gemm_f32_fifo_split(c, n, D, D, 1.0f, zcat.as<float>(), D, G32.as<float>(), G32.as<float>() + D * D, static_cast<float*>(g[0]), ldg[0],
-                        static_cast<float*>(g[1]), ldg[1], dims[0]);
+  const double* gamma = static_cast<const double*>(state);
+  const double* bias = gamma + D * D;
+  const float* g32 = reinterpret_cast<const float*>(gamma + (D + 1) * D);
+  if (dtype == CCZ_F32 && m == 2 && all && narrow_ok(sh.dims, m) &&
+      gemm_f32_fifo_pair_eligible(n, D, D, sh.dims[0], sh.dims[0], z[0].data, z[0].ld, z[1].data, z[1].ld, g[0], ldg[0], g[1], ldg[1])) {
+    gemm_f32_fifo_pair(c, n, D, D, sh.dims[0], 1.0f, static_cast<const float*>(grad_out), static_cast<const float*>(z[0].data), z[0].ld,
+                       static_cast<const float*>(z[1].data), z[1].ld, g32, bias, static_cast<float*>(g[0]), ldg[0], static_cast<float*>(g[1]),
+                       ldg[1], sh.dims[0]);
     return;
+  }
+  // general route: Gamma (and its centring row) scaled by the upstream gradient on the device, one product per block
+  DBuf scaled(c, grad_out ? (D + 1) * D : 0);
+  if (grad_out) {
+    hipLaunchKernelGGL(k_scale_by_dev, dim3((unsigned)std::min<int64_t>(((D + 1) * D + 255) / 256, 2048)), dim3(256), 0, st, gamma, (D + 1) * D,
+                       dtype, grad_out, scaled.get());
+    CCZ_LAUNCH_CHECK();
+    gamma = scaled.get();
+    bias = gamma + D * D;
   }
   // dz_a = sum_b (z_b - mean_b) Gamma_ba : the own block first (it carries the bias row of ALL blocks), then the others
   for (int a = 0; a < m; ++a) {
     if (!g[a]) continue;
-    gemm_mixed(c, dtype, n, dims[a], dims[a], 1.0, z[a].data, z[a].ld, gamma.get() + off[a] * D + off[a], D, 0.0, g[a], ldg[a], bias + off[a]);
+    gemm_mixed(c, dtype, n, sh.dims[a], sh.dims[a], 1.0, z[a].data, z[a].ld, gamma + sh.off[a] * D + sh.off[a], D, 0.0, g[a], ldg[a],
+               bias + sh.off[a]);
     for (int b = 0; b < m; ++b)
       if (b != a)
-        gemm_mixed(c, dtype, n, dims[a], dims[b], 1.0, z[b].data, z[b].ld, gamma.get() + off[b] * D + off[a], D, 1.0, g[a], ldg[a], nullptr);
+        gemm_mixed(c, dtype, n, sh.dims[a], sh.dims[b], 1.0, z[b].data, z[b].ld, gamma + sh.off[b] * D + sh.off[a], D, 1.0, g[a], ldg[a], nullptr);
   }
+}
+
+// one-shot form: forward + backward with a unit upstream gradient, the state in pooled scratch
+void pair_loss_impl(ccz_ctx* c, int dtype, const ccz_view* z, int m, int64_t n, double eps, void* loss_dev, void* const* g,
+                    const int64_t* ldg) {
+  const LossShape sh = loss_shape(z, m, n, dtype, "cca_loss");
+  if (!loss_dev) fail(CCZ_EINVAL, "cca_loss: null argument");
+  bool want = false;
+  for (int a = 0; a < m; ++a)
+    if (g && g[a]) {
+      if (!ldg || ldg[a] < sh.dims[a]) fail(CCZ_EINVAL, "cca_loss: bad gradient stride (view %d)", a);
+      want = true;
+    }
+  PoolPtr state(c, want ? size_t(pair_loss_state_bytes_impl(dtype, sh.dims, m)) : 0);
+  pair_loss_forward_impl(c, dtype, z, m, n, eps, loss_dev, state.p);
+  if (want) pair_loss_backward_impl(c, dtype, z, m, n, state.p, nullptr, g, ldg);
 }
 
 void cca_loss_impl(ccz_ctx* c, int dtype, const void* z1, const void* z2, int64_t n, int64_t d1, int64_t d2, int64_t ld1,

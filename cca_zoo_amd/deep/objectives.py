@@ -123,10 +123,13 @@ class _ShardedCCALossFn(torch.autograd.Function):
 
 
 class _PairLossFn(torch.autograd.Function):
-    """Sum over all view pairs of the CCA loss of ONE batch (``ccz_pair_loss``; two views: ``CCALoss``): one K1 pass over
-    ``[z_1 .. z_m]``, one Cholesky + inverse per VIEW -- the reference re-centres every view and recomputes its
-    ``S_aa^-1/2`` once per PAIR (cca_zoo/deep/objectives.py:138-153) -- the loss written on the device and the gradient of
-    every view straight into its own tensor.  Enqueue-only: no host synchronisation, no concatenated copy."""
+    """Sum over all view pairs of the CCA loss of ONE batch (two views: ``CCALoss``) as a two-phase autograd node:
+    ``ccz_pair_loss_forward`` -- one K1 pass over ``[z_1 .. z_m]``, one Cholesky + inverse per VIEW (the reference re-centres
+    every view and recomputes its ``S_aa^-1/2`` once per PAIR, cca_zoo/deep/objectives.py:138-153), the loss written on the
+    device, ``Gamma`` left in a small state tensor -- and ``ccz_pair_loss_backward``, which forms every view's gradient
+    ``grad_out * (Z - mean) Gamma`` from the views where they lie, the upstream gradient applied inside the product (no
+    ``grad_out * g`` passes over the n x d gradients afterwards).  Enqueue-only: no host synchronisation, no concatenated
+    copy."""
 
     @staticmethod
     def forward(ctx, eps: float, what: str, *zs: torch.Tensor) -> torch.Tensor:
@@ -141,30 +144,57 @@ class _PairLossFn(torch.autograd.Function):
         _raise_pending(h)
         need = any(ctx.needs_input_grad[2:])
         loss = torch.empty((), dtype=dt, device=vs[0].device)
-        grads = [torch.empty_like(v, memory_format=torch.contiguous_format) for v in vs] if need else None
-        views = (_backend.View * m)()
-        for i, v in enumerate(vs):
-            views[i].data, views[i].cols, views[i].ld = v.data_ptr(), int(v.shape[1]), int(v.stride(0))
-        gp = (C.c_void_p * m)(*[g.data_ptr() for g in grads]) if need else None
-        ldg = (C.c_int64 * m)(*[int(g.stride(0)) for g in grads]) if need else None
+        code = _backend.F32 if dt == torch.float32 else _backend.F64
+        state = None
+        if need:
+            dims = (C.c_int64 * m)(*[int(v.shape[1]) for v in vs])
+            nbytes = int(h.lib.ccz_pair_loss_state_bytes(code, dims, m))
+            if nbytes <= 0:
+                raise ValueError(f"{what}: unsupported views")
+            state = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=vs[0].device)
+        views = _views_of(vs)
         sp = _stream_ptr(vs[0])
         h.adopt(sp)                                         # the loss's kernels go INTO torch's current stream
         try:
-            h.check(h.lib.ccz_pair_loss(h.raw, _backend.F32 if dt == torch.float32 else _backend.F64, views, m, int(vs[0].shape[0]),
-                                        float(eps), C.c_void_p(loss.data_ptr()), gp, ldg))
+            h.check(h.lib.ccz_pair_loss_forward(h.raw, code, views, m, int(vs[0].shape[0]), float(eps), C.c_void_p(loss.data_ptr()),
+                                                C.c_void_p(state.data_ptr()) if need else None))
         finally:
             # whatever happened (ENOTSPD on the wide route, EINVAL, out of memory): the handle goes HOME to its own stream,
             # ordered behind the caller's -- a side stream may be destroyed later, and entry points that do not acquire
             # (host-array fits, gevp, sync) must never run on the legacy null stream by accident
             h.acquire(sp)
         if need:
-            ctx.save_for_backward(*grads)
+            ctx.save_for_backward(state, *vs)
             ctx.dtypes = [z.dtype for z in zs]
+            ctx.wanted = list(ctx.needs_input_grad[2:])
         return loss
 
     @staticmethod
     def backward(ctx, grad_out):
-        return (None, None, *[(grad_out * g).to(t) for g, t in zip(ctx.saved_tensors, ctx.dtypes)])
+        state, *vs = ctx.saved_tensors
+        m = len(vs)
+        dt = vs[0].dtype
+        h = _backend.handle_for(vs)
+        go = grad_out.detach().to(device=vs[0].device, dtype=dt).reshape(()).contiguous()
+        grads = [torch.empty_like(v, memory_format=torch.contiguous_format) if w else None for v, w in zip(vs, ctx.wanted)]
+        gp = (C.c_void_p * m)(*[g.data_ptr() if g is not None else None for g in grads])
+        ldg = (C.c_int64 * m)(*[int(g.stride(0)) if g is not None else 0 for g in grads])
+        views = _views_of(vs)
+        sp = _stream_ptr(vs[0])
+        h.adopt(sp)
+        try:
+            h.check(h.lib.ccz_pair_loss_backward(h.raw, _backend.F32 if dt == torch.float32 else _backend.F64, views, m, int(vs[0].shape[0]),
+                                                 C.c_void_p(state.data_ptr()), C.c_void_p(go.data_ptr()), gp, ldg))
+        finally:
+            h.acquire(sp)
+        return (None, None, *[g if g is None else g.to(t) for g, t in zip(grads, ctx.dtypes)])
+
+
+def _views_of(vs):
+    views = (_backend.View * len(vs))()
+    for i, v in enumerate(vs):
+        views[i].data, views[i].cols, views[i].ld = v.data_ptr(), int(v.shape[1]), int(v.stride(0))
+    return views
 
 
 def _inv_sqrtm(A: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:

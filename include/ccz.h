@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CCZ_VERSION 130 /* 0.1.3: ccz_comm_*, ccz_allreduce_sum_f64*; blocked Jacobi behind ccz_syevj / ccz_gesvj */
+#define CCZ_VERSION 140 /* 0.1.4: ccz_pair_loss_forward / _backward / _state_bytes (the loss as an autograd node in two phases) */
 
 #if defined(__GNUC__)
 #define CCZ_API __attribute__((visibility("default")))
@@ -247,6 +247,19 @@ CCZ_API int ccz_cca_loss(ccz_handle h, int dtype, const void* z1_dev, const void
  * n_views device pointers (entries may be NULL), ldg their leading dimensions; loss_dev: one element of `dtype`. */
 CCZ_API int ccz_pair_loss(ccz_handle h, int dtype, const ccz_view* z_dev, int n_views, int64_t n, double eps,
                   void* loss_dev, void* const* g_dev, const int64_t* ldg);
+/* The same loss in two phases, for callers inside an autograd graph (the reference's loss IS such a node: CCALoss.forward,
+ * deep/objectives.py:61-102, is differentiated by torch; its backward receives the upstream gradient of the scalar loss,
+ * cca_zoo/deep/_base.py:78-104).  ccz_pair_loss_forward evaluates the loss and leaves what the backward needs -- Gamma, the
+ * centring row, for fp32 views also Gamma in fp32 -- in state_dev: caller-owned device memory of
+ * ccz_pair_loss_state_bytes(dtype, dims, n_views) bytes (state_dev = NULL: forward only).  ccz_pair_loss_backward writes
+ *   g_a = (*grad_out_dev) * d loss / d z_a     (grad_out_dev: ONE element of `dtype` on the device, NULL = 1)
+ * for the SAME views (entries of g_dev may be NULL).  Two aligned fp32 views: one fp32 MFMA product that reads the views
+ * where they lie; the upstream gradient is applied inside it.  ccz_pair_loss == forward + backward(NULL). */
+CCZ_API int64_t ccz_pair_loss_state_bytes(int dtype, const int64_t* dims, int n_views);
+CCZ_API int ccz_pair_loss_forward(ccz_handle h, int dtype, const ccz_view* z_dev, int n_views, int64_t n, double eps,
+                          void* loss_dev, void* state_dev);
+CCZ_API int ccz_pair_loss_backward(ccz_handle h, int dtype, const ccz_view* z_dev, int n_views, int64_t n,
+                           const void* state_dev, const void* grad_out_dev, void* const* g_dev, const int64_t* ldg);
 /* ccz_cca_loss / ccz_pair_loss never read the factorization's pivot flags back (no host synchronisation between the encoders' forward
  * and backward).  If S_aa + eps I was not positive definite the loss written to loss_dev is NaN and the handle keeps a
  * sticky record: *view = 1 + index of the failing view (0: none since the last query), *pivot = the failing pivot;

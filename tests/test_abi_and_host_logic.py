@@ -22,13 +22,13 @@ def test_header_symbols_all_exported(libpath):
     from cca_zoo_amd import _backend
 
     header = open(os.path.join(ROOT, "include", "ccz.h")).read()
-    declared = set(re.findall(r"CCZ_API\s+(?:const\s+char\*|int)\s+(ccz_\w+)\s*\(", header))
+    declared = set(re.findall(r"CCZ_API\s+(?:const\s+char\*|int64_t|int)\s+(ccz_\w+)\s*\(", header))
     assert declared == set(_backend.SIGNATURES), declared ^ set(_backend.SIGNATURES)
     lib = ctypes.CDLL(libpath)
     for name in declared:
         assert hasattr(lib, name), name
     _backend.bind(lib, strict=True)
-    assert lib.ccz_version() == 130
+    assert lib.ccz_version() == 140
 
 
 def test_no_gpu_fails_loudly(libpath):
