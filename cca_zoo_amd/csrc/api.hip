@@ -104,6 +104,7 @@ int ccz_destroy(ccz_handle h) {
     for (auto& t : im->tile_tabs) if (t.dev) (void)hipFree(t.dev);
     for (auto& e : im->chain_sync) if (e.second) (void)hipFree(e.second);
     if (im->colsum_counters) (void)hipFree(im->colsum_counters);
+    if (im->chain_dbg) (void)hipFree(im->chain_dbg);
     for (int i = 0; i < 4; ++i) (void)hipEventDestroy(im->ev[i]);
     for (int i = 0; i < 4; ++i) if (im->pipe_ev[i]) (void)hipEventDestroy(im->pipe_ev[i]);
     for (int i = 0; i < 2; ++i) if (im->pin_buf[i]) (void)hipHostFree(im->pin_buf[i]);

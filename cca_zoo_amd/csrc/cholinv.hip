@@ -20,7 +20,9 @@
 // Several matrices (<= 8) share every launch.  All tile products run on v_mfma_f64_16x16x4_f64 from LDS tiles.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #include "hip_common.h"
 
@@ -53,6 +55,24 @@ __device__ __forceinline__ void tile_mm(const double* As, const double* Bs, int 
     for (int t = 0; t < 4; ++t) {
       const double b = TB ? Bs[(16 * t + lr) * CLD + kk] : Bs[kk * CLD + 16 * t + lr];
       acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+    }
+  }
+}
+
+// A (64 x 64, row-major) times an UPPER-triangular B (row-major: T_j = L_jj^-T): column tile t only needs k < 16 (t + 1),
+// 40 MFMAs per wave instead of 64
+__device__ __forceinline__ void tile_mm_upper(const double* As, const double* Bs, int w, int lane, v4f64 (&acc)[4]) {
+  const int lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int k0 = 0; k0 < CB; k0 += 4) {
+    const int kk = k0 + lk;
+    const double a = As[(16 * w + lr) * CLD + kk];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (k0 < 16 * (t + 1)) {
+        const double b = Bs[kk * CLD + 16 * t + lr];
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+      }
     }
   }
 }
@@ -100,6 +120,22 @@ template <bool TRANS>
 __device__ __forceinline__ void load_tile(double* dst, const double* __restrict__ src, int64_t ld, int rows, int cols, int tid) {
   TileRegs t;
   fetch_tile(t, src, ld, rows, cols, tid);
+  store_tile<TRANS>(dst, t, tid);
+}
+
+// ---- tiles that ANOTHER workgroup of the same launch writes (k_cholinv_chain): ld_shared / st_shared, hip_common.h ----
+__device__ __forceinline__ void fetch_tile_shared(TileRegs& t, const double* src, int64_t ld, int rows, int cols, int tid) {
+  const int c = tid & 63, r0 = tid >> 6;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = r0 + 4 * i;
+    t.v[i] = (r < rows && c < cols) ? ld_shared(src + int64_t(r) * ld + c) : 0.0;
+  }
+}
+template <bool TRANS>
+__device__ __forceinline__ void load_tile_shared(double* dst, const double* src, int64_t ld, int rows, int cols, int tid) {
+  TileRegs t;
+  fetch_tile_shared(t, src, ld, rows, cols, tid);
   store_tile<TRANS>(dst, t, tid);
 }
 
@@ -374,19 +410,40 @@ __device__ __forceinline__ void chol_panel16(v4f64 (&acc)[4][4], int lane, const
 #pragma unroll
     for (int cc = 0; cc < 16; ++cc) pv[cc] = PL[lane * CPLD + cc];
   }
+  // The pivot chain.  A dependent fp64 operation costs 32 cycles here, so what a pivot costs is the number of DEPENDENT
+  // operations between two pivots: the next pivot is formed wave-uniformly from broadcasts taken BEFORE this pivot's
+  // reciprocal is known,  piv' = a - b^2 / piv  (a, b = entries (t+1, t+1), (t+1, t) of the current Schur complement), with
+  // 1 / piv from the same v_rsq_f64 seed by a third-order step -- rsq, 2 to e, e + e^2, w, fma: six dependent operations,
+  // no lane exchange on the chain.  The column itself (x rs, third-order rsqrt from the same seed), its broadcasts and the
+  // updates of the panel's other columns fill the shadow.  A non-positive pivot is recorded and NOT repaired: NaN / inf flow
+  // through the rest of the block, whose result is reported as failed anyway.  Lanes above the diagonal carry junk that
+  // nobody reads (the factor image is only ever read on and below its diagonal).
+  double piv = bcast_lane(pv[0], C0);
+  double rd_mine = 0.0;
 #pragma unroll
   for (int t = 0; t < 16; ++t) {
-    double piv = bcast_lane(pv[t], C0 + t);
-    const bool bad = !(piv > 0.0);                     // wave-uniform; NaN counts as bad
+    const bool bad = !(piv > 0.0);                     // wave-uniform; NaN counts as bad; off the chain
     first_bad = bad ? min(first_bad, C0 + t) : first_bad;
-    piv = bad ? 1.0 : piv;
-    const double rs = rsqrt_cubic(piv);
-    l[t] = lane >= C0 + t ? pv[t] * rs : 0.0;          // select, not multiply: lanes above hold stale / foreign values
-    if (lane == 0) Rd[C0 + t] = rs;                    // 1 / L_jj for the substitution of the inverse
+    const double y0 = __builtin_amdgcn_rsq(piv);
+    const double tq = piv * y0;
+    const double e = __builtin_fma(-tq, y0, 1.0);      // 1 - piv y0^2
+    const double y2 = y0 * y0;
+    const double ge = __builtin_fma(e, e, e);
+    const double w = __builtin_fma(y2, ge, y2);        // 1 / piv  (relative error e^3)
+    double piv_next = 0.0;
+    if (t < 15) {
+      const double a = bcast_lane(pv[t + 1 < 16 ? t + 1 : 15], C0 + t + 1), bb = bcast_lane(pv[t], C0 + t + 1);
+      piv_next = __builtin_fma(-(bb * bb), w, a);
+    }
+    const double rs = __builtin_fma(y0 * e, __builtin_fma(e, 0.375, 0.5), y0);   // 1 / sqrt(piv)  (relative error (5/16) e^3)
+    l[t] = pv[t] * rs;
+    rd_mine = (lane == C0 + t) ? rs : rd_mine;         // 1 / L_jj for the substitution of the inverse
 #pragma unroll
     for (int u = t + 1; u < 16; ++u) pv[u] = __builtin_fma(-l[t], bcast_lane(l[t], C0 + u), pv[u]);
+    piv = piv_next;
   }
-  // column-major factor image Ls[col][row] (whole columns, zeros above the diagonal) -- also the MFMA operand image
+  if (lane >= C0 && lane < C0 + 16) Rd[lane] = rd_mine;
+  // column-major factor image Ls[col][row] -- also the MFMA operand image
 #pragma unroll
   for (int t = 0; t < 16; ++t) Ls[(C0 + t) * CLD + lane] = l[t];
   if (P == 3) return;
@@ -425,32 +482,33 @@ __device__ __forceinline__ int chol64_p16(const double* In, double* Ls, double* 
   return first_bad;
 }
 
-// all four waves: Xs[col * CLD + row] = (L^-1)[row][col]  (== row-major L^-T) from Ls / Rd
-__device__ __forceinline__ void inv64_mfma(const double* Ls, const double* Rd, double* Xs, int tid) {
+// all four waves: the diagonal 16 x 16 blocks of Xs[col * CLD + row] = (L^-1)[row][col] (== row-major L^-T) from Ls / Rd, and
+// zeros in the blocks above the block diagonal.  No barrier inside.
+__device__ __forceinline__ void inv64_phaseA(const double* __restrict__ Ls, const double* __restrict__ Rd, double* __restrict__ Xs, int tid) {
   const int lane = tid & 63, w = tid >> 6;
   // zero the blocks above the block diagonal (the substitution leaves exact zeros inside the diagonal blocks)
   for (int e = tid; e < CB * CB; e += 256) {
     const int row = e & 63, col = e >> 6;
     if ((row >> 4) < (col >> 4)) Xs[col * CLD + row] = 0.0;
   }
-  // phase A: wave w inverts the 16 x 16 diagonal block w by forward substitution, lane c < 16 = right-hand side e_c
-  {
-    const int o = 16 * w;
-    double v[16];
+  // wave w inverts the 16 x 16 diagonal block w by forward substitution, lane c < 16 = right-hand side e_c
+  const int o = 16 * w;
+  double v[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = (k == lane) ? 1.0 : 0.0;
+  for (int k = 0; k < 16; ++k) v[k] = (k == lane) ? 1.0 : 0.0;
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const double x = v[0] * Rd[o + t];
-      if (lane < 16) Xs[(o + lane) * CLD + o + t] = x;           // (L^-1)[o + t][o + lane]
-      const double* lcol = Ls + (o + t) * CLD + o + t;            // L[o + t + k][o + t], wave-uniform
+  for (int t = 0; t < 16; ++t) {
+    const double x = v[0] * Rd[o + t];
+    if (lane < 16) Xs[(o + lane) * CLD + o + t] = x;           // (L^-1)[o + t][o + lane]
+    const double* lcol = Ls + (o + t) * CLD + o + t;            // L[o + t + k][o + t], wave-uniform
 #pragma unroll
-      for (int k = 1; k < 16; ++k) v[k - 1] = (t + k < 16) ? v[k] - lcol[k] * x : 0.0;
-    }
+    for (int k = 1; k < 16; ++k) v[k - 1] = (t + k < 16) ? v[k] - lcol[k] * x : 0.0;
   }
-  __syncthreads();
-  // phase B: wave j forms column block j below the diagonal, top to bottom
-  const int j = w;
+}
+
+// ONE wave forms column block j of L^-1 below the diagonal, top to bottom (needs the diagonal blocks of phase A); only
+// wave-level synchronisation inside
+__device__ __forceinline__ void inv64_phaseB_col(const double* Ls, double* Xs, int lane, int j) {
   const int lr = lane & 15, lk = lane >> 4;
   for (int i = j + 1; i < 4; ++i) {
     v4f64 sacc = {0.0, 0.0, 0.0, 0.0};
@@ -476,13 +534,78 @@ __device__ __forceinline__ void inv64_mfma(const double* Ls, const double* Rd, d
   }
 }
 
-// Whole workgroup (256 threads), input tile in LDS tile 1 (identity-padded): factor (tile 0 <- L, column-major),
-// invert (tile 2 <- L^-T, row-major), publish the L block and T = L^-T to global memory.
-// FORM: 0 shift-register recurrence on two waves, 1 MFMA form with 4-column panels (rounds 2-4), 2 MFMA form with
-// 16-column panels (default)
-template <int FORM>
+// all four waves: Xs[col * CLD + row] = (L^-1)[row][col]  (== row-major L^-T) from Ls / Rd
+__device__ __forceinline__ void inv64_mfma(const double* Ls, const double* Rd, double* Xs, int tid) {
+  inv64_phaseA(Ls, Rd, Xs, tid);
+  __syncthreads();
+  inv64_phaseB_col(Ls, Xs, tid & 63, tid >> 6);       // wave j forms column block j
+}
+
+// ONE wave's 16-row strip of  X = A L^-T  (X L' = A) from the factor image Ls[col * CLD + row] and the diagonal 16 x 16
+// blocks of Xs (phase A) alone -- the off-diagonal blocks of L^-1 are not needed, so the chain does not wait for them.
+// Worked on TRANSPOSED 16 x 16 blocks: with X_c' in the MFMA accumulator layout (row = lk + 4 r, col = lr) an accumulator
+// IS the B fragment of the next product, so the whole recurrence
+//   R_c' = A_c' - sum_{s<c} L_cs X_s',   X_c' = Dinv_c R_c'
+// runs in registers: 40 MFMAs, no LDS round trip.  As: the A tile (row-major, stride CLD); out: X (row-major) for the
+// strip's rows.
+__device__ __forceinline__ void solve_strip_LT(const double* As, const double* Ls, const double* Xs, double* out, int w, int lane) {
+  const int lr = lane & 15, lk = lane >> 4;
+  v4f64 xt[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    v4f64 r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r[q] = As[(16 * w + lr) * CLD + 16 * c + lk + 4 * q];     // R_c'[lk + 4 q][lr] = A[16 w + lr][16 c + lk + 4 q]
+#pragma unroll
+    for (int sb = 0; sb < c; ++sb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double a = Ls[(16 * sb + 4 * q + lk) * CLD + 16 * c + lr];                   // L[16 c + lr][16 sb + 4 q + lk]
+        r = __builtin_amdgcn_mfma_f64_16x16x4f64(-a, xt[sb][q], r, 0, 0, 0);
+      }
+    v4f64 x = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double a = Xs[(16 * c + 4 * q + lk) * CLD + 16 * c + lr];                      // (L^-1)[16 c + lr][16 c + 4 q + lk]
+      x = __builtin_amdgcn_mfma_f64_16x16x4f64(a, r[q], x, 0, 0, 0);
+    }
+    xt[c] = x;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) out[(16 * w + lr) * CLD + 16 * c + lk + 4 * q] = x[q];   // X[16 w + lr][16 c + lk + 4 q]
+  }
+}
+
+// rows [0, rows) x 64 columns of a row-major LDS tile (stride CLD) -> global (ld ldg), write-through; `nthr` threads (tid <
+// nthr) take part.  16-byte stores when the destination rows are 16-byte aligned.
+__device__ __forceinline__ void store_rows_shared(double* dst, int64_t ldg, const double* src, int rows, int tid, int nthr) {
+  if (((reinterpret_cast<uintptr_t>(dst) | uintptr_t(ldg * 8)) & 15) == 0) {
+    for (int e = tid; e < rows * 32; e += nthr) {
+      const int r = e >> 5, c2 = (e & 31) * 2;
+      st_shared2(dst + int64_t(r) * ldg + c2, src[r * CLD + c2], src[r * CLD + c2 + 1]);
+    }
+  } else {
+    for (int e = tid; e < rows * 64; e += nthr) {
+      const int r = e >> 6, c = e & 63;
+      st_shared(dst + int64_t(r) * ldg + c, src[r * CLD + c]);
+    }
+  }
+}
+
+// the factor's 64 x 64 block of L (lower triangle) and T = L^-T out of the LDS images, write-through
+__device__ __forceinline__ void publish_block_shared(const double* lds, int tid, int nbv, double* Lblk, int64_t ldl, double* Tblk) {
+  const double* Ls = lds;
+  const double* Xs = lds + 2 * CTILE;
+  const int c = tid & 63;
+  for (int r = tid >> 6; r < CB; r += 4) {
+    if (r < nbv && c <= r) st_shared(Lblk + int64_t(r) * ldl + c, Ls[c * CLD + r]);
+    st_shared(Tblk + r * CB + c, Xs[r * CLD + c]);
+  }
+}
+
+template <int FORM, bool SHARED = false, bool STORE = true>
 __device__ __forceinline__ void factor_and_publish_t(double* lds, int tid, int nbv, double* __restrict__ Lblk, int64_t ldl,
-                                                     double* __restrict__ Tblk, int* __restrict__ info, int64_t col0) {
+                                                     double* __restrict__ Tblk, int* __restrict__ info, int64_t col0,
+                                                     unsigned long long* stamps = nullptr) {
   double* Ls = lds;
   const double* In = lds + CTILE;
   double* Xs = lds + 2 * CTILE;
@@ -492,11 +615,14 @@ __device__ __forceinline__ void factor_and_publish_t(double* lds, int tid, int n
   if (FORM != 0) {
     __syncthreads();
     if (tid < 64) {
+      if (stamps && tid == 0) stamps[0] = __builtin_readcyclecounter();
       const int bad = FORM == 2 ? chol64_p16(In, Ls, Rd, PL, tid) : chol64_mfma(In, Ls, Rd, PL, tid);
       if (tid == 0 && bad != 0x7fffffff) atomicMin(info, int(col0 + bad + 1));
+      if (stamps && tid == 0) stamps[1] = __builtin_readcyclecounter();
     }
     __syncthreads();
     inv64_mfma(Ls, Rd, Xs, tid);
+    if (stamps && tid == 0) stamps[2] = __builtin_readcyclecounter();
   } else {
     if (tid == 0) *progress = 0;
     __syncthreads();
@@ -506,10 +632,16 @@ __device__ __forceinline__ void factor_and_publish_t(double* lds, int tid, int n
     }
   }
   __syncthreads();
+  if (!STORE) return;
   const int c = tid & 63;
   for (int r = tid >> 6; r < CB; r += 4) {
-    if (r < nbv && c <= r) Lblk[int64_t(r) * ldl + c] = Ls[c * CLD + r];
-    Tblk[r * CB + c] = Xs[r * CLD + c];
+    if (SHARED) {
+      if (r < nbv && c <= r) st_shared(Lblk + int64_t(r) * ldl + c, Ls[c * CLD + r]);
+      st_shared(Tblk + r * CB + c, Xs[r * CLD + c]);
+    } else {
+      if (r < nbv && c <= r) Lblk[int64_t(r) * ldl + c] = Ls[c * CLD + r];
+      Tblk[r * CB + c] = Xs[r * CLD + c];
+    }
   }
 }
 
@@ -709,6 +841,7 @@ struct ChainPlan {
   int link_first[CH_MAXNB + 1];     // helper items of the links before j, all matrices; [nbmax] = all helper items
   int nbmax;
   int total;                        // count chain items + helper items
+  int poll_sleep;                   // s_sleep(4) periods between two polls of a progress word (CCZ_CHAIN_SLEEP)
 };
 
 // helper items of matrix (nb block columns, with / without X) at link j: trailing tiles without the chain's, XT row j, XS row j + 1
@@ -720,136 +853,241 @@ __host__ __device__ __forceinline__ void chain_counts(int nb, bool with_x, int j
   nXS = (with_x && j + 1 < nb) ? j + 1 : 0;
 }
 
-// Thread 0 polls *p (agent scope) until it reaches `target`; the workgroup follows through a barrier and acquires.
-// flag: one LDS int.  Returns false after the watchdog / an abort raised elsewhere (the caller goes on with whatever is
-// in memory: the launch must terminate, its result is reported as failed).
-__device__ __forceinline__ bool chain_wait(unsigned* p, unsigned target, ChainSync* sy, int* flag, int tid) {
+// Thread 0 polls up to three progress words (agent scope, relaxed) until each has reached its target; the workgroup
+// follows through a barrier.  No acquire fence: every shared word is read with ld_shared (past the L1).  flag: one LDS
+// int.  Returns false after the watchdog / an abort raised elsewhere (the caller goes on with whatever is in memory: the
+// launch must terminate, its result is reported as failed).
+struct ChainWaitList {
+  unsigned* p[3];
+  unsigned target[3];
+  int n = 0;
+  int sleep = 1;
+  bool first_is_step = false;     // p[0] counts chain steps (F / G): being two or more behind means a link away
+  __device__ __forceinline__ void add(unsigned* q, unsigned t) { p[n] = q; target[n] = t; ++n; }
+};
+
+__device__ __forceinline__ bool chain_wait(const ChainWaitList& wl, ChainSync* sy, int* flag, int tid) {
+  if (wl.n == 0) return true;
   if (tid == 0) {
     int good = 1, spins = 0;
-    while (int(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-      __builtin_amdgcn_s_sleep(8);
-      ++spins;
-      if ((spins & 63) == 0 && __hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { good = 0; break; }
-      if (spins > CH_WATCHDOG) {
-        __hip_atomic_store(&sy->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        good = 0;
-        break;
+    for (int q = 0; q < wl.n && good; ++q) {
+      const gu32_ptr word = (gu32_ptr)(reinterpret_cast<uintptr_t>(wl.p[q]));
+      for (;;) {
+        const int behind = int(wl.target[q] - __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (behind <= 0) break;
+        // a target several steps away (a link that has not started) is polled rarely: idle pollers cost the memory system
+        // of the workgroups that do the work (MI355X_MICROARCH.md: "255 pollers cut chip bandwidth 37-71 %")
+        const int naps = wl.sleep * (q == 0 && wl.first_is_step && behind >= 2 ? 16 : 1);
+        for (int z = 0; z < naps; ++z) __builtin_amdgcn_s_sleep(4);
+        ++spins;
+        if ((spins & 63) == 0 && __hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { good = 0; break; }
+        if (spins > CH_WATCHDOG) {
+          __hip_atomic_store(&sy->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          good = 0;
+          break;
+        }
       }
     }
     *flag = good;
   }
   __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   const bool ok = *flag != 0;
   __syncthreads();                     // the next wait may overwrite the flag
   return ok;
 }
 
-// every thread's global stores of this item -> visible device-wide, then one counter update
+// hand-over: every wave drains its write-through stores, barrier, one lane moves the progress word
 __device__ __forceinline__ void chain_publish_add(unsigned* p, int tid) {
-  __threadfence();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (tid == 0) __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void chain_publish_set(unsigned* p, unsigned v, int tid) {
-  __threadfence();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (tid == 0) __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// lds: tiles 0..2, Rd, flags, panel image (the layout factor_and_publish_t expects)
+// The chain workgroup of matrix b.  lds4: four tiles -- two factor images used alternately (while block j + 1 is being
+// factored into one of them on wave 0, waves 1-3 still read block j's image from the other), the input / Schur tile, the
+// inverse tile -- then Rd, flags and the panel image.  Per link (block j factored -> block j + 1 factored):
+//   all waves:  phase A of block j's inverse (the four 16 x 16 diagonal inverses)
+//               tiles (j+1, j), (j+1, j+1) requested (the helpers of link j - 1 must be done)
+//               L_{j+1,j} = A_{j+1,j} L_jj^-T  by the register-resident strip solve (needs phase A only), stored write-through
+//               S = A_{j+1,j+1} - L_{j+1,j} L_{j+1,j}'  -> input tile
+//   wave 0:     factor S                            || waves 1-3: phase B of block j's inverse, T_j and L_jj stored
+//                                                      write-through, drained, F[b] = j + 1  (block j is public)
+// so the publication of a block -- off-diagonal inverse blocks, 64 KB of stores, their drain -- costs the chain nothing;
+// the helpers of link j start while block j + 1 is being factored and have until its end.
+// dbg (CCZ_CHAIN_DEBUG=1, matrix 0 only): shader-clock stamps per link -- [0] link start, [1] phase A done, [2] helpers
+// awaited + tiles in LDS, [3] L_ij formed, [4] Schur block ready (fork), [5] factorization done, [6] block j published
+// (stamped by wave 1), [7] joined.
+// (the thread index passes through an empty asm at the head of this path and of the helper items: without it the compiler
+// forms every path's index constants at the kernel's entry, keeps them alive across the whole kernel, and spills 65 to 126
+// registers that are reloaded from scratch memory inside the chain)
 template <int FORM>
-__device__ __forceinline__ void chain_matrix(const CholInvBatch& bt, int b, ChainSync* sy, int* __restrict__ info, double* lds, int* flag,
-                                             int tid) {
-  const int64_t d = bt.d[b];
+__device__ __forceinline__ void chain_matrix(int64_t d, int64_t lda, int64_t ldl, double* A, double* L, double* T, bool with_x, int b,
+                                                       ChainSync* sy, int* __restrict__ info, double* lds4, int* flag, int tid,
+                                                       unsigned long long* dbg) {
+  asm volatile("" : "+v"(tid));        // index arithmetic of this path is formed HERE, not hoisted to the kernel's entry (see above)
   const int nb = int((d + CB - 1) / CB);
-  const bool with_x = bt.X[b] != nullptr;
-  const int64_t lda = bt.lda[b], ldl = bt.ldl[b];
-  double* A = bt.A[b];
-  double* L = bt.L[b];
-  double* T = bt.T[b];
-  double* P = lds;               // tile 0: becomes Ls of the factorization
-  double* Q = lds + CTILE;       // tile 1: input of the factorization
-  double* TT = lds + 2 * CTILE;  // tile 2: T_j = L_jj^-T, left there by the factorization of block j
+  double* IN = lds4 + 2 * CTILE;            // input of the factorization / staged A_ij
+  double* XS = lds4 + 3 * CTILE;            // L^-T of the current block
+  double* Rd = lds4 + 4 * CTILE;
+  int* pubcnt = reinterpret_cast<int*>(Rd + CB) + 4;     // arrivals of waves 1-3 at the end of a publication
+  double* PL = Rd + CB + 8;
   const int lane = tid & 63, w = tid >> 6;
+  if (b != 0) dbg = nullptr;
   bool ok = true;
+  int cur = 0;
+  // ---- block 0 ----
   {
     const int nbv = int(min<int64_t>(CB, d));
-    if (tid == 0) info[b] = 0x7fffffff;
+    if (tid == 0) { info[b] = 0x7fffffff; *pubcnt = 0; }
+    if (dbg && tid == 0) dbg[0] = __builtin_readcyclecounter();
     const int c = tid & 63;
     for (int r = tid >> 6; r < CB; r += 4) {
       double v = (r == c) ? 1.0 : 0.0;
-      if (r < nbv && c < nbv) v = c <= r ? A[int64_t(r) * lda + c] : A[int64_t(c) * lda + r];
-      Q[r * CLD + c] = v;
+      if (r < nbv && c < nbv) v = c <= r ? A[int64_t(r) * lda + c] : A[int64_t(c) * lda + r];   // written before the launch
+      IN[r * CLD + c] = v;
     }
-    factor_and_publish_t<FORM>(lds, tid, nbv, L, ldl, T, info + b, 0);
-    chain_publish_set(&sy->F[b], 1u, tid);
+    __syncthreads();
+    if (tid < 64) {
+      const int bad = FORM == 2 ? chol64_p16(IN, lds4 + cur * CTILE, Rd, PL, tid) : chol64_mfma(IN, lds4 + cur * CTILE, Rd, PL, tid);
+      if (tid == 0 && bad != 0x7fffffff) atomicMin(info + b, int(bad + 1));
+    }
+    __syncthreads();
+    if (dbg && tid == 0) dbg[5] = __builtin_readcyclecounter();
   }
-  for (int j = 0; j + 1 < nb; ++j) {
-    if (j >= 1) {                                        // tiles (j+1, j) and (j+1, j+1) carry the updates of the links < j
-      int hU, nXT, nXS;
-      chain_counts(nb, with_x, j - 1, hU, nXT, nXS);
-      if (hU > 0) ok = chain_wait(&sy->U[b][j - 1], unsigned(hU), sy, flag, tid) && ok;
-    }
-    const int i = j + 1;
-    const int64_t ri = int64_t(i) * CB, cj = int64_t(j) * CB;
-    const int rows_i = int(min<int64_t>(CB, d - ri));
-    load_tile<false>(P, A + ri * lda + cj, lda, rows_i, CB, tid);
+  for (int j = 0; j < nb; ++j) {
+    unsigned long long* dj = dbg ? dbg + 8 * (j + 1) : nullptr;
+    const bool more = j + 1 < nb;
+    const int64_t cj = int64_t(j) * CB;
+    const int rows_j = int(min<int64_t>(CB, d - cj));
+    double* Lcur = lds4 + cur * CTILE;            // factor images in tiles 0 / 1, alternating
+    double* Lnxt = lds4 + (cur ^ 1) * CTILE;
+    if (dj && tid == 0) dj[0] = __builtin_readcyclecounter();
+    inv64_phaseA(Lcur, Rd, XS, tid);
     __syncthreads();
-    v4f64 a1[4];
-    acc_zero(a1);
-    tile_mm<false, false>(P, TT, w, lane, a1);            // L_ij = A_ij T_j
-    __syncthreads();
-    acc_to_lds(a1, P, w, lane, 1.0);
-    __syncthreads();
-    {
-      const int c = tid & 63;
-      for (int rr = tid >> 6; rr < rows_i; rr += 4) L[(ri + rr) * ldl + cj + c] = P[rr * CLD + c];
-    }
-    chain_publish_set(&sy->G[b], unsigned(i), tid);       // row i of X may start its partial sums
-    v4f64 u[4];
-    acc_zero(u);
-    tile_mm<false, true>(P, P, w, lane, u);               // L_ij L_ij'
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int rr = 16 * w + (lane >> 4) + 4 * rg, cc = 16 * t + (lane & 15);
-        double v = (rr == cc) ? 1.0 : 0.0;
-        if (rr < rows_i && cc < rows_i) {
-          const double base = cc <= rr ? A[(ri + rr) * lda + ri + cc] : A[(ri + cc) * lda + ri + rr];
-          v = base - u[t][rg];
+    // L_jj and the four 16 x 16 diagonal blocks of T_j = L_jj^-T are all the trailing tiles of link j need (they form their
+    // panels by the same strip solve as below): stored NOW, announced with G below -- a whole factorization earlier than T_j
+    auto early_stores = [&]() {
+      double* Lb = L + cj * ldl + cj;
+      double* Tb = T + int64_t(j) * CB * CB;
+      const bool al = ((reinterpret_cast<uintptr_t>(Lb) | uintptr_t(ldl * 8)) & 15) == 0;
+      for (int e = tid; e < CB * 32; e += 256) {          // pairs of columns (c2, c2 + 1) of row r
+        const int r = e >> 5, c2 = (e & 31) * 2;
+        if (r < rows_j && c2 <= r) {                      // lower triangle of L_jj: nothing is written above the diagonal
+          const double v0 = Lcur[c2 * CLD + r];
+          if (c2 + 1 <= r) {
+            const double v1 = Lcur[(c2 + 1) * CLD + r];
+            if (al) st_shared2(Lb + int64_t(r) * ldl + c2, v0, v1);
+            else { st_shared(Lb + int64_t(r) * ldl + c2, v0); st_shared(Lb + int64_t(r) * ldl + c2 + 1, v1); }
+          } else {
+            st_shared(Lb + int64_t(r) * ldl + c2, v0);
+          }
         }
-        Q[rr * CLD + cc] = v;
+        if ((r >> 4) == (c2 >> 4)) st_shared2(Tb + r * CB + c2, XS[r * CLD + c2], XS[r * CLD + c2 + 1]);
       }
-    // (the barrier at the head of factor_and_publish_t separates the reads of P above from the factor image written there)
-    factor_and_publish_t<FORM>(lds, tid, rows_i, L + ri * ldl + ri, ldl, T + int64_t(i) * CB * CB, info + b, ri);
-    chain_publish_set(&sy->F[b], unsigned(i + 1), tid);
+    };
+    if (dj && tid == 0) dj[1] = __builtin_readcyclecounter();
+    const int i = j + 1;
+    const int64_t ri = int64_t(i) * CB;
+    const int rows_i = more ? int(min<int64_t>(CB, d - ri)) : 0;
+    double aii[4][4];                                     // A_ii in the accumulator layout of the Schur product
+    if (more) {
+      if (j >= 1) {                                        // tiles (j+1, j) and (j+1, j+1) carry the updates of the links < j
+        int hU, nXT, nXS;
+        chain_counts(nb, with_x, j - 1, hU, nXT, nXS);
+        ChainWaitList wl;
+        if (hU > 0) wl.add(&sy->U[b][j - 1], unsigned(hU));
+        ok = chain_wait(wl, sy, flag, tid) && ok;
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int rr = 16 * w + (lane >> 4) + 4 * rg, cc = 16 * t + (lane & 15);
+          double v = (rr == cc) ? 1.0 : 0.0;
+          if (rr < rows_i && cc < rows_i) v = ld_shared(cc <= rr ? A + (ri + rr) * lda + ri + cc : A + (ri + cc) * lda + ri + rr);   // lower triangle authoritative
+          aii[t][rg] = v;
+        }
+      TileRegs rpan;
+      fetch_tile_shared(rpan, A + ri * lda + cj, lda, rows_i, CB, tid);        // A_ij, row-major
+      store_tile<false>(IN, rpan, tid);
+      __syncthreads();
+      if (dj && tid == 0) dj[2] = __builtin_readcyclecounter();
+      solve_strip_LT(IN, Lcur, XS, Lnxt, w, lane);          // rows 16 w .. of L_ij = A_ij L_jj^-T -> the OTHER factor image (scratch until the factorization)
+      __syncthreads();
+      // vmcnt counts loads and stores in one in-order queue: a store issued BEFORE a load is paid for, round trip and all, by
+      // the wait for that load.  So everything this link stores goes out here, behind its last load, and lands under the
+      // Schur product; the drain in front of the G publication finds it done.
+      early_stores();
+      // (an 8- or 16-byte write-through store is one fabric write per lane: ~400 cycles per wave instruction, measured -- so
+      // the chain stores as little as it can: L_ij itself goes out with the trailing tile (j+2, j+1), which forms it anyway
+      // as its second panel block; only the last link of a matrix has no such tile)
+      if (i + 1 >= nb) store_rows_shared(L + ri * ldl + cj, ldl, Lnxt, rows_i, tid, 256);
+      if (dj && tid == 0) dj[3] = __builtin_readcyclecounter();
+      v4f64 u[4];
+      acc_zero(u);
+      tile_mm<false, true>(Lnxt, Lnxt, w, lane, u);         // L_ij L_ij'
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) IN[(16 * w + (lane >> 4) + 4 * rg) * CLD + 16 * t + (lane & 15)] = aii[t][rg] - u[t][rg];
+      chain_publish_set(&sy->G[b], unsigned(i), tid);       // L_jj, diag(T_j) and L_ij have had the products to land: the trailing tiles
+                                                            // of link j and the sums of row i of X may start.  (barrier inside)
+    }
+    if (!more) early_stores();
+    if (dj && tid == 0) dj[4] = __builtin_readcyclecounter();
+    // ---- fork: wave 0 factors block j + 1, waves 1-3 finish and publish block j ----
+    if (w == 0) {
+      if (more) {
+        const int bad = FORM == 2 ? chol64_p16(IN, Lnxt, Rd, PL, lane) : chol64_mfma(IN, Lnxt, Rd, PL, lane);
+        if (lane == 0 && bad != 0x7fffffff) atomicMin(info + b, int(ri + bad + 1));
+        if (dj && lane == 0) dj[5] = __builtin_readcyclecounter();
+      }
+    } else {
+      inv64_phaseB_col(Lcur, XS, lane, w - 1);              // column blocks 0, 1, 2 of L^-1 (column 3 has no block below its diagonal)
+      // three-wave rendezvous: the stores below read blocks the OTHER two waves have just written
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) {
+        __hip_atomic_fetch_add(pubcnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__hip_atomic_load(pubcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 3) __builtin_amdgcn_s_sleep(1);
+      }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      const int t3 = tid - 64;                              // 0 .. 191
+      for (int e = t3; e < CB * 32; e += 192) {
+        const int r = e >> 5, c2 = (e & 31) * 2;
+        double* q = T + int64_t(j) * CB * CB + r * CB + c2;
+        if ((r >> 4) < (c2 >> 4)) st_shared2(q, XS[r * CLD + c2], XS[r * CLD + c2 + 1]);   // the blocks phase B has formed
+        else if ((r >> 4) > (c2 >> 4)) st_shared2(q, 0.0, 0.0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) {
+        const int arrived = __hip_atomic_fetch_add(pubcnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (arrived == 5) {                                 // the last of the three waves: every store of the block has landed
+          __hip_atomic_store(&sy->F[b], unsigned(j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(pubcnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (dj) dj[6] = __builtin_readcyclecounter();
+        }
+      }
+    }
+    __syncthreads();                                        // join
+    if (dj && tid == 0) dj[7] = __builtin_readcyclecounter();
+    cur ^= 1;
   }
   if (!ok && tid == 0) atomicMin(info + b, CH_TIMEOUT_INFO);
 }
 
 // lds4: FOUR tiles (extra tile first), then Rd / flags / panel image
-__device__ __forceinline__ void chain_helper(const CholInvBatch& bt, const ChainPlan& plan, int q, ChainSync* sy, int* __restrict__ info,
-                                             double* lds4, int* flag, int tid) {
-  int j = 0;
-  while (j + 1 < plan.nbmax && q >= plan.link_first[j + 1]) ++j;
-  q -= plan.link_first[j];
-  int b = 0, hU = 0, nXT = 0, nXS = 0, nb = 0;
-  for (;; ++b) {
-    nb = int((bt.d[b] + CB - 1) / CB);
-    chain_counts(nb, bt.X[b] != nullptr, j, hU, nXT, nXS);
-    const int tot = hU + nXT + nXS;
-    if (q < tot || b + 1 >= bt.count) break;
-    q -= tot;
-  }
-  const bool with_x = bt.X[b] != nullptr;
-  const int64_t d = bt.d[b];
-  const int64_t lda = bt.lda[b], ldl = bt.ldl[b], ldx = bt.ldx[b];
-  double* A = bt.A[b];
-  double* L = bt.L[b];
-  double* X = bt.X[b];
-  const double* Tj = bt.T[b] + int64_t(j) * CB * CB;
+// one helper item (decoded by the caller): q < hU trailing tile, < hU + nXT row j of X from its sums, else the sums of row j + 1
+__device__ __forceinline__ void chain_helper(int j, int q, int hU, int nXT, int nb, bool with_x, int64_t d, int64_t lda, int64_t ldl,
+                                                       int64_t ldx, double* A, double* L, double* X, const double* Tj, int b, int poll_sleep,
+                                                       ChainSync* sy, int* __restrict__ info, double* lds4, int* flag, int tid) {
+  asm volatile("" : "+v"(tid));        // as in chain_matrix
   const int64_t cj = int64_t(j) * CB;
   const int lane = tid & 63, w = tid >> 6;
   double* P = lds4 + CTILE;
@@ -859,12 +1097,18 @@ __device__ __forceinline__ void chain_helper(const CholInvBatch& bt, const Chain
 
   if (q < hU) {
     // ---- trailing tile (i, k) of link j, j < k <= i, (i, k) != (j+1, j+1) ----
-    ok = chain_wait(&sy->F[b], unsigned(j + 1), sy, flag, tid) && ok;
+    // Needs L_jj and the diagonal blocks of T_j only (announced with G, a factorization before the full T_j): both panel
+    // blocks L_ij = A_ij L_jj^-T, L_kj = A_kj L_jj^-T come from the register-resident strip solve.
+    ChainWaitList wl;
+    wl.sleep = poll_sleep;
+    wl.first_is_step = true;
+    wl.add(&sy->G[b], unsigned(j + 1));
     if (j >= 1) {
       int pU, a_, b_;
       chain_counts(nb, with_x, j - 1, pU, a_, b_);
-      if (pU > 0) ok = chain_wait(&sy->U[b][j - 1], unsigned(pU), sy, flag, tid) && ok;
+      if (pU > 0) wl.add(&sy->U[b][j - 1], unsigned(pU));
     }
+    ok = chain_wait(wl, sy, flag, tid) && ok;
     const int item = q + 1;
     int ii = int((sqrtf(8.0f * float(item) + 1.0f) - 1.0f) * 0.5f);
     while (ii * (ii + 1) / 2 > item) --ii;
@@ -873,25 +1117,37 @@ __device__ __forceinline__ void chain_helper(const CholInvBatch& bt, const Chain
     const int i = j + 1 + ii, k = j + 1 + kk;
     const int64_t ri = int64_t(i) * CB, rk = int64_t(k) * CB;
     const int rows_i = int(min<int64_t>(CB, d - ri)), rows_k = int(min<int64_t>(CB, d - rk));
-    load_tile<false>(P, A + ri * lda + cj, lda, rows_i, CB, tid);
-    if (k != i) load_tile<false>(Q, A + rk * lda + cj, lda, rows_k, CB, tid);
-    load_tile<false>(TT, Tj, CB, CB, CB, tid);
-    __syncthreads();
-    v4f64 a1[4], a2[4];
-    acc_zero(a1);
-    tile_mm<false, false>(P, TT, w, lane, a1);            // L_ij = A_ij T_j
-    if (k != i) {
-      acc_zero(a2);
-      tile_mm<false, false>(Q, TT, w, lane, a2);          // L_kj = A_kj T_j
+    double* LsT = lds4;                                   // L_jj as the factor image Ls[col][row]
+    double* XsT = TT;                                     // T_j (its diagonal blocks are what the solve reads)
+    // the tile being updated is requested with the operands: its loads fly under the products
+    double cur[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int rr = 16 * w + (lane >> 4) + 4 * rg, cc = 16 * t + (lane & 15);
+        cur[t][rg] = (rr < rows_i && cc < rows_k) ? ld_shared(A + (ri + rr) * lda + rk + cc) : 0.0;
+      }
+    load_tile_shared<false>(P, A + ri * lda + cj, lda, rows_i, CB, tid);
+    if (k != i) load_tile_shared<false>(Q, A + rk * lda + cj, lda, rows_k, CB, tid);
+    {
+      // L_jj: lower triangle from memory, identity beyond the matrix (a partial last block never is block j of a link)
+      TileRegs tl;
+      const int c = tid & 63, r0 = tid >> 6;
+#pragma unroll
+      for (int qq = 0; qq < 16; ++qq) {
+        const int r = r0 + 4 * qq;
+        tl.v[qq] = c <= r ? ld_shared(L + (cj + r) * ldl + cj + c) : 0.0;
+      }
+      store_tile<true>(LsT, tl, tid);                     // Ls[c][r] = L[r][c]
     }
+    load_tile_shared<false>(XsT, Tj, CB, CB, CB, tid);
     __syncthreads();
-    acc_to_lds(a1, P, w, lane, 1.0);
-    if (k != i) acc_to_lds(a2, Q, w, lane, 1.0);
+    solve_strip_LT(P, LsT, XsT, P, w, lane);              // in place: a strip's rows belong to one wave
+    if (k != i) solve_strip_LT(Q, LsT, XsT, Q, w, lane);
     __syncthreads();
-    if (k == j + 1) {                                     // exactly one tile per block row writes L_ij
-      const int c = tid & 63;
-      for (int rr = tid >> 6; rr < rows_i; rr += 4) L[(ri + rr) * ldl + cj + c] = P[rr * CLD + c];
-    }
+    if (k == j + 1) store_rows_shared(L + ri * ldl + cj, ldl, P, rows_i, tid, 256);   // exactly one tile per block row writes L_ij
+    if (k == j + 1 && i == j + 2) store_rows_shared(L + rk * ldl + cj, ldl, Q, rows_k, tid, 256);   // ... and this one the chain's own L_{j+1,j}
     v4f64 u[4];
     acc_zero(u);
     tile_mm<false, true>(P, k != i ? Q : P, w, lane, u);  // L_ij L_kj'
@@ -900,27 +1156,28 @@ __device__ __forceinline__ void chain_helper(const CholInvBatch& bt, const Chain
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         const int rr = 16 * w + (lane >> 4) + 4 * rg, cc = 16 * t + (lane & 15);
-        if (rr < rows_i && cc < rows_k) {
-          double* p = A + (ri + rr) * lda + rk + cc;
-          *p -= u[t][rg];
-        }
+        if (rr < rows_i && cc < rows_k) st_shared(A + (ri + rr) * lda + rk + cc, cur[t][rg] - u[t][rg]);
       }
     chain_publish_add(&sy->U[b][j], tid);
   } else if (q < hU + nXT) {
     // ---- XT(j, k): X_jk = -T_j' S_jk, X_jj = T_j' ----
     const int k = q - hU;
     const int rows_j = int(min<int64_t>(CB, d - cj));
-    ok = chain_wait(&sy->F[b], unsigned(j + 1), sy, flag, tid) && ok;
+    ChainWaitList wl;
+    wl.sleep = poll_sleep;
+    wl.first_is_step = true;
+    wl.add(&sy->F[b], unsigned(j + 1));
+    if (k != j) wl.add(&sy->XS[b][j], unsigned(j));
+    ok = chain_wait(wl, sy, flag, tid) && ok;
     if (k == j) {
-      load_tile<true>(P, Tj, CB, CB, CB, tid);
+      load_tile_shared<true>(P, Tj, CB, CB, CB, tid);
       __syncthreads();
       const int c = tid & 63;
       for (int rr = tid >> 6; rr < rows_j; rr += 4)
-        if (c < rows_j) X[(cj + rr) * ldx + cj + c] = P[rr * CLD + c];
+        if (c < rows_j) st_shared(X + (cj + rr) * ldx + cj + c, P[rr * CLD + c]);
     } else {
-      ok = chain_wait(&sy->XS[b][j], unsigned(j), sy, flag, tid) && ok;
-      load_tile<false>(P, X + cj * ldx + int64_t(k) * CB, ldx, rows_j, CB, tid);     // S_jk
-      load_tile<false>(TT, Tj, CB, CB, CB, tid);
+      load_tile_shared<false>(P, X + cj * ldx + int64_t(k) * CB, ldx, rows_j, CB, tid);     // S_jk
+      load_tile_shared<false>(TT, Tj, CB, CB, CB, tid);
       __syncthreads();
       v4f64 o[4];
       acc_zero(o);
@@ -930,7 +1187,7 @@ __device__ __forceinline__ void chain_helper(const CholInvBatch& bt, const Chain
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
           const int rr = 16 * w + (lane >> 4) + 4 * rg, cc = 16 * t + (lane & 15);
-          if (rr < rows_j) X[(cj + rr) * ldx + int64_t(k) * CB + cc] = -o[t][rg];
+          if (rr < rows_j) st_shared(X + (cj + rr) * ldx + int64_t(k) * CB + cc, -o[t][rg]);
         }
     }
     chain_publish_add(&sy->XR[b][j], tid);
@@ -940,14 +1197,19 @@ __device__ __forceinline__ void chain_helper(const CholInvBatch& bt, const Chain
     const int i = j + 1;
     const int64_t ri = int64_t(i) * CB;
     const int rows_i = int(min<int64_t>(CB, d - ri));
-    ok = chain_wait(&sy->G[b], unsigned(i), sy, flag, tid) && ok;           // L_{i,i-1} (and, through the chain, every L_it)
-    ok = chain_wait(&sy->XR[b][j], unsigned(j + 1), sy, flag, tid) && ok;   // rows <= j of X
+    ChainWaitList wl;
+    wl.sleep = poll_sleep;
+    wl.first_is_step = true;
+    wl.add(&sy->G[b], unsigned(i));           // the chain has passed link j (every L_it, t < j, is final) and stored L_{i,j} if it does so itself
+    wl.add(&sy->XR[b][j], unsigned(j + 1));   // rows <= j of X
+    if (hU > 0) wl.add(&sy->U[b][j], unsigned(hU));   // L_{i,j} written by the trailing tile (j+2, j+1) of this link
+    ok = chain_wait(wl, sy, flag, tid) && ok;
     v4f64 sacc[4];
     acc_zero(sacc);
     TileRegs ra, rb;
     auto fetch = [&](int t) {
-      fetch_tile(ra, L + ri * ldl + int64_t(t) * CB, ldl, rows_i, CB, tid);                      // L_it
-      fetch_tile(rb, X + int64_t(t) * CB * ldx + int64_t(k) * CB, ldx, CB, CB, tid);             // X_tk
+      fetch_tile_shared(ra, L + ri * ldl + int64_t(t) * CB, ldl, rows_i, CB, tid);                      // L_it
+      fetch_tile_shared(rb, X + int64_t(t) * CB * ldx + int64_t(k) * CB, ldx, CB, CB, tid);             // X_tk
     };
     auto stash = [&](int buf) {
       store_tile<false>(lds4 + buf * 2 * CTILE, ra, tid);
@@ -970,7 +1232,7 @@ __device__ __forceinline__ void chain_helper(const CholInvBatch& bt, const Chain
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         const int rr = 16 * w + (lane >> 4) + 4 * rg, cc = 16 * t + (lane & 15);
-        if (rr < rows_i) X[(ri + rr) * ldx + int64_t(k) * CB + cc] = sacc[t][rg];
+        if (rr < rows_i) st_shared(X + (ri + rr) * ldx + int64_t(k) * CB + cc, sacc[t][rg]);
       }
     chain_publish_add(&sy->XS[b][i], tid);
   }
@@ -978,7 +1240,8 @@ __device__ __forceinline__ void chain_helper(const CholInvBatch& bt, const Chain
 }
 
 template <int FORM>
-__global__ __launch_bounds__(256) void k_cholinv_chain(CholInvBatch bt, ChainPlan plan, ChainSync* __restrict__ sy, int* __restrict__ info) {
+__global__ __launch_bounds__(256) void k_cholinv_chain(CholInvBatch bt, ChainPlan plan, ChainSync* __restrict__ sy, int* __restrict__ info,
+                                                       unsigned long long* __restrict__ dbg) {
   extern __shared__ __attribute__((aligned(16))) char ci_smem[];
   double* lds4 = reinterpret_cast<double*>(ci_smem);          // extra tile, then the step kernels' layout
   double* lds = lds4 + CTILE;
@@ -990,17 +1253,35 @@ __global__ __launch_bounds__(256) void k_cholinv_chain(CholInvBatch bt, ChainPla
     __syncthreads();
     const int ticket = flags[3];
     if (ticket >= plan.total) break;
-    if (ticket < bt.count) chain_matrix<FORM>(bt, ticket, sy, info, lds, flags + 2, tid);
-    else chain_helper(bt, plan, ticket - bt.count, sy, info, lds4, flags + 2, tid);
+    if (ticket < bt.count) {
+      const int b = ticket;
+      chain_matrix<FORM>(bt.d[b], bt.lda[b], bt.ldl[b], bt.A[b], bt.L[b], bt.T[b], bt.X[b] != nullptr, b, sy, info, lds4, flags + 2, tid, dbg);
+    } else {
+      int q = ticket - bt.count;
+      int j = 0;
+      while (j + 1 < plan.nbmax && q >= plan.link_first[j + 1]) ++j;
+      q -= plan.link_first[j];
+      int b = 0, hU = 0, nXT = 0, nXS = 0, nb = 0;
+      for (;; ++b) {
+        nb = int((bt.d[b] + CB - 1) / CB);
+        chain_counts(nb, bt.X[b] != nullptr, j, hU, nXT, nXS);
+        const int tot = hU + nXT + nXS;
+        if (q < tot || b + 1 >= bt.count) break;
+        q -= tot;
+      }
+      chain_helper(j, q, hU, nXT, nb, bt.X[b] != nullptr, bt.d[b], bt.lda[b], bt.ldl[b], bt.ldx[b], bt.A[b], bt.L[b], bt.X[b],
+                   bt.T[b] + int64_t(j) * CB * CB, b, plan.poll_sleep, sy, info, lds4, flags + 2, tid);
+    }
   }
   // the last workgroup to leave clears the sync block for the next launch (nobody reads or writes it any more)
-  __threadfence();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (tid == 0) flags[3] = __hip_atomic_fetch_add(&sy->done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
+  if (tid == 0) flags[3] = __hip_atomic_fetch_add(&sy->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
   __syncthreads();
   if (flags[3]) {
     unsigned* wds = reinterpret_cast<unsigned*>(sy);
-    for (int e = tid; e < int(sizeof(ChainSync) / sizeof(unsigned)); e += 256) wds[e] = 0u;
+    for (int e = tid; e < int(sizeof(ChainSync) / sizeof(unsigned)); e += 256)
+      __hip_atomic_store(wds + e, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -1025,7 +1306,9 @@ static void cholinv_attr_once() {
 }
 
 // CCZ_CHOLINV_MFMA: 0 shift-register (two-wave) form of the 64 x 64 factorization, 1 MFMA form with 4-column panels
-// (rounds 2-4), 2 (default) MFMA form with 16-column panels
+// (rounds 2-4: 30.4k shader cycles per block inside the chain kernel), 2 (default) MFMA form with 16-column panels (24.3k).
+// Either way ONE wave issues ~3000 instructions per block: a dependent fp64 operation costs 4-8 cycles, not the 32 that
+// rounds 2-4 designed around (tools/probes/lat_probe.hip: that probe timed a loop branch) -- the block is issue-bound.
 static int cholinv_form() {
   static const int form = [] { const char* e = getenv("CCZ_CHOLINV_MFMA"); const int v = e ? atoi(e) : 2; return v < 0 || v > 2 ? 2 : v; }();
   return form;
@@ -1070,15 +1353,40 @@ static bool chain_launch(ccz_ctx* c, const CholInvBatch& bt, int nbmax, int* inf
   }
   plan.link_first[nbmax] = total;
   plan.total = total + bt.count;
+  static const int sleep_env = [] { const char* e = getenv("CCZ_CHAIN_SLEEP"); return e ? std::max(1, atoi(e)) : 1; }();
+  plan.poll_sleep = sleep_env;
   ChainSync* sy = chain_sync_for(c);
   if (!sy) return false;
   Impl* im = impl(c);
   const int cap = im->chain_cap > 0 ? im->chain_cap : std::max(wgs_env, 2);
   // at least one helper workgroup next to the chain workgroups (they never leave their matrix)
   const int grid = std::min(plan.total, std::max(cap, bt.count + 1));
-  if (form == 2) hipLaunchKernelGGL(k_cholinv_chain<2>, dim3(grid), dim3(256), CHAIN_LDS, stream(c), bt, plan, sy, info_dev);
-  else hipLaunchKernelGGL(k_cholinv_chain<1>, dim3(grid), dim3(256), CHAIN_LDS, stream(c), bt, plan, sy, info_dev);
+  // CCZ_CHAIN_DEBUG=1: shader-clock stamps of matrix 0's chain workgroup, printed per launch (synchronises: measurement only)
+  static const int debug = [] { const char* e = getenv("CCZ_CHAIN_DEBUG"); return e ? atoi(e) : 0; }();
+  unsigned long long* dbg = nullptr;
+  if (debug) {
+    if (!im->chain_dbg) CCZ_HIP(hipMalloc(&im->chain_dbg, 8 * (CH_MAXNB + 1) * sizeof(unsigned long long)));
+    dbg = static_cast<unsigned long long*>(im->chain_dbg);
+    CCZ_HIP(hipMemsetAsync(dbg, 0, 8 * (CH_MAXNB + 1) * sizeof(unsigned long long), stream(c)));
+  }
+  if (form == 2) hipLaunchKernelGGL(k_cholinv_chain<2>, dim3(grid), dim3(256), CHAIN_LDS, stream(c), bt, plan, sy, info_dev, dbg);
+  else hipLaunchKernelGGL(k_cholinv_chain<1>, dim3(grid), dim3(256), CHAIN_LDS, stream(c), bt, plan, sy, info_dev, dbg);
   CCZ_LAUNCH_CHECK();
+  if (debug) {
+    std::vector<unsigned long long> hst(size_t(8) * (CH_MAXNB + 1));
+    CCZ_HIP(hipStreamSynchronize(stream(c)));
+    CCZ_HIP(hipMemcpy(hst.data(), dbg, hst.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    const int nb0 = int((bt.d[0] + CB - 1) / CB);
+    fprintf(stderr, "[ccz chain] grid %d, %d items, matrix 0: %d links; cycles since the launch's first stamp\n"
+            "  link:   start   phaseA    tiles     L_ij     fork |   factored published   joined\n", grid, plan.total, nb0);
+    const unsigned long long t0 = hst[0];
+    for (int j = 0; j < nb0; ++j) {
+      const unsigned long long* r = hst.data() + 8 * (j + 1);
+      fprintf(stderr, "  %4d: %7lld %8lld %8lld %8lld %8lld | %8lld %8lld %8lld\n", j, (long long)(r[0] - t0), (long long)(r[1] - t0),
+              (long long)(r[2] - t0), (long long)(r[3] - t0), (long long)(r[4] - t0), (long long)(r[5] - t0), (long long)(r[6] - t0),
+              (long long)(r[7] - t0));
+    }
+  }
   return true;
 }
 

@@ -822,25 +822,24 @@ __global__ __launch_bounds__(256) void k_colsum_pilot(ColsumViews cv, int64_t n,
       a2 += double(X[(r + 2) * ld]); a3 += double(X[(r + 3) * ld]);
     }
     for (; r < r1; ++r) a0 += double(X[r * ld]);
-    part[int64_t(blockIdx.y) * D + j] = (a0 + a1) + (a2 + a3);
+    st_shared(part + int64_t(blockIdx.y) * D + j, (a0 + a1) + (a2 + a3));     // write-through: read by another workgroup
   }
-  __threadfence();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0)
-    last = __hip_atomic_fetch_add(counters + blockIdx.x, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.y - 1 ? 1 : 0;
+    last = __hip_atomic_fetch_add(counters + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.y - 1 ? 1 : 0;
   __syncthreads();
   if (!last) return;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  if (threadIdx.x == 0) counters[blockIdx.x] = 0u;           // ready for the next launch
+  if (threadIdx.x == 0) __hip_atomic_store(counters + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
   if (j >= D) return;
   double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
   int rb = 0;
   const int nrb = int(gridDim.y);
   for (; rb + 3 < nrb; rb += 4) {
-    t0 += part[int64_t(rb) * D + j]; t1 += part[int64_t(rb + 1) * D + j];
-    t2 += part[int64_t(rb + 2) * D + j]; t3 += part[int64_t(rb + 3) * D + j];
+    t0 += ld_shared(part + int64_t(rb) * D + j); t1 += ld_shared(part + int64_t(rb + 1) * D + j);
+    t2 += ld_shared(part + int64_t(rb + 2) * D + j); t3 += ld_shared(part + int64_t(rb + 3) * D + j);
   }
-  for (; rb < nrb; ++rb) t0 += part[int64_t(rb) * D + j];
+  for (; rb < nrb; ++rb) t0 += ld_shared(part + int64_t(rb) * D + j);
   const double sj = (t0 + t1) + (t2 + t3);
   sums[j] = sj;
   pilot[j] = float(sj / double(n));

@@ -73,6 +73,7 @@ struct Impl {
   // workgroups (set by callers that run throughput work on another stream next to the chain)
   std::vector<std::pair<void*, void*>> chain_sync;
   int chain_cap = 0;
+  void* chain_dbg = nullptr;             // CCZ_CHAIN_DEBUG stamps
   unsigned* colsum_counters = nullptr;   // gram.hip: arrival counters of k_colsum_pilot (64 words, zero between launches)
   // comm.hip: the RCCL communicator of this handle's device (ncclComm_t), its size and this handle's rank
   void* comm = nullptr;
@@ -91,6 +92,36 @@ inline hipStream_t stream(ccz_ctx* c) { return static_cast<hipStream_t>(c->strea
   } while (0)
 
 #define CCZ_LAUNCH_CHECK() CCZ_HIP(hipGetLastError())
+
+#ifdef __HIPCC__
+// ---- words that ANOTHER workgroup of the same launch writes or reads ----
+// The per-XCD L2s are not coherent with each other and a CU's L1 is never refreshed by other CUs' stores
+// (/opt/skills/guides/MI355X_MICROARCH.md, "inter-workgroup visibility").  Instead of release / acquire fences
+// (buffer_wbl2 + buffer_inv: 1.7 - 6.5 us EACH, per workgroup and hand-over) every shared word is stored write-through
+// and loaded past the L1 with 8-byte agent-scope accesses (global_store / global_load ... sc1) -- the guide's
+// "{8-B agent atomics both sides}" form; a hand-over is then: every storing wave drains its stores (s_waitcnt vmcnt(0)),
+// barrier, ONE lane updates the progress word; the consumer polls that word and loads.
+typedef unsigned long long __attribute__((address_space(1)))* gu64_ptr;
+typedef unsigned __attribute__((address_space(1)))* gu32_ptr;
+__device__ __forceinline__ double ld_shared(const double* p) {
+  const unsigned long long u = __hip_atomic_load((gu64_ptr)(reinterpret_cast<uintptr_t>(p)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __longlong_as_double((long long)u);
+}
+__device__ __forceinline__ void st_shared(double* p, double v) {
+  __hip_atomic_store((gu64_ptr)(reinterpret_cast<uintptr_t>(p)), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+// two consecutive doubles as ONE 16-byte write-through store (p 16-byte aligned): an 8-byte sc1 store is one fabric write per
+// lane and costs a wave ~120 cycles to issue (measured: 3100 of them held the chain up for 5.8k cycles per link); the 16-byte
+// form moves twice the bytes per instruction at the plain-store rate (MI355X_MICROARCH.md, "stores of each flavour")
+typedef unsigned int ccz_v4u32 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_shared2(double* p, double a, double b) {
+  ccz_v4u32 v;
+  v[0] = unsigned(__double2loint(a)); v[1] = unsigned(__double2hiint(a));
+  v[2] = unsigned(__double2loint(b)); v[3] = unsigned(__double2hiint(b));
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+}
+#endif
 
 // ops_hip.hip: capture-once / replay-later for launch-bound fixed sequences, keyed on shapes AND pointers
 uint64_t graph_key_mix(uint64_t h, uint64_t v);

@@ -75,46 +75,84 @@ __global__ void k_loss_prep(const double* __restrict__ G, const double* __restri
 // centred form
 //   sum_r (x_ri - m_i)(x_rj - m_j) = sum_r (x_ri - p_i)(x_rj - p_j) - n (m_i - p_i)(m_j - p_j)       (m = s / n)
 // and Ce, the views' diagonal blocks, the mean, the cleared split-K destinations and accumulators all leave this ONE
-// launch (it replaces k_gram_reduce, k_pilot_fixup, k_vec_add, two fills and k_loss_prep).  grid (256, ntiles) x 256:
-// one thread per element of a 256 x 256 tile; tiles cover the upper triangle, every value is written to (i, j) and (j, i).
+// launch (rounds 2-4: k_gram_reduce, k_pilot_fixup, k_vec_add, two fills and k_loss_prep).  grid (64, ntiles) x 256: one
+// workgroup per 32 x 32 sub-block of a 256 x 256 tile (four elements per thread: the 64 MB of partial sums of a DCCA batch
+// want many loads in flight).  Tiles cover the upper triangle; the mirrored half of every matrix is written from an LDS
+// transpose, so both halves go out as full 256-byte rows.
+constexpr int PSB = 32;
 __global__ __launch_bounds__(256) void k_loss_prep_partials(const float* __restrict__ partial, const GramTile* __restrict__ tiles, int ntiles,
                                                             int64_t ksplit, const double* __restrict__ s, const float* __restrict__ pilot,
                                                             int64_t D, double n_rows, double inv_nm1, double eps, double* __restrict__ Ce,
                                                             double* __restrict__ mean, PrepArgs pa, double* __restrict__ acc,
                                                             double* __restrict__ bias) {
+  __shared__ double tr[PSB][PSB + 1];
   const int tile = blockIdx.y;
-  const int e = blockIdx.x * 256 + threadIdx.x;            // element of the 256 x 256 tile
   if (tile == 0) {
-    if (e < D) {
+    for (int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x; e < D; e += 64 * 256) {
       mean[e] = s[e] / n_rows;
       if (bias) bias[e] = 0.0;
     }
-    if (e == 0) acc[0] = 0.0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) acc[0] = 0.0;
   }
   const GramTile t = tiles[tile];
-  const int i = e >> 8, j = e & 255;
-  if (i >= t.wa || j >= t.wb) return;
-  if (t.diag && j < i) return;                             // diagonal tiles hold both halves: the upper one is used
-  double g = 0.0;
-  const float* p = partial + int64_t(tile) * 65536 + e;
-  for (int64_t ch = 0; ch < ksplit; ++ch) g += double(p[ch * int64_t(ntiles) * 65536]);
-  const int64_t gi = t.out_row + i, gj = t.out_col + j;
-  const double di = s[gi] / n_rows - double(pilot[gi]), dj = s[gj] / n_rows - double(pilot[gj]);
-  double v = (g - n_rows * di * dj) * inv_nm1;
-  if (gi == gj) v += eps;
-  const int64_t e1 = gi * D + gj, e2 = gj * D + gi;
-  Ce[e1] = v;
-  Ce[e2] = v;
-  if (pa.zero_a) { pa.zero_a[e1] = 0.0; pa.zero_a[e2] = 0.0; }
-  if (pa.zero_b) { pa.zero_b[e1] = 0.0; pa.zero_b[e2] = 0.0; }
-  int a = 0;
-  while (a + 1 < pa.m && gi >= pa.off[a + 1]) ++a;
-  if (gj < pa.off[a + 1]) {                                // gi <= gj: same view block
-    const int64_t da = pa.off[a + 1] - pa.off[a];
-    const int64_t q1 = (gi - pa.off[a]) * da + (gj - pa.off[a]), q2 = (gj - pa.off[a]) * da + (gi - pa.off[a]);
-    pa.work[a][q1] = v;
-    pa.work[a][q2] = v;
-    if (pa.zero_v[a]) { pa.zero_v[a][q1] = 0.0; pa.zero_v[a][q2] = 0.0; }
+  const int si = blockIdx.x >> 3, sj = blockIdx.x & 7;
+  if (t.diag && si > sj) return;                           // diagonal tiles hold both halves: the upper sub-blocks are used
+  if (si * PSB >= t.wa || sj * PSB >= t.wb) return;
+  const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+  const int64_t gi0 = t.out_row + si * PSB, gj0 = t.out_col + sj * PSB;
+  const int vi = t.wa - si * PSB, vj = t.wb - sj * PSB;    // valid rows / columns of this sub-block
+  int a = 0;                                               // the view of this sub-block's rows (a sub-block never straddles views:
+  while (a + 1 < pa.m && gi0 >= pa.off[a + 1]) ++a;        // panels are cut per view)
+  const bool same_view = gj0 < pa.off[a + 1];
+  const int64_t da = pa.off[a + 1] - pa.off[a], li0 = gi0 - pa.off[a], lj0 = gj0 - pa.off[a];
+  const double dj = c < vj ? s[gj0 + c] / n_rows - double(pilot[gj0 + c]) : 0.0;
+  double g[4] = {0.0, 0.0, 0.0, 0.0};
+  {
+    const float* p = partial + int64_t(tile) * 65536 + (si * PSB + r0) * 256 + sj * PSB + c;
+    const int64_t cs = int64_t(ntiles) * 65536;
+    for (int64_t ch = 0; ch < ksplit; ++ch) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (r0 + 8 * k < vi && c < vj) g[k] += double(p[ch * cs + 8 * k * 256]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + 8 * k;
+    double v = 0.0;
+    if (r < vi && c < vj) {
+      const double di = s[gi0 + r] / n_rows - double(pilot[gi0 + r]);
+      v = (g[k] - n_rows * di * dj) * inv_nm1;
+      if (gi0 + r == gj0 + c) v += eps;
+      const int64_t e1 = (gi0 + r) * D + gj0 + c;
+      Ce[e1] = v;
+      if (pa.zero_a) pa.zero_a[e1] = 0.0;
+      if (pa.zero_b) pa.zero_b[e1] = 0.0;
+      if (same_view) {
+        const int64_t q1 = (li0 + r) * da + lj0 + c;
+        pa.work[a][q1] = v;
+        if (pa.zero_v[a]) pa.zero_v[a][q1] = 0.0;
+      }
+    }
+    tr[r][c] = v;
+  }
+  if (t.diag && si == sj) return;                          // symmetric sub-block: the direct pass wrote both halves
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + 8 * k;                              // row of the MIRRORED sub-block = column r of this one
+    if (r < vj && c < vi) {
+      const double v = tr[c][r];
+      const int64_t e2 = (gj0 + r) * D + gi0 + c;
+      Ce[e2] = v;
+      if (pa.zero_a) pa.zero_a[e2] = 0.0;
+      if (pa.zero_b) pa.zero_b[e2] = 0.0;
+      if (same_view) {
+        const int64_t q2 = (lj0 + r) * da + li0 + c;
+        pa.work[a][q2] = v;
+        if (pa.zero_v[a]) pa.zero_v[a][q2] = 0.0;
+      }
+    }
   }
 }
 
@@ -250,7 +288,7 @@ void pair_core(ccz_ctx* c, const double* mom, int64_t n, const int64_t* dims, in
   // (split-K destinations of the product stages below are cleared by the same pass -- see there)
   int64_t dmin = dims[0];
   for (int a = 1; a < m; ++a) dmin = std::min(dmin, dims[a]);
-  static const int split_env = [] { const char* e = getenv("CCZ_LOSS_SPLITK"); return e ? atoi(e) : 4; }();
+  static const int split_env = [] { const char* e = getenv("CCZ_LOSS_SPLITK"); return e ? atoi(e) : 2; }();   // 2: 256 workgroups per two-view stage, half the atomics of 4 (profiles/r05_loss_c4.md)
   const int ks = (narrow && dmin >= 256 && split_env > 1) ? split_env : 1;
   if (ks > 1) {
     for (int a = 0; a < m; ++a) pa.zero_v[a] = Sinv[a].get();
@@ -258,7 +296,7 @@ void pair_core(ccz_ctx* c, const double* mom, int64_t n, const int64_t* dims, in
     pa.zero_b = want_grad ? gamma_dev : nullptr;
   }
   if (gp)
-    hipLaunchKernelGGL(k_loss_prep_partials, dim3(256, (unsigned)gp->ntiles), dim3(256), 0, st, gp->partial, gp->tiles, gp->ntiles, gp->ksplit,
+    hipLaunchKernelGGL(k_loss_prep_partials, dim3(64, (unsigned)gp->ntiles), dim3(256), 0, st, gp->partial, gp->tiles, gp->ntiles, gp->ksplit,
                        gp->colsum, gp->pilot, D, double(n), inv, eps, Ce.get(), mean_dev, pa, acc_dev, want_grad ? bias_dev : nullptr);
   else
     hipLaunchKernelGGL(k_loss_prep, dim3((unsigned)std::min<int64_t>((D * D + 255) / 256, 4096)), dim3(256), 0, st, mom, mom + D * D, D,

@@ -1414,7 +1414,13 @@ static void potrf_lower_batched_sb(ccz_ctx* c, int count, double* const* A, cons
         CCZ_HIP(hipStreamWaitEvent(s_aux, im->aux_ev[0], 0));
         {
           StreamSwap sw(c, s_aux);
-          factor(J + 1);
+          // the chain kernel's helper workgroups spin while they wait: next to the update GEMMs of the main stream they get a
+          // bounded share of the chip (CCZ_CHAIN_WGS_LA, default 64 workgroups)
+          static const int la_cap = [] { const char* e = getenv("CCZ_CHAIN_WGS_LA"); return e ? atoi(e) : 64; }();
+          const int cap0 = im->chain_cap;
+          im->chain_cap = la_cap;
+          try { factor(J + 1); } catch (...) { im->chain_cap = cap0; throw; }
+          im->chain_cap = cap0;
         }
         CCZ_HIP(hipEventRecord(im->aux_ev[1], s_aux));
       } else {

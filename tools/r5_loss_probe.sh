@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5, loss path: parity of the new kernels first, then the configs[3] timings of every A/B switch, then the kernel
-# trace.  Everything lands in gpurun_out/r5a/ (small text files).
-R=$PWD; O=$R/gpurun_out/r5a; mkdir -p $O; export TMPDIR=/tmp
+# trace.  Everything lands in gpurun_out/r5c/ (small text files).
+R=$PWD; O=$R/gpurun_out/r5c; mkdir -p $O; export TMPDIR=/tmp
 cd $R
 echo "== round-5 tests" > $O/summary.txt
 timeout 1200 python -m pytest tests/test_gpu_round5.py -x -q -m gpu --durations=8 > $O/t_round5.log 2>&1; echo "round5 rc=$?" >> $O/summary.txt
@@ -17,9 +17,10 @@ run nochain_p4 CCZ_CHOLINV_CHAIN=0 CCZ_CHOLINV_MFMA=1
 run chain_p4 CCZ_CHOLINV_MFMA=1
 run nofast CCZ_LOSS_FAST=0
 run splitk1 CCZ_LOSS_SPLITK=1
-run splitk2 CCZ_LOSS_SPLITK=2
+run splitk4 CCZ_LOSS_SPLITK=4
 run wgs64 CCZ_CHAIN_WGS=64
 run wgs250 CCZ_CHAIN_WGS=250
+CCZ_CHAIN_DEBUG=1 timeout 120 python tools/loss_profile.py 8192 512 3 2> $O/chain_debug.txt > /dev/null; tail -12 $O/chain_debug.txt >> $O/summary.txt
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/p_loss -o loss -- python $R/tools/loss_profile.py 8192 512 20 > $O/loss_profile.log 2>&1
 f=$(find /tmp/p_loss -name "*results.db" | head -1); python $R/tools/rocpd_stats.py $f > $O/r05_loss_c4.md; tail -2 $O/loss_profile.log >> $O/r05_loss_c4.md; rm -rf /tmp/p_loss
