@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--cpu-runs", type=int, default=3, help="repeats of the rCCA CPU comparator at n = 2 d (a run is ~25 s; the median is reported)")
     ap.add_argument("--no-gates", action="store_true", help="skip the parity gates of the extras (the headline gate always runs)")
     ap.add_argument("--only", default="", help="comma-separated subset of the extras to run (dcca, grid, host, metric_loss, configs, evd)")
+    ap.add_argument("--transport", choices=["torch", "ccz"], default=os.environ.get("CCZ_BENCH_TRANSPORT", "torch"),
+                    help="exchange step of the sharded fit: torch.distributed (nccl = RCCL) all-reduces, or libccz's own RCCL collective "
+                         "behind the C ABI (ccz_moments_exchange); both run the two-part exchange that overlaps the factorization")
     ap.add_argument("--launch-test", action="store_true",
                     help="(CPU test of the launcher) rendezvous over gloo, one all-reduce, ONE JSON line on rank 0; no GPU work")
     return ap.parse_args()
@@ -353,7 +356,9 @@ def cpu_baseline(n_full, d, k, sample_rows=0, runs=3):
 def cpu_c2_whole(k=32, c=0.1, n=100_000, d=1024):
     """BASELINE configs[1] WHOLE on the host, no extrapolation: the oracle's reference-form
     ``rcca_weights`` (cca_zoo/linear/_rcca.py:69-101) on the very views the GPU fits -- n = 1e5, 2 x 1024, float32 --
-    timed, and the two solutions compared per column (sign-aligned, float32 bar 1e-3) and by score."""
+    timed, and the two solutions compared by subspace and score.  JointData's 32 correlations lie within 6e-6 of each
+    other (no single column is defined at the float32 bar), so the per-column 1e-3 bar is exercised on a SECOND data set of
+    the same shape whose correlations are separated: entry ``separated``."""
     import numpy as np
     import torch
 
@@ -363,38 +368,61 @@ def cpu_c2_whole(k=32, c=0.1, n=100_000, d=1024):
 
     affinity, quota = host_cores()
     cores = int(min(affinity, quota)) if quota else affinity
+
+    def compare(views, sep_factor):
+        model = rCCA(latent_dimensions=k, c=c).fit(views)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model = rCCA(latent_dimensions=k, c=c).fit(views)
+        torch.cuda.synchronize()
+        gpu_s = time.perf_counter() - t0
+        host = [v.cpu().numpy() for v in views]
+        gpu_score = np.asarray(model.score(views), dtype=np.float64)
+        try:
+            from threadpoolctl import threadpool_limits
+
+            limiter = threadpool_limits(limits=max(cores, 1))
+        except Exception:
+            limiter = None
+        try:
+            t0 = time.perf_counter()
+            W_ref, means_ref = rf.rcca_weights(host, k, c=c)
+            cpu_s = time.perf_counter() - t0
+        finally:
+            if limiter is not None:
+                limiter.restore_original_limits()
+        agree = weights_agreement(model.weights_, W_ref, model.singular_values_, 1e-3, sep_factor)
+        ref_score = rf.mean_offdiag_corr([h.astype(np.float64) for h in host], W_ref, means_ref)
+        return {"cpu_s": cpu_s, "cpu_fits_per_s": 1.0 / cpu_s, "gpu_fit_s": gpu_s, "gpu_over_cpu": cpu_s / gpu_s,
+                "weights_vs_oracle": agree, "score_max_abs_diff": float(np.abs(gpu_score - np.asarray(ref_score)).max()),
+                "singular_values": [float(model.singular_values_[0]), float(model.singular_values_[-1])],
+                "agree_at_1e-3": bool(agree["ok"])}
+
     jd = JointData(n_views=2, n_samples=1, latent_dimensions=k, n_features=[d, d], random_state=1,
                    latent_scales=list(np.linspace(2.0, 0.5, k)))
     views = jd.sample_device(device="cuda", dtype=torch.float32, n_samples=n, seed=DATA_SEED + 1)
-    model = rCCA(latent_dimensions=k, c=c).fit(views)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    model = rCCA(latent_dimensions=k, c=c).fit(views)
-    torch.cuda.synchronize()
-    gpu_s = time.perf_counter() - t0
-    host = [v.cpu().numpy() for v in views]
-    gpu_score = np.asarray(model.score(views), dtype=np.float64)
+    out = {"config": f"configs[1] whole: rCCA n={n}, 2x{d}, k={k}, c={c}, float32", "cores": max(cores, 1), "extrapolated": False}
+    out.update(compare(views, 100.0))
     del views
     torch.cuda.empty_cache()
-    try:
-        from threadpoolctl import threadpool_limits
-
-        limiter = threadpool_limits(limits=max(cores, 1))
-    except Exception:
-        limiter = None
-    try:
-        t0 = time.perf_counter()
-        W_ref, means_ref = rf.rcca_weights(host, k, c=c)
-        cpu_s = time.perf_counter() - t0
-    finally:
-        if limiter is not None:
-            limiter.restore_original_limits()
-    agree = weights_agreement(model.weights_, W_ref, model.singular_values_, 1e-3)
-    ref_score = rf.mean_offdiag_corr([h.astype(np.float64) for h in host], W_ref, means_ref)
-    return {"config": f"configs[1] whole: rCCA n={n}, 2x{d}, k={k}, c={c}, float32", "cpu_s": cpu_s, "cpu_fits_per_s": 1.0 / cpu_s,
-            "gpu_fit_s": gpu_s, "gpu_over_cpu": cpu_s / gpu_s, "cores": max(cores, 1), "extrapolated": False,
-            "weights_vs_oracle": agree, "score_max_abs_diff": float(np.abs(gpu_score - np.asarray(ref_score)).max()),
-            "agree_at_1e-3": bool(agree["ok"])}
+    # the same shape with population correlations 0.97, 0.948, ... 0.30 (orthonormal loadings of strength rho / (1 - rho) per
+    # latent, unit noise): sample gaps ~2e-2.  A column's first-order error is (moment error ~1e-6 .. 4e-6 for float32
+    # views) / gap, so gaps above 8 x tol leave the 1e-3 bar well-posed per column (the same criterion as
+    # tests/test_gpu_round3.py::test_ns_dimensions_per_column_on_a_separated_spectrum).
+    rho = np.linspace(0.97, 0.30, k)
+    g = torch.Generator(device="cuda").manual_seed(DATA_SEED + 5)
+    amp = torch.as_tensor(np.sqrt(rho / (1.0 - rho)), dtype=torch.float64, device="cuda")
+    loads = []
+    for _ in range(2):
+        q, _ = torch.linalg.qr(torch.randn(d, k, dtype=torch.float64, device="cuda", generator=g))
+        loads.append((q * amp).T.contiguous())
+    z = torch.randn(n, k, dtype=torch.float64, device="cuda", generator=g)
+    sviews = [(z @ L + torch.randn(n, d, dtype=torch.float64, device="cuda", generator=g)).to(torch.float32) for L in loads]
+    del z
+    out["separated"] = compare(sviews, 8.0)
+    out["separated"]["data"] = "orthonormal loadings, population correlations linspace(0.97, 0.30, 32), unit noise, float32"
+    out["agree_at_1e-3"] = bool(out["agree_at_1e-3"] and out["separated"]["agree_at_1e-3"])
+    return out
 
 
 def cpu_mcca_baseline(n_full=1_000_000, d=2048, m=4, k=64, sample_rows=4096):
@@ -586,6 +614,27 @@ def dcca_extra(steps=20, warmup=3, batch=8192, d=512, label="BASELINE configs[3]
                         "note": "algorithmic flops of the whole fwd+bwd (K1 + gradient GEMM) over its wall time"}}
     if gate:
         out["parity_gate"] = loss_parity_gate(z1, z2, 1e-6, loss.item())
+    # stated context, never the target: what a user of the reference sees on THIS GPU -- its own loss (torch.linalg.eigh +
+    # autograd: cca_zoo/deep/objectives.py:61-102 as restated by the oracle) on the same embeddings on cuda, warm, back to back
+    try:
+        from oracle import losses as ol
+
+        a = z1.detach().clone().requires_grad_(True)
+        b = z2.detach().clone().requires_grad_(True)
+        for _ in range(2):
+            ol.cca_loss_autograd(a, b, 1e-6).backward()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            a.grad = None
+            b.grad = None
+            ol.cca_loss_autograd(a, b, 1e-6).backward()
+        torch.cuda.synchronize()
+        out["torch_gpu_ms"] = (time.perf_counter() - t0) / 5 * 1e3
+        out["torch_gpu_note"] = "the oracle's restatement of the reference loss (torch eigh + autograd) on cuda: context, not the target"
+    except Exception as e:                                   # a comparator must never take the measurement down
+        out["torch_gpu_ms"] = None
+        out["torch_gpu_note"] = f"comparator failed: {type(e).__name__}"
     return out
 
 
@@ -779,9 +828,9 @@ def sharded_dcca_extra(n_local, d, world, steps=2, warmup=1):
     return float(t.item())
 
 
-def weights_agreement(W, W_ref, vals, tol):
+def weights_agreement(W, W_ref, vals, tol, sep_factor=100.0):
     """Per-column relative error after sign alignment where the neighbouring canonical correlations are separated by more
-    than 100 x tol; otherwise the residual of W_ref in span(W) -- eigenvectors inside a cluster of
+    than sep_factor x tol (default 100); otherwise the residual of W_ref in span(W) -- eigenvectors inside a cluster of
     nearly equal correlations are only defined up to a rotation of the cluster, in ANY solver at this precision."""
     import numpy as np
 
@@ -791,7 +840,7 @@ def weights_agreement(W, W_ref, vals, tol):
         dv = np.abs(np.diff(vals))
         gap[:-1] = np.minimum(gap[:-1], dv)
         gap[1:] = np.minimum(gap[1:], dv)
-    sep = gap > 100.0 * tol * max(abs(vals[0]), 1e-300)
+    sep = gap > sep_factor * tol * max(abs(vals[0]), 1e-300)
     col, sub = 0.0, 0.0
     for w, r in zip(W, W_ref):
         w, r = np.asarray(w, dtype=np.float64), np.asarray(r, dtype=np.float64)
@@ -839,8 +888,23 @@ def evd_extra(sizes=(512, 1024, 2048, 4096)):
         orth = float(torch.linalg.norm(V @ V.T - torch.eye(d, dtype=torch.float64, device="cuda")))
         good = resid < 1e-11 and orth < 1e-11 and bool(torch.all(w[:-1] >= w[1:]))
         ok = ok and good
+        # stated context, never the target: what the reference itself runs on this GPU at this seam -- torch.linalg.eigh
+        # (hipSOLVER through PyTorch-ROCm; cca_zoo/deep/objectives.py:19) on the same matrix, warm
+        eigh_ms = None
+        try:
+            torch.linalg.eigh(A)
+            torch.cuda.synchronize()
+            te = []
+            for _ in range(2):
+                t0 = time.perf_counter()
+                torch.linalg.eigh(A)
+                torch.cuda.synchronize()
+                te.append((time.perf_counter() - t0) * 1e3)
+            eigh_ms = float(min(te))
+        except Exception:
+            eigh_ms = None
         out[f"syev_{d}"] = {"ms": ms, "first_call_ms": ts[0], "sweeps": sw.value, "nominal_tflops_9d3": 9.0 * d ** 3 / (ms * 1e-3) / 1e12,
-                            "residual": resid, "orthogonality": orth}
+                            "residual": resid, "orthogonality": orth, "torch_eigh_ms": eigh_ms}
         del X, A, V
     for p, q in ((1024, 1024), (4096, 1024)):
         A = torch.randn(p, q, dtype=torch.float64, device="cuda", generator=g)
@@ -862,7 +926,17 @@ def evd_extra(sizes=(512, 1024, 2048, 4096)):
                          torch.linalg.norm(Vt @ Vt.T - torch.eye(r, dtype=torch.float64, device="cuda"))))
         good = rec < 1e-11 and orth < 1e-10
         ok = ok and good
-        out[f"gesv_{p}x{q}"] = {"ms": float(min(ts)), "sweeps": sw.value, "reconstruction": rec, "orthogonality": orth}
+        svd_ms = None
+        try:
+            torch.linalg.svd(A, full_matrices=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            torch.linalg.svd(A, full_matrices=False)
+            torch.cuda.synchronize()
+            svd_ms = (time.perf_counter() - t0) * 1e3
+        except Exception:
+            svd_ms = None
+        out[f"gesv_{p}x{q}"] = {"ms": float(min(ts)), "sweeps": sw.value, "reconstruction": rec, "orthogonality": orth, "torch_svd_ms": svd_ms}
         del A, U, Vt
     torch.cuda.empty_cache()
     out["parity_gate"] = {"ok": bool(ok)}
@@ -1056,10 +1130,20 @@ def main():
     views = jd.sample_device(device=f"cuda:{local}", dtype=tdt, n_samples=n_local, seed=DATA_SEED, row0=lo)
     torch.cuda.synchronize()
     model = CCA(latent_dimensions=a.k)
+    comm = None
+    if distributed and a.transport == "ccz":
+        # libccz's own communicator: rank 0's id travels over the process group that the gates use anyway
+        from cca_zoo_amd import _dist
+
+        idt = torch.zeros(128, dtype=torch.uint8, device=f"cuda:{local}")
+        if rank == 0:
+            idt = torch.tensor(list(h.comm_unique_id()), dtype=torch.uint8, device=f"cuda:{local}")
+        dist.broadcast(idt, 0)
+        comm = _dist.CczComm(h, bytes(idt.cpu().tolist()), world, rank)
 
     def step():
         if distributed:
-            with row_sharded():
+            with row_sharded(group=comm):
                 model.fit(views)
         else:
             model.fit(views)
@@ -1120,6 +1204,9 @@ def main():
                           "host_wait_for_head_ms": float(np.mean(allreduce_ms))}
     k1_ms_per_rank = [float(np.mean(gram_ms))]
     rccl_ranks = 1
+    ccz_comm_ranks = None
+    if comm is not None:
+        ccz_comm_ranks = int(h.comm_info()[0])
     if distributed:
         rccl_ranks = dist.get_world_size()
         gt = torch.zeros(world, dtype=torch.float64, device=f"cuda:{local}")
@@ -1152,7 +1239,8 @@ def main():
         out = {
             "metric": "CCA fit()/sec at n=1e6 d=4096 k=64",
             "value": 1e3 / ms_per_step, "unit": "fit/s",
-            "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
+            "n_gpus": world, "rccl_ranks": rccl_ranks, "transport": (a.transport if distributed else None),
+            "ccz_comm_ranks": ccz_comm_ranks, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
             "step_ms": [round(x, 2) for x in step_ms],
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic (JointData latent-variable model, counter-based generator, drawn in HBM)",
@@ -1229,6 +1317,8 @@ def main():
     else:
         line = None
     if distributed:
+        if comm is not None:
+            comm.close()
         dist.barrier()
         dist.destroy_process_group()
     # RCCL writes its version banner into the C stdout buffer (it would be flushed at exit, AFTER the result).  The

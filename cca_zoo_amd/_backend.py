@@ -103,6 +103,7 @@ SIGNATURES = {
     "ccz_gemm_f64": (_int, [_vp, _int, _int, _i64, _i64, _i64, _dbl, _vp, _i64, _vp, _i64, _dbl, _vp, _i64]),
     "ccz_cca_loss": (_int, [_vp, _int, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _dbl, _vp, _vp, _vp, _i64, _i64]),
     "ccz_pair_loss": (_int, [_vp, _int, C.POINTER(View), _int, _i64, _dbl, _vp, C.POINTER(_vp), _pi64]),
+    "ccz_moments_exchange": (_int, [_vp, _vp, _i64, _pi64, _int, _i64, _pi64]),
     "ccz_pair_loss_state_bytes": (_i64, [_int, _pi64, _int]),
     "ccz_pair_loss_forward": (_int, [_vp, _int, C.POINTER(View), _int, _i64, _dbl, _vp, _vp]),
     "ccz_pair_loss_backward": (_int, [_vp, _int, C.POINTER(View), _int, _i64, _vp, _vp, C.POINTER(_vp), _pi64]),
@@ -343,6 +344,15 @@ class Handle:
     def allreduce_sum_f64(self, ptr, count):
         """In-place float64 SUM over the communicator's ranks, enqueued on the handle's stream."""
         self.check(self.lib.ccz_allreduce_sum_f64(self._h, _ptr(ptr), int(count)))
+
+    def moments_exchange(self, moments_ptr, D, dims, n_local):
+        """The whole exchange step behind the ABI (``ccz_moments_exchange``): returns the global row count; the off-diagonal
+        blocks may still be in flight -- the next solve waits for them on the device."""
+        n_total = C.c_int64(0)
+        dims_a = (C.c_int64 * len(dims))(*[int(d) for d in dims])
+        self.check(self.lib.ccz_moments_exchange(self._h, C.c_void_p(int(moments_ptr)), int(D), dims_a, len(dims), int(n_local),
+                                                 C.byref(n_total)))
+        return int(n_total.value)
 
     def solve_defer(self, event_ptr):
         """The next ``*_solve`` waits (on the device) for this hipEvent before reading off-diagonal moment blocks."""

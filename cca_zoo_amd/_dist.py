@@ -35,31 +35,62 @@ class CczComm:
         handle.comm_init_rank(unique_id, world, rank)
 
     @classmethod
-    def from_file(cls, path, world, rank, handle=None, timeout_s=120.0):
+    def from_file(cls, path, world, rank, handle=None, timeout_s=120.0, tag=None):
+        """Ship the communicator id through ``path`` on a file system every rank sees.  The file carries a 32-byte run tag
+        behind the 128-byte id: ``tag`` (any string; default: the launcher's ``MASTER_ADDR:MASTER_PORT:TORCHELASTIC_RUN_ID``
+        when present) -- readers ignore a file whose tag is not theirs, so an id left behind by an earlier run is never
+        joined.  Rank 0 removes a stale file first and deletes its own in :meth:`close`.  Without a launcher and without
+        ``tag`` the path must be fresh per run."""
+        import hashlib
         import os
         import time
 
         from cca_zoo_amd import _backend
 
         h = handle or _backend.default_handle()
+        if tag is None:
+            tag = ":".join(os.environ.get(k, "") for k in ("MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"))
+        mark = hashlib.sha256(str(tag).encode()).digest()
         if rank == 0:
+            try:
+                os.unlink(path)                            # an id of an earlier run must not be read before ours lands
+            except FileNotFoundError:
+                pass
             uid = h.comm_unique_id()
             tmp = f"{path}.tmp.{os.getpid()}"
             with open(tmp, "wb") as f:
-                f.write(uid)
-            os.replace(tmp, path)                      # atomic: readers never see a partial id
+                f.write(uid + mark)
+            os.replace(tmp, path)                          # atomic: readers never see a partial id
         else:
             t0 = time.time()
-            while not (os.path.exists(path) and os.path.getsize(path) == 128):
-                if time.time() - t0 > timeout_s:
-                    raise TimeoutError(f"no communicator id at {path} after {timeout_s:.0f} s")
-                time.sleep(0.02)
-            with open(path, "rb") as f:
-                uid = f.read()
-        return cls(h, uid, world, rank)
+            uid = None
+            while uid is None:
+                try:
+                    with open(path, "rb") as f:
+                        blob = f.read()
+                    if len(blob) == 160 and blob[128:] == mark:
+                        uid = blob[:128]
+                except FileNotFoundError:
+                    pass
+                if uid is None:
+                    if time.time() - t0 > timeout_s:
+                        raise TimeoutError(f"no communicator id for this run at {path} after {timeout_s:.0f} s")
+                    time.sleep(0.02)
+        comm = cls(h, uid, world, rank)
+        comm._id_file = path if rank == 0 else None
+        return comm
 
     def close(self):
         self.handle.comm_destroy()
+        path = getattr(self, "_id_file", None)
+        if path:
+            import os
+
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
+            self._id_file = None
 
     def allreduce_small(self, values):
         import numpy as np
@@ -125,10 +156,22 @@ def allreduce_moments(buf, group=None):
     anyway (``n`` is a host argument of ``ccz_*_solve``); it also orders the collective before libccz's stream.
     """
     import torch
-    import torch.distributed as dist
 
     if buf.dtype != torch.float64 or buf.dim() != 1 or buf.numel() < 2:
         raise ValueError("moments buffer must be a flat float64 tensor with the row count in its last slot")
+    if isinstance(group, CczComm):
+        # the collective behind the C ABI (the sharded losses inside row_sharded(group=CczComm)): libccz's stream follows
+        # torch's current stream on the device, the all-reduce runs on it, torch's stream follows back
+        if not buf.is_cuda:
+            raise ValueError("a CczComm reduces device buffers")
+        sp = int(torch.cuda.current_stream(buf.device).cuda_stream)
+        h = group.handle
+        h.acquire(sp)
+        h.allreduce_sum_f64(buf.data_ptr(), buf.numel())
+        h.release(sp)
+        return int(round(float(buf[-1].item())))
+    import torch.distributed as dist
+
     dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     return int(round(float(buf[-1].item())))
 

@@ -138,23 +138,16 @@ def compute_moments(views, handle=None, defer_offdiag=False):
     LAST["allreduce_ms"] = 0.0
     n_total = n
     if ccz_comm is not None:
-        # the exchange behind the C ABI (no torch.distributed): the packed blocks layout with the row count in the head's
-        # spare slot, ONE ccz_allreduce_sum_f64 on the handle's stream, one 8-byte read-back for n
+        # the exchange behind the C ABI (no torch.distributed), ONE call: the blocks layout in a buffer the handle keeps, the
+        # row count written on the device, head and tail reduced on the handle's exchange stream, the tail still in flight when
+        # this returns -- the solve waits for it on the device right before its first off-diagonal read (ccz_moments_exchange)
         if ccz_comm.handle is not h:
             raise ValueError("the CczComm of row_sharded() belongs to another handle / device than the views")
-        count = D * (D + 1) // 2 + D + 1
-        n_head = sum(d * (d + 1) // 2 for d in dims) + D + 1
-        packed = h.alloc(count * 8)
         if on_device:
             h.acquire(stream_ptr)
-        h.moments_pack_blocks(mom_ptr, D, dims, packed.ptr, h.BOTH)
-        h.h2d(packed.ptr + (n_head - 1) * 8, np.array([float(n)]))
         t_ar = time.perf_counter()
-        h.allreduce_sum_f64(packed.ptr, count)
-        n_total = int(round(float(h.to_host(packed, (1,), offset_bytes=(n_head - 1) * 8)[0])))
+        n_total = h.moments_exchange(mom_ptr, D, dims, n)
         LAST["allreduce_ms"] = (time.perf_counter() - t_ar) * 1e3
-        h.moments_unpack_blocks(packed.ptr, D, dims, mom_ptr, h.BOTH)
-        keep.append(packed)
     elif sharded:
         # the one exchange step of the path, in two parts: [diag-block triangles | column sums | row count] and
         # [off-diagonal blocks] (ccz.h "blocks layout") -- D (D + 1) / 2 + D + 1 doubles in all, as the plain packed form

@@ -105,6 +105,9 @@ int ccz_destroy(ccz_handle h) {
     for (auto& e : im->chain_sync) if (e.second) (void)hipFree(e.second);
     if (im->colsum_counters) (void)hipFree(im->colsum_counters);
     if (im->chain_dbg) (void)hipFree(im->chain_dbg);
+    if (im->xchg_buf) (void)hipFree(im->xchg_buf);
+    if (im->xchg_stream) (void)hipStreamDestroy(im->xchg_stream);
+    for (auto& e : im->xchg_ev) if (e) (void)hipEventDestroy(e);
     for (int i = 0; i < 4; ++i) (void)hipEventDestroy(im->ev[i]);
     for (int i = 0; i < 4; ++i) if (im->pipe_ev[i]) (void)hipEventDestroy(im->pipe_ev[i]);
     for (int i = 0; i < 2; ++i) if (im->pin_buf[i]) (void)hipHostFree(im->pin_buf[i]);
@@ -278,8 +281,10 @@ int ccz_moments_unpack(ccz_handle h, const double* packed_dev, int64_t D, double
 
 // blocks layout of the sharded exchange:  [ upper triangles of the diagonal blocks C_11 .. C_mm | colsum (D) | 1 spare
 // slot (the caller's row count) ]  then  [ the off-diagonal blocks (i < j), each d_i x d_j row-major ]
-static void moments_blocks(ccz_ctx* c, bool pack, double* mom, int64_t D, const int64_t* dims, int m, double* packed, int which,
-                           void* on_stream) {
+}  // extern "C"
+namespace ccz {
+void moments_blocks(ccz_ctx* c, bool pack, double* mom, int64_t D, const int64_t* dims, int m, double* packed, int which,
+                    void* on_stream) {
   if (!mom || !packed || !dims || m < 1 || D < 1) fail(CCZ_EINVAL, "moments blocks: bad argument");
   if (which < 1 || which > 3) fail(CCZ_EINVAL, "moments blocks: which must be 1 (head), 2 (tail) or 3 (both)");
   std::vector<int64_t> off(m + 1, 0);
@@ -311,6 +316,8 @@ static void moments_blocks(ccz_ctx* c, bool pack, double* mom, int64_t D, const 
   }
   c->stream = prev;
 }
+}  // namespace ccz
+extern "C" {
 
 int ccz_moments_pack_blocks(ccz_handle h, const double* moments_dev, int64_t D, const int64_t* dims, int n_views, double* packed_dev,
                             int which) {

@@ -44,12 +44,26 @@ def _newest_header():
     return max(t, os.path.getmtime(os.path.abspath(__file__)))
 
 
+LAST_ACTION = ""   # what the last build() did: "rebuilt N of M sources (...)" / "up to date (...)"
+
+
 def build(force=False, verbose=False):
+    """Bring ``lib/libccz.so`` up to date.  ``CCZ_FORCE_BUILD=1`` (or ``force``) recompiles everything; otherwise the
+    library is rebuilt when it is missing or OLDER than any source or header -- a shipped binary that is newer than the
+    whole source tree is used as it is (and said so), even where the per-file objects did not travel with it."""
+    global LAST_ACTION
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIB_DIR, exist_ok=True)
-    cc = hipcc()
+    force = force or os.environ.get("CCZ_FORCE_BUILD", "") not in ("", "0")
     hdr_t = _newest_header()
-    objs, rebuilt = [], False
+    src_t = max(os.path.getmtime(os.path.join(HERE, s)) for s in SOURCES)
+    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= max(hdr_t, src_t):
+        LAST_ACTION = f"up to date: {os.path.relpath(LIB, ROOT)} is newer than every source and header (CCZ_FORCE_BUILD=1 rebuilds)"
+        if verbose:
+            print(LAST_ACTION, flush=True)
+        return LIB
+    cc = hipcc()
+    objs, rebuilt, compiled = [], False, []
     for src in SOURCES:
         sp = os.path.join(HERE, src)
         op = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
@@ -67,6 +81,7 @@ def build(force=False, verbose=False):
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
         rebuilt = True
+        compiled.append(src)
         if verbose:
             print(f"  {src}: {time.time() - t0:.1f}s", flush=True)
     if rebuilt or force or not os.path.exists(LIB):
@@ -74,6 +89,7 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    LAST_ACTION = f"rebuilt {len(compiled)} of {len(SOURCES)} sources ({', '.join(compiled) or 'link only'}){' [forced]' if force else ''}"
     return LIB
 
 

@@ -11,6 +11,7 @@
 // loading on a box without RCCL.
 #include <dlfcn.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -43,13 +44,22 @@ Rccl& rccl() {
   static Rccl r;
   static std::once_flag once;
   std::call_once(once, [] {
-    const char* names[] = {"librccl.so.1", "librccl.so"};
-    for (const char* n : names)                                   // a copy that is already mapped (torch's) wins
-      if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
-    const char* paths[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* n : paths)
-      if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-    if (!r.lib) { r.why = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?"); return; }
+    // CCZ_RCCL_LIB: the one library to use (a deployment that pins its RCCL; the tests force the not-found path with it)
+    if (const char* forced = getenv("CCZ_RCCL_LIB")) {
+      r.lib = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
+    } else {
+      const char* names[] = {"librccl.so.1", "librccl.so"};
+      for (const char* n : names)                                   // a copy that is already mapped (torch's) wins
+        if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+      const char* paths[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+      for (const char* n : paths)
+        if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    }
+    if (!r.lib) {
+      const char* e = dlerror();                                    // ONE call: dlerror() clears the message it returns
+      r.why = std::string("librccl not found: ") + (e ? e : "?");
+      return;
+    }
     auto sym = [&](const char* name) {
       void* p = dlsym(r.lib, name);
       if (!p && r.why.empty()) r.why = std::string("librccl lacks ") + name;
@@ -166,6 +176,62 @@ int ccz_allreduce_sum_f64(ccz_handle h, double* buf_dev, int64_t count) {
     if (!im->comm) fail(CCZ_EINVAL, "the handle has no communicator (ccz_comm_init_rank / ccz_comm_init_all)");
     Rccl& r = need_rccl();
     check(r, r.AllReduce(buf_dev, buf_dev, size_t(count), kFloat64, kSum, im->comm, stream(h)), "ncclAllReduce");
+  })
+}
+
+/* The whole exchange step of a row-sharded fit: pack (blocks layout) into the handle's own buffer, the local row count into the
+ * head's spare slot ON THE DEVICE, all-reduce head and tail on the handle's exchange stream, unpack the head on the handle's
+ * stream and the tail behind the collective -- its completion is the event the next ccz_*_solve waits for right before its
+ * first off-diagonal read.  One 8-byte host read (the global row count), no allocation after the first fit of a size. */
+int ccz_moments_exchange(ccz_handle h, double* moments_dev, int64_t D, const int64_t* dims, int n_views, int64_t n_local,
+                         int64_t* n_total_out) {
+  CCZ_GUARD(h, {
+    if (!moments_dev || !dims || !n_total_out || D < 1 || n_views < 1 || n_local < 0) fail(CCZ_EINVAL, "moments_exchange: bad argument");
+    Impl* im = impl(h);
+    if (!im->comm) fail(CCZ_EINVAL, "the handle has no communicator (ccz_comm_init_rank / ccz_comm_init_all)");
+    Rccl& r = need_rccl();
+    int64_t n_head = D + 1;
+    for (int i = 0; i < n_views; ++i) {
+      if (dims[i] < 1) fail(CCZ_EINVAL, "moments_exchange: view %d has no features", i);
+      n_head += dims[i] * (dims[i] + 1) / 2;
+    }
+    const int64_t count = D * (D + 1) / 2 + D + 1, n_tail = count - n_head;
+    if (n_tail < 0) fail(CCZ_EINVAL, "moments_exchange: dims do not sum to D");
+    hipStream_t s0 = stream(h);
+    if (!im->xchg_stream) {
+      CCZ_HIP(hipStreamCreateWithFlags(&im->xchg_stream, hipStreamNonBlocking));
+      for (auto& e : im->xchg_ev) CCZ_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    hipStream_t sx = im->xchg_stream;
+    // the buffer may still be read by the previous fit's tail unpack (a caller that exchanged and never solved)
+    CCZ_HIP(hipStreamWaitEvent(s0, im->xchg_ev[2], 0));
+    if (im->xchg_cap < size_t(count) * 8) {
+      CCZ_HIP(hipStreamSynchronize(sx));
+      CCZ_HIP(hipStreamSynchronize(s0));
+      if (im->xchg_buf) CCZ_HIP(hipFree(im->xchg_buf));
+      im->xchg_buf = nullptr;
+      im->xchg_cap = 0;
+      CCZ_HIP(hipMalloc(&im->xchg_buf, size_t(count) * 8));
+      im->xchg_cap = size_t(count) * 8;
+    }
+    double* packed = static_cast<double*>(im->xchg_buf);
+    moments_blocks(h, true, moments_dev, D, dims, n_views, packed, 3, nullptr);
+    fill2d(h, 1, 1, packed + n_head - 1, 1, double(n_local));
+    CCZ_HIP(hipEventRecord(im->xchg_ev[0], s0));
+    CCZ_HIP(hipStreamWaitEvent(sx, im->xchg_ev[0], 0));
+    check(r, r.AllReduce(packed, packed, size_t(n_head), kFloat64, kSum, im->comm, sx), "ncclAllReduce (head)");
+    CCZ_HIP(hipEventRecord(im->xchg_ev[1], sx));
+    if (n_tail > 0) {
+      check(r, r.AllReduce(packed + n_head, packed + n_head, size_t(n_tail), kFloat64, kSum, im->comm, sx), "ncclAllReduce (tail)");
+      moments_blocks(h, false, moments_dev, D, dims, n_views, packed, 2, sx);
+    }
+    CCZ_HIP(hipEventRecord(im->xchg_ev[2], sx));
+    CCZ_HIP(hipStreamWaitEvent(s0, im->xchg_ev[1], 0));
+    moments_blocks(h, false, moments_dev, D, dims, n_views, packed, 1, nullptr);
+    double nt = 0.0;
+    d2h(h, &nt, packed + n_head - 1, 8);                    // waits for the head only; the tail is still in flight
+    *n_total_out = int64_t(nt + 0.5);
+    if (n_tail > 0) im->deferred_event = im->xchg_ev[2];    // consumed by the next solve (ops_hip.hip: wait_deferred)
   })
 }
 

@@ -75,6 +75,12 @@ struct Impl {
   int chain_cap = 0;
   void* chain_dbg = nullptr;             // CCZ_CHAIN_DEBUG stamps
   unsigned* colsum_counters = nullptr;   // gram.hip: arrival counters of k_colsum_pilot (64 words, zero between launches)
+  // comm.hip: ccz_moments_exchange -- the packed blocks buffer the handle keeps between fits (grown on demand), the stream its
+  // collectives run on and the events that tie it to the handle's stream
+  void* xchg_buf = nullptr;
+  size_t xchg_cap = 0;
+  hipStream_t xchg_stream = nullptr;
+  hipEvent_t xchg_ev[3] = {nullptr, nullptr, nullptr};   // packed (main -> exchange), head reduced, tail unpacked
   // comm.hip: the RCCL communicator of this handle's device (ncclComm_t), its size and this handle's rank
   void* comm = nullptr;
   int comm_world = 0, comm_rank = -1;
@@ -130,6 +136,10 @@ void sync_short(ccz_ctx* c);   // polled wait for the handle's stream (short wai
 
 // evd_block.hip: one-sided block Jacobi on the rows of W (p a multiple of 64, even leading dimensions)
 int jacobi_rows_block(ccz_ctx* c, int64_t p, int64_t q, double* W, int64_t ldw, double* Q, int64_t qc, int64_t ldq, int max_sweeps);
+
+// api.hip: blocks layout of the sharded exchange (ccz.h), pack or unpack, head / tail / both, optionally on a foreign stream
+void moments_blocks(ccz_ctx* c, bool pack, double* mom, int64_t D, const int64_t* dims, int m, double* packed, int which,
+                    void* on_stream);
 
 // gram.hip: one entry of a launch's tile table -- the two column panels (of one or two views) whose product is one
 // 256 x 256 (fp32) / 128 x 128 (fp64) tile of the stacked Gram matrix

@@ -197,9 +197,66 @@ def _views_of(vs):
     return views
 
 
+class _InvSqrtmFn(torch.autograd.Function):
+    """``A^-1/2`` with eigenvalues clamped at ``eps`` as a differentiable node (the reference's ``_inv_sqrtm`` sits inside
+    the autograd graph of ``CCALoss.forward``, cca_zoo/deep/objectives.py:9-21, :94-97): ``A = V diag(lam) V'`` by the device
+    Jacobi EVD (``ccz_syevj``), ``F = V diag(f(lam)) V'`` with ``f = max(., eps)^-1/2``, and the Daleckii-Krein backward
+    ``dA = V ((V' G V) o K) V'``, ``K_ij = (f_i - f_j) / (lam_i - lam_j)`` (``f'(lam_i)`` on the diagonal and between equal
+    eigenvalues -- finite where ``eigh``'s own backward divides by zero).  All products are ``ccz_gemm_f64``."""
+
+    @staticmethod
+    def forward(ctx, A: torch.Tensor, eps: float) -> torch.Tensor:
+        h = _backend.handle_for([A])
+        d = int(A.shape[0])
+        a64 = A.detach().to(torch.float64).contiguous().clone()      # ccz_syevj overwrites its input
+        w = torch.empty(d, dtype=torch.float64, device=A.device)
+        Vr = torch.empty((d, d), dtype=torch.float64, device=A.device)   # row i = eigenvector i
+        sp = _stream_ptr(A)
+        h.acquire(sp)
+        h.check(h.lib.ccz_syevj(h.raw, C.c_void_p(a64.data_ptr()), d, C.c_void_p(w.data_ptr()), C.c_void_p(Vr.data_ptr()), None))
+        h.release(sp)
+        f = torch.clamp(w, min=eps).rsqrt()
+        scaled = (Vr * f[:, None]).contiguous()                      # diag(f) V'
+        out = torch.empty((d, d), dtype=torch.float64, device=A.device)
+        h.acquire(sp)
+        h.gemm(True, False, d, d, d, 1.0, Vr.data_ptr(), d, scaled.data_ptr(), d, 0.0, out.data_ptr(), d)   # V diag(f) V'
+        h.release(sp)
+        ctx.save_for_backward(w, Vr, f)
+        ctx.eps, ctx.dtype = float(eps), A.dtype
+        return out.to(A.dtype)
+
+    @staticmethod
+    def backward(ctx, G):
+        w, Vr, f = ctx.saved_tensors
+        d = int(w.shape[0])
+        h = _backend.handle_for([Vr])
+        g64 = G.detach().to(torch.float64)
+        g64 = (0.5 * (g64 + g64.t())).contiguous()                   # F is symmetric: only the symmetric part of G acts
+        fp = torch.where(w > ctx.eps, -0.5 * f ** 3, torch.zeros_like(f))     # f'(lam); 0 where the clamp is active
+        dl = w[:, None] - w[None, :]
+        close = dl.abs() <= 1e-12 * torch.clamp(w.abs().max(), min=1e-300)
+        K = torch.where(close, (0.5 * (fp[:, None] + fp[None, :])).expand(d, d), (f[:, None] - f[None, :]) / torch.where(close, torch.ones_like(dl), dl))
+        t1 = torch.empty((d, d), dtype=torch.float64, device=Vr.device)
+        M = torch.empty((d, d), dtype=torch.float64, device=Vr.device)
+        sp = _stream_ptr(Vr)
+        h.acquire(sp)
+        h.gemm(False, False, d, d, d, 1.0, Vr.data_ptr(), d, g64.data_ptr(), d, 0.0, t1.data_ptr(), d)      # V' G   (rows of Vr = eigenvectors)
+        h.gemm(False, True, d, d, d, 1.0, t1.data_ptr(), d, Vr.data_ptr(), d, 0.0, M.data_ptr(), d)        # V' G V
+        h.release(sp)
+        MK = (M * K).contiguous()
+        h.acquire(sp)
+        h.gemm(True, False, d, d, d, 1.0, Vr.data_ptr(), d, MK.data_ptr(), d, 0.0, t1.data_ptr(), d)       # V (M o K)
+        h.gemm(False, False, d, d, d, 1.0, t1.data_ptr(), d, Vr.data_ptr(), d, 0.0, M.data_ptr(), d)       # ... V'
+        h.release(sp)
+        return M.to(ctx.dtype), None
+
+
 def _inv_sqrtm(A: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
-    """``A^-1/2`` with eigenvalues clamped at ``eps`` (device Jacobi EVD, forward only)."""
+    """``A^-1/2`` with eigenvalues clamped at ``eps`` (device Jacobi EVD).  Differentiable: when ``A`` requires a gradient
+    the result is a node of the autograd graph (:class:`_InvSqrtmFn`); otherwise one fused call (``ccz_inv_sqrtm``)."""
     _require_cuda(A, "_inv_sqrtm")
+    if A.requires_grad and torch.is_grad_enabled():
+        return _InvSqrtmFn.apply(A, float(eps))
     h = _backend.handle_for([A])
     a64 = A.detach().to(torch.float64).contiguous()
     out = torch.empty_like(a64)

@@ -155,6 +155,16 @@ CCZ_API int ccz_comm_info(ccz_handle h, int* world_out, int* rank_out);
 CCZ_API int ccz_comm_destroy(ccz_handle h);
 CCZ_API int ccz_allreduce_sum_f64(ccz_handle h, double* buf_dev, int64_t count);
 CCZ_API int ccz_allreduce_sum_f64_multi(ccz_handle* handles, double* const* bufs_dev, int n, int64_t count);
+/* The whole exchange step of a row-sharded fit in ONE call -- what cca_zoo's fit would run between its second-moment pass and
+ * its solve (linear/_rcca.py:69-101, _mcca.py:99-197, _gcca.py:80-110 on a rank's rows): moments_dev ([G | s] of THIS rank's
+ * n_local rows) is packed in the blocks layout into a buffer the handle keeps between fits, the row count is written into the
+ * head's spare slot on the device, head and tail are all-reduced on a stream of the handle's own, the head is unpacked on the
+ * handle's stream, the tail behind its collective -- the next ccz_{rcca,mcca,gcca}_solve waits for that on the device right
+ * before its first off-diagonal read, i.e. the tail's transfer overlaps the per-view factorizations.  *n_total_out: the
+ * global row count (the call's only host read).  Needs ccz_comm_init_rank / _init_all.  CCZ_RCCL_LIB=path pins the RCCL
+ * library that is dlopen'ed. */
+CCZ_API int ccz_moments_exchange(ccz_handle h, double* moments_dev, int64_t D, const int64_t* dims, int n_views,
+                                 int64_t n_local, int64_t* n_total_out);
 /* Moments are additive over disjoint row sets: y <- alpha x + beta y over the D*D + D doubles of two
  * moment buffers.  With (alpha, beta) = (-1, 1) it turns the moments of all rows into those of the rows
  * outside a cross-validation fold -- the Gram reuse behind cca_zoo_amd.model_selection.GridSearchCV

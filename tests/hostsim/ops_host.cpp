@@ -608,6 +608,23 @@ int ccz_allreduce_sum_f64(ccz_handle h, double* buf, int64_t count) {
 int ccz_allreduce_sum_f64_multi(ccz_handle* hs, double* const* bufs, int n, int64_t count) {
   return (hs && bufs && n == 1) ? ccz_allreduce_sum_f64(hs[0], bufs[0], count) : CCZ_ERCCL;
 }
+// the whole exchange step: pack (blocks layout) -> all-reduce (a world of one) -> unpack, the row count through the head's slot
+int ccz_moments_exchange(ccz_handle h, double* mom, int64_t D, const int64_t* dims, int m, int64_t n_local, int64_t* n_total) {
+  if (!h || !mom || !dims || !n_total || D < 1 || m < 1 || n_local < 0) return CCZ_EINVAL;
+  if (h->last_pilot != 1000) { h->err = "the handle has no communicator (ccz_comm_init_rank / ccz_comm_init_all)"; return CCZ_EINVAL; }
+  const int64_t count = D * (D + 1) / 2 + D + 1;
+  int64_t n_head = D + 1;
+  for (int i = 0; i < m; ++i) n_head += dims[i] * (dims[i] + 1) / 2;
+  std::vector<double> packed(size_t(count), 0.0);
+  int rc = blocks_copy(true, mom, D, dims, m, packed.data(), 3);
+  if (rc != CCZ_OK) return rc;
+  packed[size_t(n_head - 1)] = double(n_local);
+  rc = ccz_allreduce_sum_f64(h, packed.data(), count);
+  if (rc != CCZ_OK) return rc;
+  rc = blocks_copy(false, mom, D, dims, m, packed.data(), 3);
+  *n_total = int64_t(packed[size_t(n_head - 1)] + 0.5);
+  return rc;
+}
 int ccz_transform(ccz_handle h, int dtype, const void* X, int64_t n, int64_t d, int64_t ld, const double* mean,
                   const double* W, int64_t k, void* out, int64_t ldo) {
   if (!h || !X || !W || !out) return CCZ_EINVAL;

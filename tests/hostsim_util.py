@@ -15,11 +15,23 @@ HEADERS = [os.path.join(ROOT, "cca_zoo_amd", "csrc", "ops.h"), os.path.join(ROOT
            os.path.join(ROOT, "include", "ccz.h")]
 
 
+SIM_SO_SAN = os.path.join(SIM_DIR, "libccz_hostsim_asan.so")
+
+
+def sanitized():
+    """CCZ_HOSTSIM_SANITIZE=1: the double is built with AddressSanitizer + UndefinedBehaviorSanitizer (the
+    product driver source solve.cpp runs under both).  The process must have libasan preloaded: tests/test_sanitizers.py."""
+    return os.environ.get("CCZ_HOSTSIM_SANITIZE", "") not in ("", "0")
+
+
 def build_hostsim():
     newest = max(os.path.getmtime(p) for p in SOURCES + HEADERS)
-    if not os.path.exists(SIM_SO) or os.path.getmtime(SIM_SO) < newest:
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", SIM_SO] + SOURCES)
-    return SIM_SO
+    so = SIM_SO_SAN if sanitized() else SIM_SO
+    if not os.path.exists(so) or os.path.getmtime(so) < newest:
+        flags = (["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"]
+                 if sanitized() else ["-O2"])
+        subprocess.check_call(["g++"] + flags + ["-std=c++17", "-fPIC", "-shared", "-o", so] + SOURCES)
+    return so
 
 
 def hostsim_handle():
