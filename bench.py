@@ -705,6 +705,10 @@ def timed_fit(make_model, views, runs):
     # host work a generation-2 collection of the sklearn + torch + scipy heap costs ~30 ms and lands inside a "solve"
     gc.collect()
     gc.disable()
+    # the gate of the PREVIOUS configuration ends with seconds of multi-threaded host BLAS: under a cgroup CPU quota that
+    # leaves a throttling debt, and a launch chain of ~400 dispatches issued by a throttled host thread is what made one fit
+    # in three of an extra 10-20 ms slower (solve_ms_runs [32.2, 25.6, 32.2] in BENCH_r04).  Three quota periods of rest.
+    time.sleep(0.3)
     try:
         for _ in range(runs + 1):            # first run warms allocator pools / code objects and is dropped
             t0 = time.perf_counter()

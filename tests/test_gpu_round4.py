@@ -165,7 +165,12 @@ def test_c5_gcca_weights_against_the_oracle_at_full_dimensions(H):
     G, s = flat[:D * D].reshape(D, D), flat[D * D:]
 
     def lanczos(K, kk):
-        lam, U = spla.eigsh(K, k=kk, which="LA", ncv=3 * kk, tol=1e-11)
+        # the oracle's Lanczos (scipy eigsh) with its ~1000 matrix-vector products of the 16384 x 16384 operator done by the
+        # comparator on the device (torch.mv): 2.1 GB per product made this test 100 s of the suite on the host
+        Kt = torch.as_tensor(K, device="cuda")
+        op = spla.LinearOperator(K.shape, dtype=np.float64,
+                                 matvec=lambda x: (Kt @ torch.as_tensor(np.ascontiguousarray(x).reshape(-1), device="cuda")).cpu().numpy())
+        lam, U = spla.eigsh(op, k=kk, which="LA", ncv=3 * kk, tol=1e-11)
         o = np.argsort(lam)[::-1]
         return lam[o], U[:, o]
 
