@@ -104,6 +104,7 @@ int ccz_destroy(ccz_handle h) {
     for (auto& t : im->tile_tabs) if (t.dev) (void)hipFree(t.dev);
     for (auto& e : im->chain_sync) if (e.second) (void)hipFree(e.second);
     if (im->colsum_counters) (void)hipFree(im->colsum_counters);
+    for (auto& e : im->k1_plans) if (e.dev) (void)hipFree(e.dev);
     if (im->chain_dbg) (void)hipFree(im->chain_dbg);
     if (im->xchg_buf) (void)hipFree(im->xchg_buf);
     if (im->xchg_stream) (void)hipStreamDestroy(im->xchg_stream);

@@ -495,6 +495,102 @@ __global__ __launch_bounds__(256, 1) void k_gram_f32_fifo(const GramTile* __rest
 }
 
 // ---------------------------------------------------------------------------
+// The FIFO kernel on a SMALL grid (a DCCA batch: ten tiles x a few hundred rows per workgroup, one round of workgroups):
+// per-workgroup fp32 partial tiles instead of atomics (25 workgroups adding to every address of G cost 640 us), and a
+// per-TILE row split -- a diagonal tile costs 62.5 % of an off-diagonal one, so it gets 1.6x the rows and the round ends
+// together (uniform chunks left 15 % of the chip idle: 352 rows x 0.213 us = 75 us against 61 us).
+//   plan[3 t .. 3 t + 2] = {first workgroup, workgroups, rows per workgroup (whole ring periods)} of tile t.
+// Partial layout of slot blockIdx.x (65536 floats), read by loss.hip::k_loss_prep_partials(fifo_layout):
+//   off-diagonal tile: the 256 x 256 tile, row-major;
+//   diagonal tile: Q00 and Q11 hold their UPPER triangles only (the symmetric quadrants compute 10 of 16 MFMA tiles);
+//     Q01 is the sum of its own slot (rows [0, half) of the workgroup) and of the Q10 slot (the remaining rows, stored there
+//     un-transposed by the wave that would otherwise repeat Q01').
+// ---------------------------------------------------------------------------
+template <bool PILOT>
+__global__ __launch_bounds__(256, 1) void k_gram_f32_fifo_small(const GramTile* __restrict__ tiles, int ntiles, const int* __restrict__ plan,
+                                                                int64_t n, float* __restrict__ partial, const float* __restrict__ pilot) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int tile = 0;
+  while (tile + 1 < ntiles && int(blockIdx.x) >= plan[3 * (tile + 1)]) ++tile;
+  const int chunk = int(blockIdx.x) - plan[3 * tile];
+  if (chunk >= plan[3 * tile + 1]) return;
+  const int64_t rows_per_wg = plan[3 * tile + 2];
+  const GramTile t = tiles[tile];
+  const int64_t k_begin = int64_t(chunk) * rows_per_wg;
+  const int64_t k_end = min(n, k_begin + rows_per_wg);
+  float* pt = partial + int64_t(blockIdx.x) * 65536;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int wr = wave >> 1, wc = wave & 1;
+  const bool diag = t.diag != 0;
+  const bool sym = diag && wr == wc;
+  const int64_t nrows_wg = max<int64_t>(k_end - k_begin, 0);
+  int64_t row0 = 0, nrows = nrows_wg;
+  bool second_half = false;
+  if (diag && wr != wc) {
+    constexpr int HB = FB * FR;                              // both halves stay whole ring periods
+    const int64_t half = ((nrows_wg + 1) / 2 + HB - 1) / HB * HB;
+    if (wr == 0) nrows = min(half, nrows_wg);
+    else { row0 = min(half, nrows_wg); nrows = nrows_wg - row0; wr = 0; wc = 1; second_half = true; }
+  }
+  v16f32 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  if (nrows > 0) {
+    char* ring = smem + wave * (FR * FSLOT);
+    const char* rd = ring + lane * 16;
+    const __amdgpu_buffer_rsrc_t srcA =
+        panel_rsrc(static_cast<const float*>(t.a) + (k_begin + row0) * t.lda + wr * 128, ((nrows - 1) * t.lda + 128) * 4);
+    const __amdgpu_buffer_rsrc_t srcB =
+        panel_rsrc(static_cast<const float*>(t.b) + (k_begin + row0) * t.ldb + wc * 128, ((nrows - 1) * t.ldb + 128) * 4);
+    const int voffA = int(((lane >> 5) * t.lda + 4 * (lane & 31)) * 4);
+    const int voffB = int(((lane >> 5) * t.ldb + 4 * (lane & 31)) * 4);
+    const int stepA = __builtin_amdgcn_readfirstlane(int(2 * t.lda * 4));
+    const int stepB = __builtin_amdgcn_readfirstlane(int(2 * t.ldb * 4));
+    v4f32 pa = {0.f, 0.f, 0.f, 0.f}, pb = {0.f, 0.f, 0.f, 0.f};
+    if (PILOT) {
+      pa = -*reinterpret_cast<const v4f32*>(pilot + t.out_row + wr * 128 + 4 * (lane & 31));
+      pb = -*reinterpret_cast<const v4f32*>(pilot + t.out_col + wc * 128 + 4 * (lane & 31));
+    }
+    if (sym) gram_fifo_quadrant<true, PILOT>(acc, ring, rd, srcA, srcB, voffA, voffB, stepA, stepB, nrows, pa, pb);
+    else gram_fifo_quadrant<false, PILOT>(acc, ring, rd, srcA, srcB, voffA, voffB, stepA, stepB, nrows, pa, pb);
+  }
+  // epilogue: plain stores into this workgroup's slot (zeros from a wave that had no rows)
+  if (!sym) {
+    const int qr = second_half ? 1 : wr, qc = second_half ? 0 : wc;     // the second half of Q01 lands in the Q10 slot
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int trow = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int i = qr * 128 + 4 * trow + ti;
+        const v4f32 v = {acc[ti][0][r], acc[ti][1][r], acc[ti][2][r], acc[ti][3][r]};
+        *reinterpret_cast<v4f32*>(pt + i * 256 + qc * 128 + 4 * (lane & 31)) = v;
+      }
+  } else {
+    float* Q = pt + (wr * 128) * 256 + wc * 128;
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int trow = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int i = 4 * trow + ti;
+#pragma unroll
+        for (int tj = ti; tj < 4; ++tj) {
+          const int j = 4 * (lane & 31) + tj;
+          const float v = acc[ti][tj][r];
+          if (i <= j) Q[i * 256 + j] = v;
+          else if (tj != ti) Q[j * 256 + i] = v;
+        }
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // fp64: 128 x 128 tile per workgroup, 4 waves (2 x 2), each wave 64 x 64 =
 // 4 x 4 MFMA f64 16x16x4 tiles (128 accumulator registers)
 // ---------------------------------------------------------------------------
@@ -897,6 +993,7 @@ struct TileTable {
   GramTile* dev = nullptr;
   int ntiles = 0;
   bool fast = true;      // every view: width a multiple of the tile, 16-byte aligned rows -> the buffer-descriptor kernels
+  std::vector<unsigned char> diag;   // host copy of the tiles' diag flags, in table order
 };
 
 template <typename T>
@@ -1040,6 +1137,8 @@ TileTable build_tile_table(ccz_ctx* c, const ccz_view* views, int n_views, void*
   tt.dev = d_tiles;
   tt.ntiles = ntiles;
   tt.fast = fast;
+  tt.diag.resize(tiles.size());
+  for (size_t q = 0; q < tiles.size(); ++q) tt.diag[q] = tiles[q].diag ? 1 : 0;
   (void)tiles_from_handle_cache;          // handle-cached tables stay with the handle
   return tt;
 }
@@ -1329,9 +1428,62 @@ bool gram_partials_f32(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n
   const TileTable tt = build_tile_table<float>(c, views, n_views, nullptr);
   const RowPlan rp = plan_rows<float>(c, views, n_views, n, tt.ntiles, tt.fast);
   static const int64_t partial_cap = [] { const char* e = getenv("CCZ_GRAM_PARTIAL_MB"); return (e ? atoll(e) : 192LL) << 20; }();
-  const int64_t bytes = rp.ksplit * int64_t(tt.ntiles) * T32 * T32 * 4;
+  int64_t bytes = rp.ksplit * int64_t(tt.ntiles) * T32 * T32 * 4;
   if (rp.sliced || bytes > partial_cap) return false;
   const int ncu = std::max(1, im->props.multiProcessorCount);
+  // ---- the FIFO kernel with a per-tile row split (k_gram_f32_fifo_small), when every chunk can be whole ring periods ----
+  static const int fifo_env = [] { const char* e = getenv("CCZ_LOSS_K1_FIFO"); return e ? atoi(e) : 1; }();
+  bool fifo_plan_ok = false;
+  int fifo_wgs = 0;
+  int* fifo_plan_dev = nullptr;
+  if (fifo_env && rp.fast && n % (FB * FR) == 0 && tt.ntiles <= 64) {
+    // the plan depends on (n, which tiles are diagonal, CUs) only: formed once, kept on the device with the handle (a training
+    // loop meets the same batch shape every step -- the search below and a host -> device copy per call cost more than they saved)
+    uint64_t key = 1469598103934665603ull;
+    auto mix = [&](uint64_t v) { key ^= v; key *= 1099511628211ull; };
+    mix(uint64_t(n)); mix(uint64_t(tt.ntiles)); mix(uint64_t(ncu));
+    for (unsigned char dflag : tt.diag) mix(dflag);
+    for (auto& e : im->k1_plans)
+      if (e.key == key) { fifo_plan_dev = static_cast<int*>(e.dev); fifo_wgs = e.wgs; break; }
+    if (!fifo_plan_dev) {
+      int n_diag = 0;
+      for (unsigned char dflag : tt.diag) n_diag += dflag ? 1 : 0;
+      const int n_off = tt.ntiles - n_diag;
+      const int64_t P = n / (FB * FR);                        // ring periods of the batch
+      double best = 1e300;
+      int64_t bo = 0, bd = 0;
+      for (int64_t ko = (n_off ? 1 : 0); ko <= (n_off ? std::min<int64_t>(P, ncu) : 0); ++ko)
+        for (int64_t kd = (n_diag ? 1 : 0); kd <= (n_diag ? std::min<int64_t>(P, ncu) : 0); ++kd) {
+          if (n_off * ko + n_diag * kd > ncu) break;
+          const double po = n_off ? double((P + ko - 1) / ko) : 0.0, pd = n_diag ? 0.625 * double((P + kd - 1) / kd) : 0.0;
+          const double cost = std::max(po, pd) + 1.2;         // + the fixed cost of a workgroup (prologue, 256 KB of stores), in periods
+          if (cost < best) { best = cost; bo = ko; bd = kd; }
+        }
+      if (best < 1e299 && im->k1_plans.size() < 64) {
+        std::vector<int> plan_h(size_t(3) * tt.ntiles);
+        int first = 0;
+        for (int t = 0; t < tt.ntiles; ++t) {
+          const int64_t kk = tt.diag[size_t(t)] ? bd : bo;
+          const int64_t per = (P + kk - 1) / kk;
+          const int wgs = int((P + per - 1) / per);
+          plan_h[size_t(3 * t)] = first;
+          plan_h[size_t(3 * t + 1)] = wgs;
+          plan_h[size_t(3 * t + 2)] = int(per * FB * FR);
+          first += wgs;
+        }
+        void* dp = nullptr;
+        CCZ_HIP(hipMalloc(&dp, plan_h.size() * sizeof(int)));
+        h2d_small(c, dp, plan_h.data(), plan_h.size() * sizeof(int));
+        im->k1_plans.push_back({key, dp, first});
+        fifo_plan_dev = static_cast<int*>(dp);
+        fifo_wgs = first;
+      }
+    }
+    if (fifo_plan_dev) {
+      bytes = int64_t(fifo_wgs) * T32 * T32 * 4;
+      fifo_plan_ok = bytes <= partial_cap;
+    }
+  }
   // column sums + pilot
   const int64_t colblocks = (D + 255) / 256;
   if (colblocks > 64) return false;
@@ -1345,6 +1497,7 @@ bool gram_partials_f32(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n
   out->colsum = static_cast<double*>(dev_alloc(c, size_t(D) * 8));
   out->pilot = static_cast<float*>(dev_alloc(c, size_t(D) * 4));
   out->partial = static_cast<float*>(dev_alloc(c, size_t(bytes)));
+  out->tile_plan = fifo_plan_ok ? fifo_plan_dev : nullptr;   // owned by the handle
   double* part = static_cast<double*>(dev_alloc(c, size_t(rowblocks) * D * 8));
   ColsumViews cv{};
   cv.m = n_views;
@@ -1357,7 +1510,12 @@ bool gram_partials_f32(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n
   hipLaunchKernelGGL(k_colsum_pilot, dim3((unsigned)colblocks, (unsigned)rowblocks), dim3(256), 0, st, cv, n, D, rpb, part, im->colsum_counters,
                      out->colsum, out->pilot);
   const size_t lds_bytes = size_t(2) * 2 * BK * T32 * sizeof(float);
-  if (rp.fast) {
+  if (fifo_plan_ok) {
+    const size_t fifo_bytes = size_t(4) * FR * FSLOT;
+    CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_f32_fifo_small<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(fifo_bytes)));
+    hipLaunchKernelGGL(k_gram_f32_fifo_small<true>, dim3((unsigned)fifo_wgs), dim3(256), fifo_bytes, st, tt.dev, tt.ntiles, out->tile_plan, n,
+                       out->partial, out->pilot);
+  } else if (rp.fast) {
     CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_f32<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
     hipLaunchKernelGGL(k_gram_f32<true>, dim3((unsigned)rp.nblocks), dim3(256), lds_bytes, st, tt.dev, tt.ntiles, rp.per_xcd, rp.ksplit, n, rp.rows_per_wg,
                        static_cast<double*>(nullptr), D, out->pilot, out->partial, int64_t(0));
@@ -1379,7 +1537,7 @@ void gram_partials_release(ccz_ctx* c, GramPartials* gp) {
   if (gp->partial) dev_free(c, gp->partial);
   if (gp->pilot) dev_free(c, gp->pilot);
   if (gp->colsum) dev_free(c, gp->colsum);
-  gp->partial = nullptr; gp->pilot = nullptr; gp->colsum = nullptr;
+  gp->partial = nullptr; gp->pilot = nullptr; gp->colsum = nullptr; gp->tile_plan = nullptr;
 }
 
 void moments_impl(ccz_ctx* c, int dtype, const ccz_view* views, int n_views, int64_t n_rows, bool on_device,

@@ -74,6 +74,8 @@ struct Impl {
   std::vector<std::pair<void*, void*>> chain_sync;
   int chain_cap = 0;
   void* chain_dbg = nullptr;             // CCZ_CHAIN_DEBUG stamps
+  struct K1Plan { uint64_t key; void* dev; int wgs; };
+  std::vector<K1Plan> k1_plans;          // gram.hip: per-tile row splits of k_gram_f32_fifo_small, by batch shape
   unsigned* colsum_counters = nullptr;   // gram.hip: arrival counters of k_colsum_pilot (64 words, zero between launches)
   // comm.hip: ccz_moments_exchange -- the packed blocks buffer the handle keeps between fits (grown on demand), the stream its
   // collectives run on and the events that tie it to the handle's stream
@@ -162,6 +164,9 @@ struct GramPartials {
   float* partial = nullptr;
   float* pilot = nullptr;
   double* colsum = nullptr;
+  // null: slot of (chunk, tile) = chunk * ntiles + tile, ksplit chunks per tile, full tiles (k_gram_f32).  Else (k_gram_f32_fifo_small):
+  // 3 ints per tile {first slot, slots, rows per slot}, slots of a tile contiguous, diagonal tiles in the FIFO kernel's layout
+  int* tile_plan = nullptr;
 };
 bool gram_partials_f32(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, GramPartials* out);
 void gram_partials_release(ccz_ctx* c, GramPartials* gp);

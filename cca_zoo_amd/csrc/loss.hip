@@ -81,7 +81,8 @@ __global__ void k_loss_prep(const double* __restrict__ G, const double* __restri
 // transpose, so both halves go out as full 256-byte rows.
 constexpr int PSB = 32;
 __global__ __launch_bounds__(256) void k_loss_prep_partials(const float* __restrict__ partial, const GramTile* __restrict__ tiles, int ntiles,
-                                                            int64_t ksplit, const double* __restrict__ s, const float* __restrict__ pilot,
+                                                            int64_t ksplit, const int* __restrict__ plan, const double* __restrict__ s,
+                                                            const float* __restrict__ pilot,
                                                             int64_t D, double n_rows, double inv_nm1, double eps, double* __restrict__ Ce,
                                                             double* __restrict__ mean, PrepArgs pa, double* __restrict__ acc,
                                                             double* __restrict__ bias) {
@@ -107,13 +108,29 @@ __global__ __launch_bounds__(256) void k_loss_prep_partials(const float* __restr
   const int64_t da = pa.off[a + 1] - pa.off[a], li0 = gi0 - pa.off[a], lj0 = gj0 - pa.off[a];
   const double dj = c < vj ? s[gj0 + c] / n_rows - double(pilot[gj0 + c]) : 0.0;
   double g[4] = {0.0, 0.0, 0.0, 0.0};
+  // slots of this tile: (chunk, tile) interleaved (k_gram_f32) or contiguous per tile (plan: k_gram_f32_fifo_small)
+  const int64_t slot0 = plan ? plan[3 * tile] : tile, nslots = plan ? plan[3 * tile + 1] : ksplit, sstride = plan ? 1 : ntiles;
+  // FIFO layout of a diagonal tile: the symmetric quadrants hold their upper triangles only (lower elements come from the
+  // transposed position), Q01 is the sum of its slot and of the Q10 slot
+  const bool fifo_diag = plan != nullptr && t.diag;
+  const bool q01 = fifo_diag && si < 4 && sj >= 4;
+  const bool qsym_diag_block = fifo_diag && si == sj;      // a 32 x 32 block on the tile's diagonal
   {
-    const float* p = partial + int64_t(tile) * 65536 + (si * PSB + r0) * 256 + sj * PSB + c;
-    const int64_t cs = int64_t(ntiles) * 65536;
-    for (int64_t ch = 0; ch < ksplit; ++ch) {
+    const int rr0 = si * PSB + r0, cc = sj * PSB + c;
+    const float* p = partial + slot0 * 65536;
+    for (int64_t ch = 0; ch < nslots; ++ch) {
+      const float* pc = p + ch * sstride * 65536;
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (r0 + 8 * k < vi && c < vj) g[k] += double(p[ch * cs + 8 * k * 256]);
+      for (int k = 0; k < 4; ++k) {
+        const int rr = rr0 + 8 * k;
+        if (r0 + 8 * k < vi && c < vj) {
+          float x;
+          if (qsym_diag_block && rr > cc) x = pc[cc * 256 + rr];      // lower element of a symmetric block: stored transposed
+          else x = pc[rr * 256 + cc];
+          if (q01) x += pc[(rr + 128) * 256 + cc - 128];
+          g[k] += double(x);
+        }
+      }
     }
   }
 #pragma unroll
@@ -297,7 +314,7 @@ void pair_core(ccz_ctx* c, const double* mom, int64_t n, const int64_t* dims, in
   }
   if (gp)
     hipLaunchKernelGGL(k_loss_prep_partials, dim3(64, (unsigned)gp->ntiles), dim3(256), 0, st, gp->partial, gp->tiles, gp->ntiles, gp->ksplit,
-                       gp->colsum, gp->pilot, D, double(n), inv, eps, Ce.get(), mean_dev, pa, acc_dev, want_grad ? bias_dev : nullptr);
+                       gp->tile_plan, gp->colsum, gp->pilot, D, double(n), inv, eps, Ce.get(), mean_dev, pa, acc_dev, want_grad ? bias_dev : nullptr);
   else
     hipLaunchKernelGGL(k_loss_prep, dim3((unsigned)std::min<int64_t>((D * D + 255) / 256, 4096)), dim3(256), 0, st, mom, mom + D * D, D,
                        1.0 / double(n), inv, eps, Ce.get(), mean_dev, pa, acc_dev, want_grad ? bias_dev : nullptr);

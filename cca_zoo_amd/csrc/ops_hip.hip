@@ -1796,18 +1796,21 @@ int jacobi_rows(ccz_ctx* c, int64_t p, int64_t q, double* W, int64_t ldw, double
   Impl* im = impl(c);
   const int64_t pe = (p + 1) & ~int64_t(1);
   const double tol = 2.220446049250313e-16 * std::sqrt(double(q)) * 4.0;
-  double floor2 = 0.0;
-  {
+  // rows whose squared norm is below 1e-28 of the largest never rotate (one row_dots + one blocking read-back): only the
+  // one-workgroup kernel and the legacy loop take it as an argument -- the block form finds its own on the device
+  auto rest_floor = [&]() {
     DBuf nn(c, p);
     row_dots(c, p, q, W, ldw, W, ldw, nn);
     std::vector<double> nh(p);
     d2h(c, nh.data(), nn, size_t(p) * 8);
     double mx = 0.0;
     for (double v : nh) mx = std::max(mx, v);
-    floor2 = mx * 1e-28;
-  }
+    return mx * 1e-28;
+  };
+  double floor2 = 0.0;
   const size_t lds_need = (size_t(p) * (q | 1) + (Q ? size_t(p) * (qc | 1) : 0)) * 8;
   if (lds_need <= size_t(144) * 1024) {
+    floor2 = rest_floor();
     CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jacobi_lds), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_need + 16)));
     hipLaunchKernelGGL(k_jacobi_lds, dim3(1), dim3(1024), lds_need + 16, stream(c), int(p), int(q), W, ldw, Q, int(Q ? qc : 0), ldq,
                        tol, floor2, max_sweeps, im->d_flag + 1);
@@ -1835,6 +1838,7 @@ int jacobi_rows(ccz_ctx* c, int64_t p, int64_t q, double* W, int64_t ldw, double
   }
   const bool small = std::max(q, Q ? qc : 0) <= 256;
   dim3 grid((unsigned)(pe / 2));
+  floor2 = rest_floor();
   for (int sweep = 1; sweep <= max_sweeps; ++sweep) {
     CCZ_HIP(hipMemsetAsync(im->d_flag + 1, 0, sizeof(int), stream(c)));
     // one sweep = pe - 1 dependent tiny launches: replayed as a hipGraph after the first sweep

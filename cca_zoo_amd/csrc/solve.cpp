@@ -52,11 +52,17 @@ std::vector<int64_t> offsets(const int64_t* dims, int m) {
 // ---------------------------------------------------------------------------
 }  // namespace
 
-// Symmetric EVD.  The rows of (A + shift I) are orthogonalised; the accumulated
-// rotations are the eigenvectors.  shift = ||A||_inf makes the matrix positive
-// definite so that +lam / -lam pairs (MCCA with two views has them exactly)
-// cannot mix; pass psd=true to skip it and keep relative accuracy of small
-// eigenvalues of a covariance / Gram matrix.
+// Symmetric EVD.  Three routes by size and definiteness:
+//   * d <= syev_small_max (160) and not psd: two-sided Jacobi in one workgroup (Rayleigh-Ritz problems);
+//   * psd and 2 d (d | 1) 8 <= 144 KB (d <= 95): the one-workgroup ONE-sided kernel on the rows of A -- the only route that
+//     keeps the RELATIVE accuracy of small eigenvalues of a covariance / Gram matrix;
+//   * everything else, psd or not: the two-sided block Jacobi (evd_block.hip).  Its eigenvalues carry an ABSOLUTE error of
+//     ~0.6e-15 d ||A|| (the refresh of d >= 1536 brings the residual to 1e-14, not the small eigenvalues to relative
+//     accuracy): a psd caller that separates "zero" from "small" must do so with an absolute floor well above that --
+//     make_whiteners' rank floor is kRankTol d lam_0 = 64 eps d lam_0 = 1.4e-14 d lam_0, a factor ~24 over the noise, and
+//     tests/test_gpu_seams_r5.py::test_rank_detection_between_the_kernels holds the detected rank at d = 320 / 256 / 700.
+// The legacy route below (CCZ_EVD_LEGACY=1): rows of (A + shift I) orthogonalised, shift = ||A||_inf so that +lam / -lam
+// pairs (MCCA with two views has them exactly) cannot mix; psd skips the shift.
 static bool legacy_evd() {   // CCZ_EVD_LEGACY=1: rounds 1-3's launch-per-round one-sided Jacobi above d = 160 (A/B)
   static const bool v = [] { const char* e = getenv("CCZ_EVD_LEGACY"); return e && atoi(e) != 0; }();
   return v;

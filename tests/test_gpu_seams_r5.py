@@ -174,3 +174,29 @@ def test_gevp_topk_at_2048_with_a_dense_metric(H):
     S = np.sign(np.sum(V * (Bm @ Vr[:, ::-1]), axis=0))
     err = np.linalg.norm(V * S - Vr[:, ::-1], axis=0) / np.linalg.norm(Vr[:, ::-1], axis=0)
     assert err.max() < 1e-6, err.max()
+
+
+@pytest.mark.parametrize("d1,d2,r0", [(320, 256, 100), (700, 130, 60), (1400, 96, 90)])
+def test_rank_detection_between_the_kernels(d1, d2, r0):
+    """c = 0 on views that live in an r0-dimensional subspace of their feature space (X_i = Z_i B_i, Z_i of full column rank
+    r0 < d_i): the covariances have rank r0 EXACTLY, the Cholesky whitener fails and the eigen-floored fallback must read that
+    rank off the block Jacobi's eigenvalues (widths between the one-workgroup kernel and the refresh threshold).
+    Canonical correlations are invariant under the maps B_i, so the truth is the full-rank problem (Z_1, Z_2) in float64
+    LAPACK; one numerically-zero direction taken for signal would add a spurious correlation and move every value."""
+    from cca_zoo_amd.linear import CCA
+
+    n, k = 3000, 5
+    rng = np.random.default_rng(d1 + r0)
+    Z1 = rng.standard_normal((n, r0))
+    Z2 = 0.8 * Z1 @ (rng.standard_normal((r0, r0)) / np.sqrt(r0)) + rng.standard_normal((n, r0))
+    X1 = Z1 @ rng.standard_normal((r0, d1))
+    X2 = Z2 @ rng.standard_normal((r0, d2))
+    m = CCA(latent_dimensions=k).fit([X1, X2])
+    q1, _ = np.linalg.qr(Z1 - Z1.mean(0))
+    q2, _ = np.linalg.qr(Z2 - Z2.mean(0))
+    truth = np.linalg.svd(q1.T @ q2, compute_uv=False)[:k]
+    np.testing.assert_allclose(np.asarray(m.singular_values_)[:k], truth, rtol=0, atol=1e-7)
+    zs = m.transform([X1, X2])
+    np.testing.assert_allclose(np.var(zs[0], axis=0, ddof=1), 1.0, atol=1e-6)
+    for a in range(k):
+        assert abs(np.corrcoef(zs[0][:, a], zs[1][:, a])[0, 1] - truth[a]) < 1e-6

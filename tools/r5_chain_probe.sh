@@ -9,8 +9,9 @@ run default_again CCZ_DUMMY=1
 run p4 CCZ_CHOLINV_MFMA=1
 run nochain CCZ_CHOLINV_CHAIN=0
 run nofast CCZ_LOSS_FAST=0
-for w in 24 40 64 96 200; do run wgs$w CCZ_CHAIN_WGS=$w; done
-for sl in 2 4 16; do run sleep$sl CCZ_CHAIN_SLEEP=$sl; done
+run k1staged CCZ_LOSS_K1_FIFO=0
+for w in 64 200; do run wgs$w CCZ_CHAIN_WGS=$w; done
+for sl in 4; do run sleep$sl CCZ_CHAIN_SLEEP=$sl; done
 run wgs64_sleep4 CCZ_CHAIN_WGS=64 CCZ_CHAIN_SLEEP=4
 CCZ_CHAIN_DEBUG=1 timeout 120 python tools/loss_profile.py 8192 512 2 2> $O/chain_debug_A.txt > /dev/null; tail -10 $O/chain_debug_p16.txt >> $O/summary.txt
 CCZ_CHOLINV_MFMA=1 CCZ_CHAIN_DEBUG=1 timeout 120 python tools/loss_profile.py 8192 512 2 2> $O/chain_debug_B.txt > /dev/null; tail -10 $O/chain_debug_p4.txt >> $O/summary.txt
