@@ -25,8 +25,16 @@ def svd_whiten(X: np.ndarray, regularization: float = 0.0) -> tuple[np.ndarray, 
         X = X.astype(np.float64)
     n, d = X.shape
     h = _backend.default_handle()
+    code = _backend.F32 if X.dtype == np.float32 else _backend.F64
     mom = h.alloc((d * d + d) * 8)
-    h.moments([(X, d, d)], n, _backend.F32 if X.dtype == np.float32 else _backend.F64, False, mom.ptr)
+    # X crosses the host link ONCE when it fits next to its whitened copy (it used to be streamed for the
+    # moments and pushed a second time for X W): resident, K1 and the projection both read it from HBM
+    resident = 2 * X.nbytes + (1 << 30) < 0.5 * float(h.device_info()["hbm_bytes"])
+    Xd = h.to_device(X) if resident else None
+    if resident:
+        h.moments([(Xd.ptr, d, d)], n, code, True, mom.ptr)
+    else:
+        h.moments([(X, d, d)], n, code, False, mom.ptr)
     h.moments_symmetrize(mom.ptr, d)
     Wd = h.alloc(d * d * 8)
     lam = h.alloc(d * 8)
@@ -36,9 +44,10 @@ def svd_whiten(X: np.ndarray, regularization: float = 0.0) -> tuple[np.ndarray, 
     W = h.to_host(Wd, (d, r.value)).astype(X.dtype, copy=False)
     # X_white = X W on the device
     out = h.alloc(n * r.value * X.itemsize)
-    Xd = h.to_device(X)
+    if Xd is None:
+        Xd = h.to_device(X)
     Wd64 = h.to_device(np.ascontiguousarray(W, dtype=np.float64))
-    h.check(h.lib.ccz_transform(h.raw, _backend.F32 if X.dtype == np.float32 else _backend.F64,
+    h.check(h.lib.ccz_transform(h.raw, code,
                                 C.c_void_p(Xd.ptr), n, d, d, None, C.c_void_p(Wd64.ptr), r.value,
                                 C.c_void_p(out.ptr), r.value))
     X_white = h.to_host(out, (n, r.value), dtype=X.dtype)

@@ -125,6 +125,13 @@ __global__ void k_copy_words(const unsigned long long* __restrict__ src, unsigne
   for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) dst[i] = src[i];
   __threadfence_system();
 }
+// the same in 16-byte pieces (both pointers 16-byte aligned, n16 pieces): a store to host-mapped memory leaves the chip as one
+// request per lane-group, and 8-byte lanes were seen to take 8 ms per 2 MB in some fits (bench extras: backproject 16 / 25 ms)
+typedef unsigned int v4u32_copy __attribute__((ext_vector_type(4)));
+__global__ void k_copy_words16(const v4u32_copy* __restrict__ src, v4u32_copy* __restrict__ dst, int64_t n16) {
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n16; i += int64_t(gridDim.x) * blockDim.x) dst[i] = src[i];
+  __threadfence_system();
+}
 
 static void wait_stream_short(ccz_ctx* c) {
   Impl* im = impl(c);
@@ -166,20 +173,53 @@ void d2h(ccz_ctx* c, void* dst, const void* src, size_t bytes) {
         im->d2h_pin_dev = nullptr;
       }
     }
+    // CCZ_D2H_MODE (a measurement switch, tools/d2h_probe.py): 0 copy kernel, 8-byte lanes, up to 2048 workgroups (default) |
+    // 1 copy kernel, 16-byte lanes | 2 hipMemcpyAsync into the pinned buffer + polled event | 3 the same + hipStreamSynchronize |
+    // 4 one blocking hipMemcpy into the destination
+    const char* me = std::getenv("CCZ_D2H_MODE");
+    const int mode = me ? std::atoi(me) : 0;
+    const bool trace = std::getenv("CCZ_TRACE_D2H") != nullptr;
+    static hipEvent_t tev[2] = {nullptr, nullptr};
+    const auto th0 = std::chrono::steady_clock::now();
+    if (trace) {
+      if (!tev[0]) { CCZ_HIP(hipEventCreate(&tev[0])); CCZ_HIP(hipEventCreate(&tev[1])); }
+      CCZ_HIP(hipEventRecord(tev[0], stream(c)));
+    }
+    auto report = [&](const char* what) {
+      if (!trace) return;
+      float dev_ms = -1.f;
+      (void)hipEventSynchronize(tev[1]);
+      (void)hipEventElapsedTime(&dev_ms, tev[0], tev[1]);
+      std::fprintf(stderr, "[ccz] d2h %s %zu bytes: device %.3f ms, host %.3f ms\n", what, bytes, dev_ms,
+                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th0).count());
+    };
+    if (mode == 4) {
+      CCZ_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+      if (trace) { CCZ_HIP(hipEventRecord(tev[1], stream(c))); report("blocking"); }
+      return;
+    }
     if (im->d2h_pin) {
       // a KERNEL writes the pinned (host-mapped) buffer: no SDMA engine, hence no cross-engine dependency for the
       // runtime's helper thread to resolve -- with hipMemcpyAsync the event behind the copy was observed to complete
       // 15 - 19 ms late on the DEVICE time line in some fits (three read-backs of the back-projection phase)
-      if (im->d2h_pin_dev && bytes % 8 == 0 && reinterpret_cast<uintptr_t>(src) % 8 == 0) {
+      if (mode <= 1 && im->d2h_pin_dev && bytes % 8 == 0 && reinterpret_cast<uintptr_t>(src) % 8 == 0) {
         const int64_t words = int64_t(bytes / 8);
-        hipLaunchKernelGGL(k_copy_words, dim3((unsigned)std::min<int64_t>((words + 255) / 256, 2048)), dim3(256), 0, stream(c),
-                           static_cast<const unsigned long long*>(src), static_cast<unsigned long long*>(im->d2h_pin_dev), words);
+        if (mode == 1 && bytes % 16 == 0 && reinterpret_cast<uintptr_t>(src) % 16 == 0) {
+          hipLaunchKernelGGL(k_copy_words16, dim3((unsigned)std::min<int64_t>((words / 2 + 255) / 256, 2048)), dim3(256), 0, stream(c),
+                             static_cast<const v4u32_copy*>(src), static_cast<v4u32_copy*>(im->d2h_pin_dev), words / 2);
+        } else {
+          hipLaunchKernelGGL(k_copy_words, dim3((unsigned)std::min<int64_t>((words + 255) / 256, 2048)), dim3(256), 0, stream(c),
+                             static_cast<const unsigned long long*>(src), static_cast<unsigned long long*>(im->d2h_pin_dev), words);
+        }
         CCZ_LAUNCH_CHECK();
       } else {
         CCZ_HIP(hipMemcpyAsync(im->d2h_pin, src, bytes, hipMemcpyDeviceToHost, stream(c)));
       }
-      wait_stream_short(c);
+      if (trace) CCZ_HIP(hipEventRecord(tev[1], stream(c)));
+      if (mode == 3) CCZ_HIP(hipStreamSynchronize(stream(c)));
+      else wait_stream_short(c);
       std::memcpy(dst, im->d2h_pin, bytes);
+      report(mode <= 1 ? "kernel" : "sdma");
       return;
     }
   }

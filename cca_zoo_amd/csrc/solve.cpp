@@ -588,15 +588,17 @@ void means_out(ccz_ctx* c, const double* s_dev, int64_t D, int64_t n, bool cente
   }
 }
 
-// rows-form device block Wt (k x d, ld ldw) -> host (d x k) row-major
+// rows-form device block Wt (k x d, ld ldw) -> host (d x k) row-major.  The transposition happens on the DEVICE: the host
+// loop that used to do it walked a 2 MB buffer with a stride of d * 8 bytes (32 KB at d = 4096: every access of a column in
+// the same cache set), which cost 0.5 ms in some fits and 8 - 13 ms in others, depending on where the allocator put the
+// buffer -- the whole of the "outlier" solves of rounds 3 - 5 (tools/d2h_probe.py, profiles/r05_solve_outliers.md).
 void rows_to_host_cols(ccz_ctx* c, const double* Wt, int64_t k, int64_t d, int64_t ldw, double scale,
                        double* out_host) {
   DBuf tmp(c, k * d);
-  copy2d(c, k, d, Wt, ldw, tmp, d);
-  std::vector<double> h(size_t(k) * d);
-  d2h(c, h.data(), tmp, h.size() * 8);
-  for (int64_t i = 0; i < d; ++i)
-    for (int64_t j = 0; j < k; ++j) out_host[i * k + j] = scale * h[j * d + i];
+  transpose(c, k, d, Wt, ldw, tmp, k);
+  d2h(c, out_host, tmp, size_t(k) * size_t(d) * 8);
+  if (scale != 1.0)
+    for (int64_t i = 0; i < d * k; ++i) out_host[i] *= scale;
 }
 
 void check_common(const double* moments, int64_t n, const int64_t* dims, int m, int k) {
