@@ -34,6 +34,9 @@ def _pair(n, d1, d2, seed, dtype, offset=0.0):
 # ---------------------------------------------------------------------------------------------
 # the wide route of pair_core (csrc/loss.hip): any view wider than 2048 columns
 # ---------------------------------------------------------------------------------------------
+_WIDE_CLOSED_FORM = {}
+
+
 @pytest.mark.parametrize("d1,d2,kind,offset", [
     (2304, 2304, "f64", 0.0), (2560, 2049, "f64", 3.0), (4096, 4096, "f64", 0.0),
     (2304, 2304, "f32", 0.0), (2560, 2049, "f32", 3.0), (4096, 4096, "f32", 0.0),
@@ -55,7 +58,13 @@ def test_wide_cca_loss_against_closed_form(d1, d2, kind, offset):
     loss = CCALoss(eps=eps)([a, b])
     loss.backward()
     check_async_errors()
-    l, g1, g2 = ol.cca_loss_closed_form(z1.numpy(), z2.numpy(), eps)
+    # the host closed form (two dense eigen-solves: 20 s at 4096) is evaluated ONCE per shape, on the float64 batch; the
+    # float32 case feeds the kernel that batch rounded to float32, which moves the closed form by ~1e-6 << its 1e-3 bar
+    key = (d1, d2, offset)
+    if key not in _WIDE_CLOSED_FORM:
+        y1, y2 = _pair(n, d1, d2, d1 + d2, torch.float64, offset)
+        _WIDE_CLOSED_FORM[key] = ol.cca_loss_closed_form(y1.numpy(), y2.numpy(), eps)
+    l, g1, g2 = _WIDE_CLOSED_FORM[key]
     assert abs(loss.item() - l) <= tol * abs(l), (loss.item(), l)
     assert rel_err(a.grad.cpu().numpy(), g1) < tol
     assert rel_err(b.grad.cpu().numpy(), g2) < tol
@@ -397,15 +406,16 @@ def test_pilot_inside_the_fifo_kernel(n):
 # ---------------------------------------------------------------------------------------------
 # per-column parity at the metric's dimensions on a WELL-POSED spectrum
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("kind", ["f64", "f32"])
-def test_ns_dimensions_per_column_on_a_separated_spectrum(kind):
+def test_ns_dimensions_per_column_on_a_separated_spectrum():
     """CCA, 2 x 4096 features, k = 64 -- the metric's dimensions -- on data whose 64 leading canonical correlations are
     separated by ~1.3e-2 (population values 0.985, 0.9722, ... 0.1786: orthonormal loadings of strength rho / (1 - rho)
     per latent, unit noise, n = 1e6 so that the sample noise floor ~0.13 stays below the last one; the sample gaps are
     asserted to exceed 8e-3).  With such gaps every single
     direction is well defined and the north-star bar applies PER COLUMN: weights and correlations within 1e-5
-    (float64 views) / 1e-3 (float32 views) of oracle.gram_form on the float64 moments of the same data
-    (cca_zoo/linear/_rcca.py:92-100)."""
+    (float64 views) / 1e-3 (float32 views) of oracle.gram_form on the float64 moments of the data
+    (cca_zoo/linear/_rcca.py:92-100).  One data set and ONE oracle solve (40 s of host LAPACK) serve both dtypes: the
+    float32 fit sees the float64 views rounded to float32, which moves the oracle's answer by ~1e-6 of a column, three
+    orders below that fit's 1e-3 bar."""
     import torch
 
     from cca_zoo_amd.linear import CCA
@@ -413,10 +423,9 @@ def test_ns_dimensions_per_column_on_a_separated_spectrum(kind):
     from oracle import gram_form as gf
 
     d, k, n = 4096, 64, 1_000_000
-    tdt = torch.float64 if kind == "f64" else torch.float32
     torch.cuda.empty_cache()                                # blocks cached by earlier tests are not "free" to mem_get_info
     free, _ = torch.cuda.mem_get_info()
-    if free < 2.6 * n * 2 * d * (8 if kind == "f64" else 4) + 12e9:
+    if free < 2.6 * n * 2 * d * 8 + 12e9:
         pytest.skip("not enough free HBM")
     rho = 0.985 - 0.0128 * np.arange(k)
     g = torch.Generator(device="cuda").manual_seed(77)
@@ -425,19 +434,19 @@ def test_ns_dimensions_per_column_on_a_separated_spectrum(kind):
     for v in range(2):
         q, _ = torch.linalg.qr(torch.randn(d, k, dtype=torch.float64, device="cuda", generator=g))
         loads.append((q * amp).T.contiguous())                      # k x d, row j = sqrt(s_j) q_j'
-    tv = [torch.empty(n, d, dtype=tdt, device="cuda") for _ in range(2)]
+    tv = [torch.empty(n, d, dtype=torch.float64, device="cuda") for _ in range(2)]
     step = 31250
     for r0 in range(0, n, step):
         z = torch.randn(step, k, dtype=torch.float64, device="cuda", generator=g)
         for v in range(2):
-            tv[v][r0:r0 + step] = (z @ loads[v] + torch.randn(step, d, dtype=torch.float64, device="cuda", generator=g)).to(tdt)
+            tv[v][r0:r0 + step] = z @ loads[v] + torch.randn(step, d, dtype=torch.float64, device="cuda", generator=g)
     m = CCA(latent_dimensions=k).fit(tv)
     # comparator: float64 moments of the same data (torch, chunked), oracle solve on the host
     D = 2 * d
     G = torch.zeros(D, D, dtype=torch.float64, device="cuda")
     s = torch.zeros(D, dtype=torch.float64, device="cuda")
     for r0 in range(0, n, step):
-        X = torch.cat([t[r0:r0 + step].double() for t in tv], dim=1)
+        X = torch.cat([t[r0:r0 + step] for t in tv], dim=1)
         G += X.T @ X
         s += X.sum(0)
         del X
@@ -445,12 +454,22 @@ def test_ns_dimensions_per_column_on_a_separated_spectrum(kind):
     del G
     gaps = -np.diff(sv)
     assert gaps.min() > 8e-3 and sv[0] < 0.99 and sv[-1] > 0.15, (gaps.min(), sv[0], sv[-1])   # the problem IS well posed
-    tol = 1e-5 if kind == "f64" else 1e-3
-    np.testing.assert_allclose(m.singular_values_, sv, rtol=tol)
-    for w, r in zip(m.weights_, W):
-        assert w.shape == (d, k)
-        assert col_rel_err(w, r) < tol, col_rel_err(w, r)
-    np.testing.assert_allclose(m.score(tv), sv, atol=10 * tol)
+
+    def check(model, views, tol):
+        np.testing.assert_allclose(model.singular_values_, sv, rtol=tol)
+        for w, r in zip(model.weights_, W):
+            assert w.shape == (d, k)
+            assert col_rel_err(w, r) < tol, col_rel_err(w, r)
+        np.testing.assert_allclose(model.score(views), sv, atol=10 * tol)
+
+    check(m, tv, 1e-5)
+    tv32 = []
+    while tv:                                               # float32 views of the same rows, the float64 ones released one by one
+        tv32.append(tv.pop(0).float())
+    torch.cuda.empty_cache()
+    m32 = CCA(latent_dimensions=k).fit(tv32)
+    assert m32.weights_[0].dtype == np.float32
+    check(m32, tv32, 1e-3)
 
 
 # ---------------------------------------------------------------------------------------------
