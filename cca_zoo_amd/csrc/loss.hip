@@ -14,9 +14,15 @@
 //   Gamma_ab = -2 M_ab / (n-1)   (a != b),      Gamma_aa = (2 (A M)_aa - 2 M_aa) / (n-1)
 // (for m = 2 these are the G12, G11 + G11', G22 + G22' of the two-view closed form).  Launch sequence, all on the
 // handle's stream with no host synchronisation until the very end:
-//   K1 (pilot-shifted for fp32) -> prep (Ce, mean, per-view copies) -> batched Cholesky + inverse (cholinv.hip,
-//   d/64 + 1 launches for all views together) -> 4 batched 64-tile GEMM launches (Sinv_a; A_ab; Gamma_ab;
-//   Gamma_aa = -sum_b A_ab Gamma_ba) -> loss reduction -> ONE sample-side GEMM (Z - mean) Gamma on the fp32 MFMA pipe.
+//   general path: K1 (pilot-shifted for fp32) -> prep (Ce, mean, per-view copies) -> batched Cholesky + inverse
+//   (cholinv.hip: one persistent launch, or d/64 + 1 launches) -> 4 batched 64-tile GEMM launches (Sinv_a; A_ab;
+//   Gamma_ab; Gamma_aa = -sum_b A_ab Gamma_ba) -> loss reduction -> sample-side GEMM(s) (Z - mean) Gamma;
+//   fast path (round 5; two aligned fp32 views <= 2048 columns, n % 32 == 0 -- a DCCA batch; CCZ_LOSS_FAST=0 turns it
+//   off): k_colsum_pilot -> K1 writing partial tiles (k_gram_f32_fifo_small) -> k_loss_prep_partials (reduce + Ce in
+//   the per-view layout + zeroed destinations) -> k_cholinv_chain -> the 4 GEMM stages, the loss riding on the third
+//   -> k_loss_tail -> [backward] ONE fp32 product over the two views where they lie, grad_output read on the device:
+//   10 dispatches per forward + backward (profiles/r05_loss_c4.md).  The two phases are separate entry
+//   points (pair_loss_forward_impl / pair_loss_backward_impl) joined by a caller-owned state buffer.
 // Views wider than 2048 columns (the metric shape, d = 4096) run the SAME formulas through the super-blocked
 // factorization, explicit triangular inverses and the 128-tile fp64 GEMM (pair_core, `narrow == false`); there the four
 // sample-side n x d x d products dominate.  Nothing on the narrow path is read back by the host: a non-positive pivot
