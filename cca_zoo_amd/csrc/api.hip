@@ -125,6 +125,7 @@ int ccz_destroy(ccz_handle h) {
     if (im->wait_ev) (void)hipEventDestroy(im->wait_ev);
     if (im->defer_own_ev) (void)hipEventDestroy(im->defer_own_ev);
     if (im->d2h_pin) (void)hipHostFree(im->d2h_pin);
+    for (hipEvent_t& e : im->d2h_tev) if (e) (void)hipEventDestroy(e);
     (void)hipFree(im->d_flag);
     (void)hipFree(im->d_small);
     delete im;

@@ -64,6 +64,7 @@ struct Impl {
   hipEvent_t wait_ev = nullptr;
   void* d2h_pin = nullptr;
   void* d2h_pin_dev = nullptr;      // device view of d2h_pin (host-mapped): written by a copy kernel
+  hipEvent_t d2h_tev[2] = {nullptr, nullptr};   // CCZ_TRACE_D2H: timing events around a read-back (this handle's device)
   static constexpr size_t kD2hPinBytes = size_t(4) << 20;
   void* deferred_event = nullptr;   // awaited by the next solve before it reads off-diagonal blocks (ccz_solve_defer, or the
                                     // handle's own event behind an unpack on a foreign stream)

@@ -179,7 +179,7 @@ void d2h(ccz_ctx* c, void* dst, const void* src, size_t bytes) {
     const char* me = std::getenv("CCZ_D2H_MODE");
     const int mode = me ? std::atoi(me) : 0;
     const bool trace = std::getenv("CCZ_TRACE_D2H") != nullptr;
-    static hipEvent_t tev[2] = {nullptr, nullptr};
+    hipEvent_t* tev = im->d2h_tev;
     const auto th0 = std::chrono::steady_clock::now();
     if (trace) {
       if (!tev[0]) { CCZ_HIP(hipEventCreate(&tev[0])); CCZ_HIP(hipEventCreate(&tev[1])); }

@@ -1,5 +1,5 @@
-import sys, time, numpy as np, torch
-sys.path.insert(0, '.')
+import os, sys, time, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cca_zoo_amd.linear import CCA
 from cca_zoo_amd import _backend
 rows, d = 262144, 4096
