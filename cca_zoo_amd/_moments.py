@@ -148,6 +148,10 @@ def compute_moments(views, handle=None, defer_offdiag=False):
         t_ar = time.perf_counter()
         n_total = h.moments_exchange(mom_ptr, D, dims, n)
         LAST["allreduce_ms"] = (time.perf_counter() - t_ar) * 1e3
+        if not defer_offdiag:
+            # the caller is not a solve (score, grid search, partial / group estimators): it reads off-diagonal blocks through
+            # other entry points, which do not wait for the tail -- consume the deferral now (a device-side wait)
+            h.solve_defer(None)
     elif sharded:
         # the one exchange step of the path, in two parts: [diag-block triangles | column sums | row count] and
         # [off-diagonal blocks] (ccz.h "blocks layout") -- D (D + 1) / 2 + D + 1 doubles in all, as the plain packed form

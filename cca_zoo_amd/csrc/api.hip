@@ -343,7 +343,13 @@ int ccz_moments_unpack_blocks(ccz_handle h, const double* packed_dev, int64_t D,
 }
 
 int ccz_solve_defer(ccz_handle h, void* event) {
-  CCZ_GUARD(h, impl(h)->deferred_event = event)
+  CCZ_GUARD(h, {
+    // event == NULL: a pending deferral (ccz_moments_exchange's tail, a foreign-stream unpack) is awaited NOW on the handle's
+    // stream -- a device-side wait, the host does not block -- for callers that go on to read off-diagonal blocks through
+    // entry points other than the solves (score, grid search, the partial / group estimators)
+    if (event) impl(h)->deferred_event = event;
+    else wait_deferred(h);
+  })
 }
 
 int ccz_moments_last_ms(ccz_handle h, double* gram_ms, double* colsum_ms) {

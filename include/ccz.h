@@ -132,7 +132,10 @@ CCZ_API int ccz_moments_unpack(ccz_handle h, const double* packed_dev, int64_t D
  * which: 1 = head, 2 = tail, 3 = both.  unpack's on_stream (hipStream_t as void*, NULL = the handle's stream) lets the
  * tail be unpacked on the stream the collective completes on; ccz_solve_defer(h, event) then makes the NEXT
  * ccz_{rcca,mcca,gcca}_solve wait for `event` (hipEvent_t as void*, recorded after that unpack) on the device right
- * before its first read of an off-diagonal block -- i.e. after the Cholesky chain of the diagonal blocks. */
+ * before its first read of an off-diagonal block -- i.e. after the Cholesky chain of the diagonal blocks.
+ * ccz_solve_defer(h, NULL): whatever is pending (this registration, a foreign-stream unpack's, ccz_moments_exchange's tail) is
+ * awaited NOW on the handle's stream (device-side; the host does not block) and cleared -- for callers that read off-diagonal
+ * blocks of the moments through entry points other than the three solves. */
 CCZ_API int ccz_moments_pack_blocks(ccz_handle h, const double* moments_dev, int64_t D, const int64_t* dims, int n_views,
                                     double* packed_dev, int which);
 CCZ_API int ccz_moments_unpack_blocks(ccz_handle h, const double* packed_dev, int64_t D, const int64_t* dims, int n_views,
@@ -160,8 +163,8 @@ CCZ_API int ccz_allreduce_sum_f64_multi(ccz_handle* handles, double* const* bufs
  * n_local rows) is packed in the blocks layout into a buffer the handle keeps between fits, the row count is written into the
  * head's spare slot on the device, head and tail are all-reduced on a stream of the handle's own, the head is unpacked on the
  * handle's stream, the tail behind its collective -- the next ccz_{rcca,mcca,gcca}_solve waits for that on the device right
- * before its first off-diagonal read, i.e. the tail's transfer overlaps the per-view factorizations.  *n_total_out: the
- * global row count (the call's only host read).  Needs ccz_comm_init_rank / _init_all.  CCZ_RCCL_LIB=path pins the RCCL
+ * before its first off-diagonal read, i.e. the tail's transfer overlaps the per-view factorizations (any OTHER reader of the
+ * off-diagonal blocks calls ccz_solve_defer(h, NULL) first).  *n_total_out: the global row count (the call's only host read).  Needs ccz_comm_init_rank / _init_all.  CCZ_RCCL_LIB=path pins the RCCL
  * library that is dlopen'ed. */
 CCZ_API int ccz_moments_exchange(ccz_handle h, double* moments_dev, int64_t D, const int64_t* dims, int n_views,
                                  int64_t n_local, int64_t* n_total_out);

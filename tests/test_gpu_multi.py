@@ -122,8 +122,8 @@ def test_whole_exchange_entry_world_size_one_and_buffer_reuse():
             mom = np.concatenate([np.triu(G).reshape(-1), rng.standard_normal(D)])
             buf = H.to_device(mom)
             assert H.moments_exchange(buf.ptr, D, dims, 1234) == 1234
-            H.sync()
-            torch.cuda.synchronize()
+            H.solve_defer(None)                               # not a solve: await the tail on the handle's stream (ccz.h) ...
+            H.sync()                                          # ... and that stream alone is what the host waits for
             got = H.to_host(buf, (D * D + D,))
             np.testing.assert_array_equal(np.triu(got[:D * D].reshape(D, D)), np.triu(G))
             np.testing.assert_array_equal(got[D * D:], mom[D * D:])

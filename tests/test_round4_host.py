@@ -66,6 +66,9 @@ def test_ccz_comm_route_of_row_sharded_on_the_host_double(monkeypatch):
         _dist.CczComm(h, uid, 2, 0)
     comm = _dist.CczComm(h, uid, 1, 0)
     assert h.comm_info() == (1, 0)
+    consumed = []
+    real_defer = h.solve_defer
+    monkeypatch.setattr(h, "solve_defer", lambda ev: (consumed.append(ev), real_defer(ev))[1])
     try:
         for make in (lambda: rCCA(latent_dimensions=3, c=0.2), lambda: MCCA(latent_dimensions=3, c=0.1)):
             vs = views[:2] if isinstance(make(), rCCA) else views
@@ -73,7 +76,10 @@ def test_ccz_comm_route_of_row_sharded_on_the_host_double(monkeypatch):
             with row_sharded(group=comm):
                 assert _dist.is_sharded() and _dist.rank_and_world(comm) == (0, 1)
                 sharded = make().fit(vs)
+                assert consumed == []                       # a fit leaves the exchange's tail to its solve (overlap) ...
                 sc = sharded.score(vs)
+                assert consumed and all(ev is None for ev in consumed)   # ... every other reader of the moments awaits it first
+                consumed.clear()
             for a, b in zip(plain.weights_, sharded.weights_):
                 np.testing.assert_array_equal(a, b)
             np.testing.assert_allclose(sc, plain.score(vs), rtol=1e-12)
