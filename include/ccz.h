@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-#define CCZ_VERSION 140 /* 0.1.4: ccz_pair_loss_forward / _backward / _state_bytes (the loss as an autograd node in two phases) */
+#define CCZ_VERSION 140 /* 0.1.4: ccz_pair_loss_forward / _backward / _state_bytes (the loss as an autograd node in two phases),
+                          * ccz_moments_exchange (the whole exchange step), ccz_solve_defer(h, NULL) = await a pending deferral now */
 
 #if defined(__GNUC__)
 #define CCZ_API __attribute__((visibility("default")))
