@@ -123,3 +123,48 @@ def test_bench_weights_agreement_separated_and_clustered_columns():
     W3 = W.copy()
     W3[:, 3] = rng.standard_normal(d)                                          # the cluster leaves the subspace
     assert not bench.weights_agreement([W3], [W], vals, 1e-3)["ok"]
+
+
+def test_ccz_comm_from_file_ignores_a_stale_id_and_cleans_up(tmp_path, monkeypatch):
+    """an id file left behind by an earlier run must never be joined.  The file carries a run tag; a reader polls
+    until an id with ITS tag appears, rank 0 removes whatever was there before it writes, and ``close()`` deletes the file.
+    (The host double has no transport beyond world size one, so the communicator's constructor is stubbed; the file protocol
+    is the code under test.)"""
+    import threading
+    import time
+
+    from cca_zoo_amd import _dist
+
+    h = hostsim_handle()
+    made = []
+
+    def fake_init(self, handle, unique_id, world, rank):
+        self.handle, self.world, self.rank = handle, world, rank
+        made.append((rank, bytes(unique_id)))
+
+    monkeypatch.setattr(_dist.CczComm, "__init__", fake_init)
+    monkeypatch.setattr(h, "comm_destroy", lambda: None)
+    path = str(tmp_path / "comm.id")
+    with open(path, "wb") as f:                       # a previous run's id: right length, another tag
+        f.write(b"\x11" * 128 + b"\x22" * 32)
+    got = {}
+
+    def reader():
+        got["comm"] = _dist.CczComm.from_file(path, 2, 1, handle=h, timeout_s=20.0, tag="run-2")
+
+    t = threading.Thread(target=reader)
+    t.start()
+    time.sleep(0.3)
+    assert t.is_alive() and not made                  # the stale file is there and is NOT accepted
+    monkeypatch.setattr(h, "comm_unique_id", lambda: b"\x5a" * 128)
+    c0 = _dist.CczComm.from_file(path, 2, 0, handle=h, tag="run-2")
+    t.join(timeout=20.0)
+    assert not t.is_alive()
+    assert sorted(made) == [(0, b"\x5a" * 128), (1, b"\x5a" * 128)]
+    assert os.path.exists(path)
+    got["comm"].close()                               # a reader does not own the file
+    assert os.path.exists(path)
+    c0.close()
+    assert not os.path.exists(path)
+    with pytest.raises(TimeoutError, match="for this run"):
+        _dist.CczComm.from_file(path, 2, 1, handle=h, timeout_s=0.2, tag="run-3")
