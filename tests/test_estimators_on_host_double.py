@@ -170,3 +170,21 @@ def test_grid_search_and_partial_edge_cases_on_host_double(host_double):
     assert gs.best_estimator_.weights_[0].shape[1] <= 5
     with pytest.warns(RuntimeWarning, match="fit failed"), pytest.raises(ValueError, match="All the 2 fits failed"):
         GridSearchCV(rCCA(), {"c": [2.0]}, cv=2).fit([X, Y])
+
+
+@pytest.mark.parametrize("tag", ["three", "two"])
+def test_deep_score_of_representations_matches_the_reference(host_double, tag):
+    """``BaseDeep.score`` (cca_zoo/deep/_base.py:159-173) = MCCA fit + score on the encoders' representations: the golden
+    holds representations and the reference's score (tools/gen_golden_deep_score.py)."""
+    from cca_zoo_amd.deep import score_representations
+
+    g = load_golden("deep_score")
+    reps, i = [], 0
+    while f"{tag}/rep{i}" in g:
+        reps.append(g[f"{tag}/rep{i}"])
+        i += 1
+    got = score_representations(reps, int(g[f"{tag}/k"]))
+    assert got.shape == g[f"{tag}/score"].shape
+    np.testing.assert_allclose(got, g[f"{tag}/score"], rtol=1e-8, atol=1e-10)
+    with pytest.raises(ValueError, match="two views"):
+        score_representations(reps[:1], 2)
