@@ -87,6 +87,8 @@ SIGNATURES = {
     "ccz_allreduce_sum_f64_multi": (_int, [C.POINTER(_vp), C.POINTER(_vp), _int, _i64]),
     "ccz_moments_last_ms": (_int, [_vp, _pdbl, _pdbl]),
     "ccz_moments_last_pilot": (_int, [_vp, _pint]),
+    "ccz_k1_route": (_int, [_vp, _int, _pint]),
+    "ccz_moments_last_route": (_int, [_vp, _pint, _pdbl, _pdbl, _pdbl]),
     "ccz_rcca_solve": (_int, [_vp, _vp, _i64, _pi64, _pdbl, _int, _int, _vp, _vp, _vp, _pint]),
     "ccz_mcca_solve": (_int, [_vp, _vp, _i64, _pi64, _int, _pdbl, _dbl, _int, _int, _vp, _vp, _vp, _pint]),
     "ccz_gcca_solve": (_int, [_vp, _vp, _i64, _pi64, _int, _pdbl, _pdbl, _dbl, _int, _int, _vp, _vp, _vp, _pint]),
@@ -379,6 +381,22 @@ class Handle:
         u = C.c_int(0)
         self.check(self.lib.ccz_moments_last_pilot(self._h, C.byref(u)))
         return bool(u.value)
+
+    K1_ROUTES = {"auto": 0, "fp32": 1, "bf16x2": 2, "fp64": 3}
+
+    def k1_route(self, route=None):
+        """Arithmetic route of fp32 views through K1 (include/ccz.h: CCZ_K1_*): "auto" | "fp32" | "bf16x2".  Returns the
+        previous setting's name; ``None`` only queries."""
+        prev = C.c_int(0)
+        code = -1 if route is None else (self.K1_ROUTES[route] if isinstance(route, str) else int(route))
+        self.check(self.lib.ccz_k1_route(self._h, code, C.byref(prev)))
+        return {v: k for k, v in self.K1_ROUTES.items()}[prev.value]
+
+    def moments_last_route(self):
+        """(route name, split_ms, mfma_ms, reduce_ms) of the last K1 launch on this handle (stage times: timed bf16x2 launches)."""
+        r, a, b, d = C.c_int(0), C.c_double(), C.c_double(), C.c_double()
+        self.check(self.lib.ccz_moments_last_route(self._h, C.byref(r), C.byref(a), C.byref(b), C.byref(d)))
+        return {v: k for k, v in self.K1_ROUTES.items()}.get(r.value, "none"), a.value, b.value, d.value
 
     # -- fused solves ----------------------------------------------------------------------
     def _solve_out(self, dims, k):

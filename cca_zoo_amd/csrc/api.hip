@@ -111,6 +111,7 @@ int ccz_destroy(ccz_handle h) {
     for (auto& e : im->xchg_ev) if (e) (void)hipEventDestroy(e);
     for (int i = 0; i < 4; ++i) (void)hipEventDestroy(im->ev[i]);
     for (int i = 0; i < 4; ++i) if (im->pipe_ev[i]) (void)hipEventDestroy(im->pipe_ev[i]);
+    for (auto& e : im->sp_ev) if (e) (void)hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) if (im->pin_buf[i]) (void)hipHostFree(im->pin_buf[i]);
     for (int i = 0; i < Impl::kSmallSlots; ++i) {
       if (im->small_ev[i]) (void)hipEventDestroy(im->small_ev[i]);
@@ -356,6 +357,23 @@ int ccz_moments_last_ms(ccz_handle h, double* gram_ms, double* colsum_ms) {
   CCZ_GUARD(h, {
     if (gram_ms) *gram_ms = h->last_gram_ms;
     if (colsum_ms) *colsum_ms = h->last_colsum_ms;
+  })
+}
+
+int ccz_k1_route(ccz_handle h, int route, int* previous) {
+  CCZ_GUARD(h, {
+    if (route < -1 || route > CCZ_K1_BF16X2) fail(CCZ_EINVAL, "k1_route: route must be CCZ_K1_AUTO, CCZ_K1_FP32 or CCZ_K1_BF16X2 (or -1 to query)");
+    if (previous) *previous = h->k1_route;
+    if (route >= 0) h->k1_route = route;
+  })
+}
+
+int ccz_moments_last_route(ccz_handle h, int* route, double* split_ms, double* mfma_ms, double* reduce_ms) {
+  CCZ_GUARD(h, {
+    if (route) *route = h->last_route;
+    if (split_ms) *split_ms = h->last_split_ms;
+    if (mfma_ms) *mfma_ms = h->last_mfma_ms;
+    if (reduce_ms) *reduce_ms = h->last_reduce_ms;
   })
 }
 

@@ -32,6 +32,7 @@
 #include <vector>
 
 #include "hip_common.h"
+#include "gram_map.h"
 
 namespace ccz {
 
@@ -55,56 +56,6 @@ typedef const double __attribute__((address_space(1)))* gptr_f64;
 // time).  Rows past the extent are out of range for the descriptor and read as 0, which is
 // exactly the zero padding the row tail needs.
 typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
-
-// blockIdx -> (tile, row chunk), XCD-aware.  The dispatcher is observed to place block b on XCD b % 8
-// (a speed hint only: any placement gives the same result).  The tile list is in supertile order
-// (4 x 8 blocks of tiles); XCD x owns the contiguous slice [x * per_xcd, (x+1) * per_xcd) of it and walks
-// that slice chunk after chunk, so the ~32 workgroups an XCD runs at any time are neighbouring tiles that
-// share panels through that XCD's 4 MiB L2, while all XCDs stream the same row chunk (Infinity Cache).
-// per_xcd == 0 selects the plain chunk-major order (small grids: one workgroup per CU matters more).
-struct WorkItem { int tile; int64_t chunk; bool valid; };
-__device__ __forceinline__ WorkItem locate_work(unsigned bid, int ntiles, int per_xcd, int64_t ksplit) {
-  WorkItem it;
-  if (per_xcd == 0) {
-    it.tile = int(bid % unsigned(ntiles));
-    it.chunk = bid / unsigned(ntiles);
-    it.valid = it.chunk < ksplit;
-    return it;
-  }
-  const unsigned x = bid & 7u, m = bid >> 3;
-  if (per_xcd < 0) {
-    // chunk-per-XCD order: XCD x works through row chunks x, x + 8, ... and walks the WHOLE tile list for each, so
-    // the 32 workgroups it runs at any time are 32 consecutive tiles of one chunk -- a 4 x 8 supertile that shares 12
-    // panels through that XCD's L2.  Odd local chunks walk the list backwards: the list's ragged tail (528 tiles =
-    // 16.5 rounds of 32) meets the tail of the next chunk and the two half rounds fill the XCD together.
-    // XCD x enters its (cyclic) sequence x * rot items in, rot a multiple of 32: at any moment the eight XCDs are on
-    // different supertiles (no two flush the same tile of G or stream the same columns at the same time)
-    const unsigned total = unsigned(ksplit >> 3) * unsigned(ntiles);
-    const unsigned rot = (total >> 8) << 5;
-    unsigned mm = m + x * rot;
-    if (mm >= total) mm -= total;
-    const unsigned lc = mm / unsigned(ntiles);
-    unsigned t = mm - lc * unsigned(ntiles);
-    if (lc & 1u) t = unsigned(ntiles) - 1u - t;
-    it.tile = int(t);
-    it.chunk = int64_t(lc) * 8 + x;
-    it.valid = it.chunk < ksplit;
-    return it;
-  }
-  it.chunk = m / unsigned(per_xcd);
-  it.tile = int(x) * per_xcd + int(m % unsigned(per_xcd));
-  it.valid = it.chunk < ksplit && it.tile < ntiles;
-  return it;
-}
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t panel_rsrc(const void* base, int64_t bytes) {
-  const uint64_t p = reinterpret_cast<uint64_t>(base);
-  const unsigned lo = __builtin_amdgcn_readfirstlane(unsigned(p));
-  const unsigned hi = __builtin_amdgcn_readfirstlane(unsigned(p >> 32));
-  const unsigned nb = __builtin_amdgcn_readfirstlane(unsigned(bytes));
-  void* q = reinterpret_cast<void*>((uint64_t(hi) << 32) | lo);
-  return __builtin_amdgcn_make_buffer_rsrc(q, 0, int(nb), 0x00020000);
-}
 
 // ---------------------------------------------------------------------------
 // fp32: 256 x 256 tile per workgroup, 4 waves (2 x 2), each wave 128 x 128 =
@@ -1234,6 +1185,22 @@ bool launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
   static const int pilot_env = [] { const char* e = getenv("CCZ_GRAM_PILOT"); return e ? atoi(e) : -1; }();   // -1: caller's mode
   if (pilot_env == 0 || pilot_env == 1) pilot_mode = pilot_env == 1 ? 2 : 0;
   if (!is32) pilot_mode = 0;                                  // fp64 views accumulate in fp64: nothing to protect
+  // arithmetic route of fp32 views (ccz_k1_route): the split-bf16 route always shifts by the pilot -- the subtraction rides
+  // in its split pass for free and needs no read-back
+  bool split = false;
+  if (is32) {
+    static const int route_env = [] {
+      const char* e = getenv("CCZ_K1_ROUTE");
+      if (!e) return 0;
+      if (!strcmp(e, "fp32")) return int(CCZ_K1_FP32);
+      if (!strcmp(e, "bf16x2")) return int(CCZ_K1_BF16X2);
+      return 0;
+    }();
+    const int route = c->k1_route != CCZ_K1_AUTO ? c->k1_route : route_env;
+    split = route == CCZ_K1_BF16X2 || (route == CCZ_K1_AUTO && gram_split_worthwhile(n, D));
+    if (split) pilot_mode = 2;
+  }
+  c->last_route = !is32 ? CCZ_K1_FP64 : (split ? CCZ_K1_BF16X2 : CCZ_K1_FP32);
   static const double pilot_thr = [] { const char* e = getenv("CCZ_GRAM_PILOT_RATIO"); return e ? atof(e) : 2.0; }();
   double* s_launch = s;            // column sums of THIS launch's rows (separate from the running sums in pilot modes)
   double* sq = nullptr;
@@ -1292,12 +1259,14 @@ bool launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
   // staged fp32 kernel on a small grid: per-(chunk, tile) partial sums + one reduce instead of contended atomics
   float* partial = nullptr;
   const bool staged32 = is32 && !(fast && impl_sel != 0 && !use_pilot) && !fifo_pilot;
-  if (staged32 && ksplit >= 2 && !sliced) {
+  if (staged32 && ksplit >= 2 && !sliced && !split) {
     static const int64_t partial_cap = [] { const char* e = getenv("CCZ_GRAM_PARTIAL_MB"); return (e ? atoll(e) : 192LL) << 20; }();
     const int64_t bytes = ksplit * int64_t(ntiles) * T32 * T32 * 4;
     if (bytes <= partial_cap) partial = static_cast<float*>(dev_alloc(c, size_t(bytes)));
   }
-  if (is32) {
+  if (split) {
+    gram_split_f32(c, views, n_views, n, G, D, pilot, time_it);
+  } else if (is32) {
     if (fifo_pilot) {
       const size_t fifo_bytes = size_t(4) * FR * FSLOT;
       CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_f32_fifo<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(fifo_bytes)));

@@ -1,0 +1,489 @@
+// K1 on the bf16 matrix pipe: fp32 second moments from TWO bf16 planes ("bf16 split-accumulate ... only if
+// it holds the 1e-3 bar").
+//
+//   d = fl32(x - p)            p: the launch's pilot (fp32 column mean), subtracted once, undone in fp64 (k_pilot_fixup)
+//   d = hi + mid + lo          hi = bf16(d), mid = bf16(d - hi)  (d - hi is exact in fp32), |mid| <= 2^-8 |d|, |lo| <= 2^-16 |d|
+//   d_i d_j = hi_i hi_j + hi_i mid_j + mid_i hi_j  [+ mid_i mid_j + hi_i lo_j + lo_i hi_j + ...]
+//
+// The three kept products run as THREE MFMAs into ONE fp32 accumulator per k-step (operand sequences (H, H, M) x (H, M, H)),
+// so an output tile needs no symmetrisation pass and costs 3 bf16 MFMAs per fp32 one it replaces -- at 16x the fp32 MFMA
+// rate.  Of the dropped terms only mid_i mid_i on the DIAGONAL is systematic (a sum of squares); it is added back exactly
+// from sum_k mid_ik^2, which the split pass accumulates on the side.  The rest are zero-mean at 2^-16 per product and
+// average out over the rows like the fp32 kernel's own accumulation error (measured in bench.py: k1_rel_err of both routes).
+// Accumulation is unchanged from the fp32 kernel: fp32 inside a row chunk (<= 16384 rows), fp64 across chunks.
+//
+// Data layout.  The MFMA operand of v_mfma_f32_32x32x16_bf16 is 8 consecutive k (= ROWS of a view) of one column per lane,
+// which row-major views cannot deliver coalesced -- so the split pass also transposes, into the exact LDS image the Gram
+// kernel wants:  planes[panel p][k-step s][plane H|M][column tile t: 8][k half h: 2][column c: 32][k: 8]  (bf16), i.e. one
+// panel (256 columns) x one k-step (16 rows) = 16 KiB, and every 1 KiB run of it is one MFMA operand of one wave
+// (lane l = (h, c) holds its 16 bytes).  The Gram kernel streams those runs with buffer_load ... lds (LDS-DMA: lane-linear
+// image, no VGPRs, no ds_write) and reads them back with conflict-free ds_read_b128 -- no address arithmetic anywhere.
+// Views are padded per view to whole panels and the rows to whole k-steps with zeros (d = 0, not x - p), so every tile is
+// a full tile: ragged widths, unaligned rows and odd leading dimensions all take this one path.
+//
+// Gram kernel: 256 x 256 output tile per workgroup, 4 waves (2 x 2) of 128 x 128 = 4 x 4 MFMA tiles, one wave per SIMD
+// (256 accumulator registers).  LDS: a 4-slot ring of k-steps (32 KiB each: A panel H|M, B panel H|M); each wave DMAs a
+// quarter of every slot.  One barrier per k-step: wave-side `s_waitcnt vmcnt(16)` (its own DMAs of step s + 1 have landed)
+// -> s_barrier (everybody's have; everybody has finished reading slot s) -> DMA of step s + 4 into slot s -> fragments of
+// step s + 1 from LDS while the 48 MFMAs of step s run.  Three k-steps of loads are always in flight.
+//
+// Output: per (row chunk, tile) fp32 partial tiles with plain 16-byte stores (no atomics); k_split_reduce adds the chunks
+// up in fp64 into G and applies the diagonal correction.
+//
+// Roofline: executed flops = 3 x n Dp (Dp + 256) on the bf16 pipe (2.5 PF dense peak); algorithmic F = n D (D + 1).
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "hip_common.h"
+#include "gram_map.h"
+
+namespace ccz {
+
+typedef float sp_v16f32 __attribute__((ext_vector_type(16)));
+typedef float sp_v4f32 __attribute__((ext_vector_type(4)));
+typedef __bf16 sp_v8bf16 __attribute__((ext_vector_type(8)));
+typedef __bf16 sp_v2bf16 __attribute__((ext_vector_type(2)));
+typedef float sp_v2f32 __attribute__((ext_vector_type(2)));
+typedef unsigned int sp_v4u32 __attribute__((ext_vector_type(4)));
+
+constexpr int SP_T = 256;            // columns per panel / tile edge
+constexpr int SP_K = 16;             // rows per k-step
+constexpr int SP_PSTEP = 16384;      // bytes of one panel x one k-step: [plane 2][tile 8][half 2][col 32][k 8] bf16
+constexpr int SP_PLANE = 8192;       // bytes of one plane of it
+constexpr int SP_STAGE = 2 * SP_PSTEP;   // LDS slot: A panel | B panel
+constexpr int SP_NST = 4;            // ring slots
+constexpr int SP_RB = 512;           // rows per workgroup of the split pass
+
+struct SplitPanel {
+  const float* base;     // first column of the panel in its view, row 0 of the view
+  int64_t ld;
+  int32_t width;         // valid columns (<= 256); the rest of the panel is zero
+  int32_t gcol0;         // column of G (and of pilot / msq) of the panel's first column
+};
+
+struct SplitTile {
+  int32_t pa, pb;        // panels (pa <= pb)
+  int32_t out_row, out_col;
+  int32_t wa, wb;
+  int32_t diag;
+  int32_t pad_;
+};
+
+// ---------------------------------------------------------------------------
+// split pass: fp32 rows [r0, r0 + nrows) of every view -> the two bf16 planes of this launch (k-steps [0, ksteps)),
+// and msq[j] += sum_k mid_kj^2.  grid = (row blocks of SP_RB rows, panels).  A thread owns 4 consecutive columns and, per
+// pass, the 8 rows of one k half: its 8 float4 loads are one 1 KiB-per-wave row segment each, its stores 64 contiguous
+// bytes per plane.  HBM-bound: 4 bytes in, 4 bytes out per element.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned sp_pack2(float a, float b) {
+  const sp_v2f32 f = {a, b};
+  const sp_v2bf16 h = __builtin_convertvector(f, sp_v2bf16);      // v_cvt_pk_bf16_f32: round to nearest even
+  return __builtin_bit_cast(unsigned, h);
+}
+
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void k_split_bf16x2(const SplitPanel* __restrict__ panels, int64_t r0, int64_t nrows, int64_t ksteps,
+                                                      const float* __restrict__ pilot, char* __restrict__ planes,
+                                                      double* __restrict__ msq) {
+  __shared__ float red[4][256];
+  const SplitPanel pn = panels[blockIdx.y];
+  const int tid = threadIdx.x, cg = tid & 63, rg = tid >> 6;
+  const int64_t rows_pad = ksteps * SP_K;
+  const int64_t rb0 = int64_t(blockIdx.x) * SP_RB;
+  const int c0 = 4 * cg;
+  sp_v4f32 p = {0.f, 0.f, 0.f, 0.f};
+  bool cok[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    cok[e] = c0 + e < pn.width;
+    if (pilot && cok[e]) p[e] = pilot[pn.gcol0 + c0 + e];
+  }
+  const float* __restrict__ X = pn.base + c0;
+  char* out = planes + int64_t(blockIdx.y) * ksteps * SP_PSTEP + (cg >> 3) * 1024 + (cg & 7) * 64;
+  sp_v4f32 q = {0.f, 0.f, 0.f, 0.f};
+  for (int pass = 0; pass < SP_RB / 32; ++pass) {
+    const int64_t row = rb0 + pass * 32 + rg * 8;          // first of this thread's 8 rows (within the launch)
+    if (row >= rows_pad) break;
+    sp_v4f32 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const bool rok = row + k < nrows;
+      const float* src = X + (r0 + (rok ? row + k : 0)) * pn.ld;
+      if (ALIGNED) {
+        v[k] = p;                                          // (whole 4-column groups are inside or outside the panel's width)
+        if (cok[0]) v[k] = *reinterpret_cast<const sp_v4f32*>(src);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[k][e] = cok[e] ? src[e] : 0.f;
+      }
+      if (!rok) v[k] = p;                                  // d = 0 exactly for the rows that pad the last k-step
+    }
+    sp_v4u32 hw[4], mw[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float d[8], m[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) d[k] = cok[e] ? v[k][e] - p[e] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; k += 2) {
+        const unsigned hb = sp_pack2(d[k], d[k + 1]);
+        hw[e][k >> 1] = hb;
+        m[k] = d[k] - __builtin_bit_cast(float, hb << 16);            // exact: hi shares d's leading bits
+        m[k + 1] = d[k + 1] - __builtin_bit_cast(float, hb & 0xffff0000u);
+        const unsigned mb = sp_pack2(m[k], m[k + 1]);
+        mw[e][k >> 1] = mb;
+        const float m0 = __builtin_bit_cast(float, mb << 16), m1 = __builtin_bit_cast(float, mb & 0xffff0000u);
+        q[e] += m0 * m0 + m1 * m1;
+      }
+    }
+    char* dst = out + (row >> 4) * SP_PSTEP + ((row >> 3) & 1) * 512;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      *reinterpret_cast<sp_v4u32*>(dst + e * 16) = hw[e];
+      *reinterpret_cast<sp_v4u32*>(dst + SP_PLANE + e * 16) = mw[e];
+    }
+  }
+  // msq: the four row groups of the workgroup -> one fp64 atomic per column
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[rg][c0 + e] = q[e];
+  __syncthreads();
+  if (tid < pn.width) {
+    const double s = double(red[0][tid]) + double(red[1][tid]) + double(red[2][tid]) + double(red[3][tid]);
+    unsafeAtomicAdd(msq + pn.gcol0 + tid, s);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Gram kernel
+// ---------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* sp_lds_ptr;
+
+// DMA of this wave's quarter (8 KiB: one plane of one panel) of k-step `soff / SP_PSTEP` into slot `slot`
+#define SP_DMA(slot, soff)                                                                                          \
+  do {                                                                                                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_)                                                                \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(src, (sp_lds_ptr)(wr_base + (slot) * SP_STAGE + i_ * 1024), 16,   \
+                                                 voff, (soff) + i_ * 1024, 0, 0);                                   \
+  } while (0)
+
+__global__ __launch_bounds__(256, 1) void k_gram_bf16x2(const SplitTile* __restrict__ tiles, int ntiles, int per_xcd, int64_t ksplit,
+                                                        const char* __restrict__ planes, int64_t ksteps, int64_t steps_per_wg,
+                                                        float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const WorkItem wi = locate_work(blockIdx.x, ntiles, per_xcd, ksplit);
+  if (!wi.valid) return;
+  const SplitTile t = tiles[wi.tile];
+  const int64_t s0 = wi.chunk * steps_per_wg;
+  const int64_t s1 = min(ksteps, s0 + steps_per_wg);
+  if (s0 >= s1) return;
+  const int nsteps = int(s1 - s0);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+
+  // this wave's DMA share: plane (wave & 1) of panel (wave < 2 ? A : B); out-of-range k-steps arrive as zeros
+  const int64_t panel = wave < 2 ? t.pa : t.pb;
+  const __amdgpu_buffer_rsrc_t src =
+      panel_rsrc(planes + (panel * ksteps + s0) * SP_PSTEP + (wave & 1) * SP_PLANE, int64_t(nsteps - 1) * SP_PSTEP + SP_PLANE);
+  const int voff = lane * 16;
+  char* wr_base = smem + wave * SP_PLANE;
+  // fragment read bases: A panel tiles 4 wr .. 4 wr + 3, B panel tiles 4 wc .. 4 wc + 3
+  const char* rdA = smem + lane * 16 + wr * 4096;
+  const char* rdB = smem + SP_PSTEP + lane * 16 + wc * 4096;
+
+  sp_v16f32 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  sp_v8bf16 ah[2][4], am[2][4], bh[2][4], bm[2][4];
+  int soff = 0;
+#pragma unroll
+  for (int s = 0; s < SP_NST; ++s) {
+    SP_DMA(s, soff);
+    soff += SP_PSTEP;
+  }
+  asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti) {
+    ah[0][ti] = *reinterpret_cast<const sp_v8bf16*>(rdA + ti * 1024);
+    bh[0][ti] = *reinterpret_cast<const sp_v8bf16*>(rdB + ti * 1024);
+    bm[0][ti] = *reinterpret_cast<const sp_v8bf16*>(rdB + SP_PLANE + ti * 1024);
+    am[0][ti] = *reinterpret_cast<const sp_v8bf16*>(rdA + SP_PLANE + ti * 1024);
+  }
+
+  const int nloop = (nsteps + SP_NST - 1) / SP_NST;
+  for (int it = 0; it < nloop; ++it) {
+#pragma unroll
+    for (int u = 0; u < SP_NST; ++u) {
+      const int cur = u & 1, nxt = cur ^ 1;
+      const int nslot = (u + 1) % SP_NST;
+      // step s = 4 it + u: its fragments are in set `cur`; steps s+1 .. s+3 are in flight / landed in the other slots
+      asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      SP_DMA(u, soff);                       // step s + 4 -> the slot step s was read from
+      soff += SP_PSTEP;
+      __builtin_amdgcn_sched_barrier(0);
+      const char* nA = rdA + nslot * SP_STAGE;
+      const char* nB = rdB + nslot * SP_STAGE;
+      // ---- hi' hi: acc[ti][tj] += B_hi[tj]' A_hi[ti]  (operands swapped: a lane then holds 4 consecutive j of one i) ----
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti) {
+        ah[nxt][ti] = *reinterpret_cast<const sp_v8bf16*>(nA + ti * 1024);
+        bh[nxt][ti] = *reinterpret_cast<const sp_v8bf16*>(nB + ti * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+          acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[cur][tj], ah[cur][ti], acc[ti][tj], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // ---- hi' mid ----
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti) {
+        bm[nxt][ti] = *reinterpret_cast<const sp_v8bf16*>(nB + SP_PLANE + ti * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+          acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bm[cur][tj], ah[cur][ti], acc[ti][tj], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // ---- mid' hi ----
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti) {
+        am[nxt][ti] = *reinterpret_cast<const sp_v8bf16*>(nA + SP_PLANE + ti * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+          acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[cur][tj], am[cur][ti], acc[ti][tj], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the run-ahead DMAs (zeros past the extent) must land before the LDS is handed on
+
+  // epilogue: the chunk's fp32 sums -> this (chunk, tile)'s slot, row-major 256 x 256.  MFMA C layout with the operands swapped:
+  // lane l, register r of tile (ti, tj): i = 32 ti + (l & 31), j = 32 tj + (r & 3) + 8 (r >> 2) + 4 (l >> 5).
+  float* pt = partial + (wi.chunk * int64_t(ntiles) + wi.tile) * int64_t(SP_T * SP_T);
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti) {
+    float* prow = pt + (wr * 128 + ti * 32 + (lane & 31)) * SP_T + wc * 128 + 4 * (lane >> 5);
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const sp_v4f32 v = {acc[ti][tj][4 * g], acc[ti][tj][4 * g + 1], acc[ti][tj][4 * g + 2], acc[ti][tj][4 * g + 3]};
+        *reinterpret_cast<sp_v4f32*>(prow + tj * 32 + 8 * g) = v;
+      }
+  }
+}
+
+// G (upper tiles) += sum over the row chunks of the fp32 partial tiles, in fp64; diagonal: += sum_k mid^2 (the one dropped
+// product that does not average out).  grid = (64, tiles), a thread owns 4 consecutive elements of a tile row.
+__global__ __launch_bounds__(256) void k_split_reduce(const float* __restrict__ partial, const SplitTile* __restrict__ tiles, int ntiles,
+                                                      int64_t ksplit, double* __restrict__ G, int64_t ldg, const double* __restrict__ msq) {
+  const int tile = blockIdx.y;
+  const SplitTile t = tiles[tile];
+  const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const int i = e >> 8, j = e & 255;
+  if (i >= t.wa || j >= t.wb) return;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  const float* p = partial + int64_t(tile) * (SP_T * SP_T) + e;
+  const int64_t stride = int64_t(ntiles) * (SP_T * SP_T);
+  for (int64_t c = 0; c < ksplit; ++c) {
+    const sp_v4f32 v = *reinterpret_cast<const sp_v4f32*>(p + c * stride);
+    a0 += double(v[0]); a1 += double(v[1]); a2 += double(v[2]); a3 += double(v[3]);
+  }
+  const double a[4] = {a0, a1, a2, a3};
+  double* g = G + (int64_t(t.out_row) + i) * ldg + t.out_col + j;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (j + q >= t.wb) break;
+    double v = a[q];
+    if (t.diag && i == j + q) v += msq[t.out_row + i];
+    g[q] += v;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+namespace {
+
+// (i, j) panel pairs, i <= j, in launch order -- the order of gram.hip's tile table: whole 4 x 8 supertiles without a
+// diagonal tile first (32 consecutive tiles share 12 panels through an XCD's L2), then the diagonal tiles, then the rest
+std::vector<std::pair<int, int>> split_tile_order(int np) {
+  std::vector<std::pair<int, int>> full, dg, rest;
+  for (int I = 0; I < np; I += 4)
+    for (int J = (I / 8) * 8; J < np; J += 8) {
+      std::vector<std::pair<int, int>> blk;
+      bool has_diag = false;
+      for (int i = I; i < std::min(np, I + 4); ++i)
+        for (int j = std::max(i, J); j < std::min(np, J + 8); ++j) { blk.emplace_back(i, j); has_diag = has_diag || i == j; }
+      for (const auto& ij : blk) {
+        if (blk.size() == 32 && !has_diag) full.push_back(ij);
+        else (ij.first == ij.second ? dg : rest).push_back(ij);
+      }
+    }
+  full.insert(full.end(), dg.begin(), dg.end());
+  full.insert(full.end(), rest.begin(), rest.end());
+  return full;
+}
+
+size_t split_scratch_budget(ccz_ctx* c) {
+  static const double env_gb = [] { const char* e = getenv("CCZ_SPLIT_SCRATCH_GB"); return e ? atof(e) : 48.0; }();
+  const double cap = 0.4 * double(impl(c)->props.totalGlobalMem);
+  return size_t(std::max(64.0 * 1048576.0, std::min(env_gb * 1073741824.0, cap)));
+}
+
+}  // namespace
+
+// Does the split route pay for this launch?  (auto mode)  It carries an HBM pass over the rows, a reduce over the partial
+// tiles and two small table uploads; below ~1e11 algorithmic flops the fp32 kernel's single launch wins.
+bool gram_split_worthwhile(int64_t n, int64_t D) {
+  static const double min_flop = [] { const char* e = getenv("CCZ_SPLIT_MIN_FLOP"); return e ? atof(e) : 1e11; }();
+  return n >= 2048 && D >= 256 && double(n) * double(D) * double(D + 1) >= min_flop;
+}
+
+// G (upper tiles) += sum over rows of d d' for d = x - pilot (pilot may be null: d = x), through the split-bf16 route.
+// Everything is enqueued on the handle's stream; with time_it the three stages are timed with HIP events (one host wait per
+// row super-chunk) into c->last_split_ms / last_mfma_ms / last_reduce_ms.
+void gram_split_f32(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, double* G, int64_t D, const float* pilot, bool time_it) {
+  Impl* im = impl(c);
+  hipStream_t st = stream(c);
+  // ---- panels and tiles ----
+  std::vector<SplitPanel> panels;
+  bool aligned = true;
+  int64_t g0 = 0;
+  for (int v = 0; v < n_views; ++v) {
+    const float* base = static_cast<const float*>(views[v].data);
+    for (int64_t c0 = 0; c0 < views[v].cols; c0 += SP_T) {
+      SplitPanel p;
+      p.base = base + c0;
+      p.ld = views[v].ld;
+      p.width = int32_t(std::min<int64_t>(SP_T, views[v].cols - c0));
+      p.gcol0 = int32_t(g0 + c0);
+      panels.push_back(p);
+    }
+    if (views[v].cols % 4 != 0 || views[v].ld % 4 != 0 || reinterpret_cast<uintptr_t>(base) % 16 != 0) aligned = false;
+    g0 += views[v].cols;
+  }
+  const int np = int(panels.size());
+  if (D > 0x7fffffffLL - 256) fail(CCZ_EUNSUP, "gram (split route): stacked width too large");
+  std::vector<SplitTile> tiles;
+  for (const auto& ij : split_tile_order(np)) {
+    SplitTile t;
+    t.pa = ij.first; t.pb = ij.second;
+    t.out_row = panels[ij.first].gcol0; t.out_col = panels[ij.second].gcol0;
+    t.wa = panels[ij.first].width; t.wb = panels[ij.second].width;
+    t.diag = ij.first == ij.second ? 1 : 0;
+    t.pad_ = 0;
+    tiles.push_back(t);
+  }
+  const int ntiles = int(tiles.size());
+  SplitPanel* d_panels = static_cast<SplitPanel*>(dev_alloc(c, panels.size() * sizeof(SplitPanel)));
+  SplitTile* d_tiles = static_cast<SplitTile*>(dev_alloc(c, tiles.size() * sizeof(SplitTile)));
+  double* msq = static_cast<double*>(dev_alloc(c, size_t(D) * 8));
+  char* planes = nullptr;
+  float* partial = nullptr;
+  auto release = [&] {
+    if (partial) dev_free(c, partial);
+    if (planes) dev_free(c, planes);
+    dev_free(c, msq);
+    dev_free(c, d_tiles);
+    dev_free(c, d_panels);
+  };
+  try {
+    h2d_small(c, d_panels, panels.data(), panels.size() * sizeof(SplitPanel));
+    h2d_small(c, d_tiles, tiles.data(), tiles.size() * sizeof(SplitTile));
+
+    // ---- rows per launch (scratch budget) and per workgroup ----
+    const int ncu = std::max(1, im->props.multiProcessorCount);
+    static const int64_t max_steps = [] { const char* e = getenv("CCZ_SPLIT_ROWS"); return std::max<int64_t>(1, (e ? atoll(e) : 16384LL) / SP_K); }();
+    const double per_row = double(np) * SP_PSTEP / SP_K + double(ntiles) * (SP_T * SP_T * 4) / double(max_steps * SP_K);
+    const size_t budget = split_scratch_budget(c);
+    int64_t launch_rows = int64_t(double(budget) / per_row) / (max_steps * SP_K) * (max_steps * SP_K);
+    launch_rows = std::max<int64_t>(launch_rows, max_steps * SP_K);
+    const int64_t n_launch = (n + launch_rows - 1) / launch_rows;
+    launch_rows = ((n + n_launch - 1) / n_launch + SP_K - 1) / SP_K * SP_K;       // equal super-chunks
+    const size_t fifo_bytes = size_t(SP_NST) * SP_STAGE;
+    CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_bf16x2), hipFuncAttributeMaxDynamicSharedMemorySize, int(fifo_bytes)));
+    if (time_it) {
+      for (auto& e : im->sp_ev)
+        if (!e) CCZ_HIP(hipEventCreate(&e));
+    }
+    c->last_split_ms = c->last_mfma_ms = c->last_reduce_ms = 0.0;
+    size_t planes_cap = 0, partial_cap = 0;
+    for (int64_t r0 = 0; r0 < n; r0 += launch_rows) {
+      const int64_t rows = std::min(launch_rows, n - r0);
+      const int64_t ksteps = (rows + SP_K - 1) / SP_K;
+      // row chunk per workgroup: minimise rounds x (steps + fixed cost) like gram.hip::plan_rows; whole multiples of 8 chunks
+      // on a chip-filling grid select the chunk-per-XCD walk
+      int64_t best_k = 1;
+      {
+        const int64_t kmin = std::max<int64_t>(1, (ksteps + max_steps - 1) / max_steps);
+        const int64_t kmax = std::max<int64_t>(kmin, std::min<int64_t>(ksteps / 16, 8192));
+        double best = 1e300;
+        for (int64_t ks = kmin; ks <= kmax; ++ks) {
+          const int64_t steps = (ksteps + ks - 1) / ks;
+          const bool big = int64_t(ntiles) * ks >= 16 * int64_t(ncu);
+          int64_t rounds;
+          if (big && ks % 8 == 0) rounds = ((ks / 8) * int64_t(ntiles) + ncu / 8 - 1) / (ncu / 8);
+          else if (big) rounds = (int64_t((ntiles + 7) / 8) * ks + ncu / 8 - 1) / (ncu / 8);
+          else rounds = (int64_t(ntiles) * ks + ncu - 1) / ncu;
+          const double cost = (big && ks % 8 != 0 ? 1.03 : 1.0) * double(rounds) * double(steps + 24);
+          if (cost < best) { best = cost; best_k = ks; }
+        }
+      }
+      const int64_t steps_per_wg = (ksteps + best_k - 1) / best_k;
+      const int64_t ksplit = (ksteps + steps_per_wg - 1) / steps_per_wg;
+      const bool sliced = int64_t(ntiles) * ksplit >= 16 * int64_t(ncu);
+      const bool xchunks = sliced && ksplit % 8 == 0;
+      const int per_xcd = xchunks ? -1 : (sliced ? (ntiles + 7) / 8 : 0);
+      const int64_t nblocks = xchunks ? int64_t(ntiles) * ksplit : (sliced ? int64_t(8) * per_xcd * ksplit : int64_t(ntiles) * ksplit);
+      if (nblocks > 0x7fffffffLL) fail(CCZ_EUNSUP, "gram (split route): grid too large");
+      if ((int64_t(steps_per_wg) + SP_NST) * SP_PSTEP > 0x7fffffffLL) fail(CCZ_EUNSUP, "gram (split route): row chunk too long");
+      const size_t planes_bytes = size_t(np) * size_t(ksteps) * SP_PSTEP;
+      const size_t partial_bytes = size_t(ksplit) * size_t(ntiles) * (SP_T * SP_T * 4);
+      if (planes_bytes > planes_cap) { if (planes) dev_free(c, planes); planes = static_cast<char*>(dev_alloc(c, planes_bytes)); planes_cap = planes_bytes; }
+      if (partial_bytes > partial_cap) { if (partial) dev_free(c, partial); partial = static_cast<float*>(dev_alloc(c, partial_bytes)); partial_cap = partial_bytes; }
+      zero(c, msq, size_t(D) * 8);
+      if (time_it) CCZ_HIP(hipEventRecord(im->sp_ev[0], st));
+      {
+        const dim3 grid((unsigned)((ksteps * SP_K + SP_RB - 1) / SP_RB), (unsigned)np);
+        if (aligned) hipLaunchKernelGGL(k_split_bf16x2<true>, grid, dim3(256), 0, st, d_panels, r0, rows, ksteps, pilot, planes, msq);
+        else hipLaunchKernelGGL(k_split_bf16x2<false>, grid, dim3(256), 0, st, d_panels, r0, rows, ksteps, pilot, planes, msq);
+      }
+      if (time_it) CCZ_HIP(hipEventRecord(im->sp_ev[1], st));
+      hipLaunchKernelGGL(k_gram_bf16x2, dim3((unsigned)nblocks), dim3(256), fifo_bytes, st, d_tiles, ntiles, per_xcd, ksplit, planes, ksteps,
+                         steps_per_wg, partial);
+      if (time_it) CCZ_HIP(hipEventRecord(im->sp_ev[2], st));
+      hipLaunchKernelGGL(k_split_reduce, dim3(64, (unsigned)ntiles), dim3(256), 0, st, partial, d_tiles, ntiles, ksplit, G, D, msq);
+      CCZ_LAUNCH_CHECK();
+      if (time_it) {
+        CCZ_HIP(hipEventRecord(im->sp_ev[3], st));
+        CCZ_HIP(hipEventSynchronize(im->sp_ev[3]));
+        float a = 0.f, b = 0.f, d = 0.f;
+        CCZ_HIP(hipEventElapsedTime(&a, im->sp_ev[0], im->sp_ev[1]));
+        CCZ_HIP(hipEventElapsedTime(&b, im->sp_ev[1], im->sp_ev[2]));
+        CCZ_HIP(hipEventElapsedTime(&d, im->sp_ev[2], im->sp_ev[3]));
+        c->last_split_ms += a;
+        c->last_mfma_ms += b;
+        c->last_reduce_ms += d;
+      }
+    }
+  } catch (...) {
+    release();
+    throw;
+  }
+  release();
+}
+
+}  // namespace ccz

@@ -77,6 +77,7 @@ struct Impl {
   void* chain_dbg = nullptr;             // CCZ_CHAIN_DEBUG stamps
   struct K1Plan { uint64_t key; void* dev; int wgs; };
   std::vector<K1Plan> k1_plans;          // gram.hip: per-tile row splits of k_gram_f32_fifo_small, by batch shape
+  hipEvent_t sp_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // gram_split.hip: stage boundaries of a timed split-route launch
   unsigned* colsum_counters = nullptr;   // gram.hip: arrival counters of k_colsum_pilot (64 words, zero between launches)
   // comm.hip: ccz_moments_exchange -- the packed blocks buffer the handle keeps between fits (grown on demand), the stream its
   // collectives run on and the events that tie it to the handle's stream
@@ -169,6 +170,10 @@ struct GramPartials {
   // 3 ints per tile {first slot, slots, rows per slot}, slots of a tile contiguous, diagonal tiles in the FIFO kernel's layout
   int* tile_plan = nullptr;
 };
+// gram_split.hip: the same sums through two bf16 planes per view on the bf16 matrix pipe (hi'hi + hi'mid + mid'hi in one fp32
+// accumulator, the diagonal's mid'mid added back exactly): G (upper tiles) += sum_rows (x - pilot)(x - pilot)'.
+bool gram_split_worthwhile(int64_t n, int64_t D);
+void gram_split_f32(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, double* G, int64_t D, const float* pilot, bool time_it);
 bool gram_partials_f32(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, GramPartials* out);
 void gram_partials_release(ccz_ctx* c, GramPartials* gp);
 

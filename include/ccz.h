@@ -189,6 +189,25 @@ CCZ_API int ccz_moments_last_ms(ccz_handle h, double* gram_ms, double* colsum_ms
  * centres before any product (_base.py:97-99) and raw fp32 products would cancel catastrophically.  *used = 1 if
  * the last ccz_moments launch on this handle took that path. */
 CCZ_API int ccz_moments_last_pilot(ccz_handle h, int* used);
+/* Arithmetic route of fp32 views through K1 (fp64 views always run on the fp64 matrix pipe).
+ *   CCZ_K1_FP32    v_mfma_f32_32x32x2_f32 on the fp32 rows as they lie (the reference's own precision:
+ *                  np.linalg.svd in float32, _utils/_linalg.py:28; X1_w.T @ X2_w, linear/_rcca.py:96);
+ *   CCZ_K1_BF16X2  x - pilot = hi + mid (two bf16 planes, written by one transposing pass over the rows), the
+ *                  products hi'hi + hi'mid + mid'hi as three v_mfma_f32_32x32x16_bf16 into one fp32 accumulator,
+ *                  diag(sum mid^2) added back exactly -- 3 bf16 MFMAs for each fp32 one at 16x the rate; agreement
+ *                  with float64 moments is measured beside the fp32 route's in bench.py (k1_rel_err);
+ *   CCZ_K1_AUTO    (default) CCZ_K1_BF16X2 where it pays (n D (D+1) >= 1e11, n >= 2048, D >= 256), else CCZ_K1_FP32.
+ * The environment variable CCZ_K1_ROUTE = fp32 | bf16x2 overrides AUTO.  route = -1 only queries; *previous (may be
+ * NULL) receives the handle's setting before the call. */
+#define CCZ_K1_AUTO 0
+#define CCZ_K1_FP32 1
+#define CCZ_K1_BF16X2 2
+#define CCZ_K1_FP64 3
+CCZ_API int ccz_k1_route(ccz_handle h, int route, int* previous);
+/* route the last ccz_moments launch on this handle took (CCZ_K1_FP32 / CCZ_K1_BF16X2 / CCZ_K1_FP64) and, for a timed
+ * CCZ_K1_BF16X2 launch, the HIP-event milliseconds of its three stages: the split pass (HBM-bound), the bf16 MFMA kernel
+ * and the fp64 reduce of the partial tiles (0 otherwise).  Any pointer may be NULL. */
+CCZ_API int ccz_moments_last_route(ccz_handle h, int* route, double* split_ms, double* mfma_ms, double* reduce_ms);
 
 /* ---- fused solves on reduced moments (replicated after the all-reduce) ----
  * Inputs: moments (device; only the upper triangle of G is read, so no symmetrisation is
