@@ -28,7 +28,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}   # dense MFMA peaks, MI355X_MICROARCH.md / datasheet
+PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6, "bf16": 2500.0}   # dense MFMA peaks, MI355X_MICROARCH.md / datasheet
 DATA_SEED = 20260
 
 
@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--d", type=int, default=4096)
     ap.add_argument("--k", type=int, default=64)
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
+    ap.add_argument("--k1-route", choices=["auto", "fp32", "bf16x2"], default=os.environ.get("CCZ_BENCH_K1_ROUTE", "auto"),
+                    help="arithmetic route of fp32 views through K1 (include/ccz.h: ccz_k1_route); auto = split-bf16 where it pays")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra configurations (C2, C3, C5, f64, losses, grid search)")
     ap.add_argument("--no-dcca", action="store_true")
@@ -53,7 +55,7 @@ def parse():
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="rows of the rCCA CPU comparator's sample (0: 2 d)")
     ap.add_argument("--cpu-runs", type=int, default=3, help="repeats of the rCCA CPU comparator at n = 2 d (a run is ~25 s; the median is reported)")
     ap.add_argument("--no-gates", action="store_true", help="skip the parity gates of the extras (the headline gate always runs)")
-    ap.add_argument("--only", default="", help="comma-separated subset of the extras to run (dcca, grid, host, metric_loss, configs, evd)")
+    ap.add_argument("--only", default="", help="comma-separated subset of the extras to run (routes, dcca, grid, host, metric_loss, configs, evd)")
     ap.add_argument("--transport", choices=["torch", "ccz"], default=os.environ.get("CCZ_BENCH_TRANSPORT", "torch"),
                     help="exchange step of the sharded fit: torch.distributed (nccl = RCCL) all-reduces, or libccz's own RCCL collective "
                          "behind the C ABI (ccz_moments_exchange); both run the two-part exchange that overlaps the factorization")
@@ -97,6 +99,70 @@ def k1_spot_check(views, jd, seed, row0=0, n_check=2048):
     rep["k1_rel_err"] = float((np.abs(flat[:D * D].reshape(D, D)[iu] - Gref[iu]) / scale).max())
     rep["ok"] = bool(ok and rep["k1_rel_err"] < (2e-5 if ndt == np.float32 else 1e-12))
     return rep
+
+
+def k1_rates(h, flop, g_ms, kind):
+    """Rates of the last K1 launch on handle ``h``: ``flop`` = ALGORITHMIC flops n D (D+1), ``g_ms`` = the whole K1 (for the
+    split-bf16 route: split pass + MFMA kernel + reduce).  The fp32 / fp64 kernels execute the algorithmic flops on their own
+    pipe; the split route executes THREE bf16 products per algorithmic one (hi'hi + hi'mid + mid'hi), so its roofline is
+    3 x flop over the MFMA kernel's own time against the dense bf16 peak, with the algorithmic rate beside it."""
+    route, split_ms, mfma_ms, reduce_ms = h.moments_last_route()
+    alg = flop / (g_ms * 1e-3) / 1e12
+    if route == "bf16x2" and mfma_ms > 0:
+        ex = 3.0 * flop / (mfma_ms * 1e-3) / 1e12
+        return {"k1_route": route, "gram_tflops": alg, "gram_executed_bf16_tflops": ex, "gram_frac_of_peak": ex / PEAK_TFLOPS["bf16"],
+                "gram_peak_tflops": PEAK_TFLOPS["bf16"], "gram_stages_ms": {"split": split_ms, "mfma": mfma_ms, "reduce": reduce_ms}}
+    return {"k1_route": route, "gram_tflops": alg, "gram_frac_of_peak": alg / PEAK_TFLOPS[kind], "gram_peak_tflops": PEAK_TFLOPS[kind]}
+
+
+def k1_routes_extra(h, views, make_model, chunk=16384, fits=3):
+    """Both arithmetic routes of K1 on ALL rows of the timed views: max relative error of a Gram entry against float64
+    moments of the same fp32 rows (device float64 GEMM in row chunks: the vendor's, a comparator outside every timed
+    region) and the fit time with the route forced.  The gate of the split route: its error is no larger than the fp32
+    kernel's on the same rows -- else it would be narrower arithmetic than the reference's float32 path."""
+    import numpy as np
+    import torch
+
+    n = int(views[0].shape[0])
+    dims = [int(v.shape[1]) for v in views]
+    D = sum(dims)
+    dev = views[0].device
+    G64 = torch.zeros(D, D, dtype=torch.float64, device=dev)
+    for r0 in range(0, n, chunk):
+        xc = torch.cat([v[r0:r0 + chunk] for v in views], dim=1).double()
+        G64.addmm_(xc.T, xc)
+        del xc
+    dg = torch.diag(G64)
+    iu = torch.triu(torch.ones(D, D, dtype=torch.bool, device=dev))
+    prev = h.k1_route(None)
+    out = {"rows": n, "D": D, "comparator": "float64 Gram of the same rows (torch.addmm on the device, row chunks of %d)" % chunk}
+    mom = torch.empty(D * D + D, dtype=torch.float64, device=dev)
+    try:
+        for route in ("fp32", "bf16x2"):
+            h.k1_route(route)
+            torch.cuda.synchronize()
+            h.moments([(v.data_ptr(), v.shape[1], v.stride(0)) for v in views], n, 0, True, mom.data_ptr())
+            h.sync()
+            g_ms = h.moments_last_ms()[0]
+            G = mom[:D * D].view(D, D)
+            err = torch.zeros((), dtype=torch.float64, device=dev)
+            for i0 in range(0, D, 1024):                       # row blocks: no second and third D x D temporaries
+                blk = (G[i0:i0 + 1024] - G64[i0:i0 + 1024]).abs() / torch.sqrt(dg[i0:i0 + 1024, None] * dg[None, :])
+                err = torch.maximum(err, blk[iu[i0:i0 + 1024]].max())
+            rec = {"k1_rel_err": float(err), "k1_ms": g_ms, **k1_rates(h, float(n) * D * (D + 1), g_ms, "f32")}
+            ts = []
+            for _ in range(fits + 1):
+                t0 = time.perf_counter()
+                make_model().fit(views)
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t0) * 1e3)
+            rec["fit_ms"] = float(np.median(ts[1:]))
+            out[route] = rec
+    finally:
+        h.k1_route(prev)
+    out["split_no_worse_than_fp32"] = bool(out["bf16x2"]["k1_rel_err"] <= out["fp32"]["k1_rel_err"])
+    del G64, mom
+    return out
 
 
 def check_fit_properties(model, views, jd, seed, row0=0, sharded=False, n_check=2048):
@@ -756,7 +822,7 @@ def config_extras(info, gates=True):
         flop = float(n) * D * (D + 1)
         kind = "f32" if tdt == torch.float32 else "f64"
         res = {"config": label, "fit_ms": ms, "fits_per_s": 1e3 / ms, "gram_ms": g_ms, "solve_ms": model.timings_["solve_ms_median"], "solve_ms_runs": model.timings_["solve_ms_all"],
-               "gram_tflops": flop / (g_ms * 1e-3) / 1e12, "gram_frac_of_peak": flop / (g_ms * 1e-3) / 1e12 / PEAK_TFLOPS[kind],
+               **k1_rates(h, flop, g_ms, kind),
                "dtype": kind, "n": n, "pilot_shifted_k1": bool(h.moments_last_pilot()),
                "score_top": float(np.asarray(model.score(views))[0])}
         if gates:
@@ -771,6 +837,7 @@ def config_extras(info, gates=True):
         out[tag] = res
         del views, model
         torch.cuda.empty_cache()
+        h.pool_trim()                         # the split route's planes and partial tiles (tens of GB) go back before the next draw
 
     run("c2_rcca", "configs[1]: rCCA n=100k, 2x1024, k=32, float32", (1024, 1024), 100_000, 32, torch.float32,
         lambda: rCCA(latent_dimensions=32, c=0.1), "rcca", 0.1, runs=5)
@@ -1124,6 +1191,7 @@ def main():
     from cca_zoo_amd.linear import CCA
 
     h = _backend.default_handle(local)
+    h.k1_route(a.k1_route)
     info = h.device_info()
     lo, hi = shard_bounds(a.n, rank, world)
     n_local = hi - lo
@@ -1153,6 +1221,7 @@ def main():
             model.fit(views)
 
     gram_ms, colsum_ms, solve_ms, allreduce_ms, exchange_events = [], [], [], [], []
+    stage_ms = []                                         # split-bf16 route: (split, mfma, reduce) of every timed step
     from cca_zoo_amd import _moments
 
     _moments.TIME_EXCHANGE = distributed                  # event pairs around the two parts of the exchange (no host waits)
@@ -1182,6 +1251,7 @@ def main():
         g, cs = h.moments_last_ms()
         gram_ms.append(g)
         colsum_ms.append(cs)
+        stage_ms.append(h.moments_last_route())
         solve_ms.append(model.timings_["solve_ms"])
         allreduce_ms.append(model.timings_["allreduce_ms"])
         step_ms.append((time.perf_counter() - ts) * 1e3)
@@ -1237,9 +1307,27 @@ def main():
         D = 2 * a.d
         flop = float(n_local) * D * (D + 1)                    # algorithmic flops of ONE Gram launch (this rank)
         g_ms = float(np.mean(gram_ms))
-        achieved = flop / (g_ms * 1e-3) / 1e12
-        peak = PEAK_TFLOPS[a.dtype]
-        traffic, traffic_src = gram_traffic(a.dtype, D, n_local)
+        route = stage_ms[-1][0] if stage_ms else ("fp32" if a.dtype == "f32" else "fp64")
+        if route == "bf16x2":
+            # split-bf16 route: the dominant kernel is k_gram_bf16x2, which EXECUTES 3 bf16 products per algorithmic one
+            # (hi'hi + hi'mid + mid'hi in one accumulator).  achieved = 3 x F_gram / that kernel's own HIP-event time against
+            # the dense bf16 peak; the algorithmic rate of the WHOLE K1 (split pass + MFMA kernel + reduce) stands beside it.
+            kernel, kernel_ms = "k_gram_bf16x2", float(np.mean([sm[2] for sm in stage_ms]))
+            achieved = 3.0 * flop / (kernel_ms * 1e-3) / 1e12
+            peak = PEAK_TFLOPS["bf16"]
+            traffic, traffic_src = gram_traffic("bf16x2", D, n_local)
+            roof_extra = {"executed_flop_per_launch": 3.0 * flop, "algorithmic_tflops": flop / (g_ms * 1e-3) / 1e12,
+                          "algorithmic_tflops_kernel_only": flop / (kernel_ms * 1e-3) / 1e12, "k1_ms": g_ms,
+                          "k1_stages_ms": {"split": float(np.mean([sm[1] for sm in stage_ms])), "mfma": kernel_ms,
+                                           "reduce": float(np.mean([sm[3] for sm in stage_ms]))},
+                          "arithmetic": "fp32 rows as two bf16 planes (x - pilot = hi + mid); 3 bf16 MFMAs per fp32 product, fp32 "
+                                        "accumulation per <= 16384-row chunk, fp64 across chunks; diag(sum mid^2) added back exactly"}
+        else:
+            kernel, kernel_ms = ("k_gram_f32_fifo" if a.dtype == "f32" else "k_gram_f64_fifo"), g_ms
+            achieved = flop / (g_ms * 1e-3) / 1e12
+            peak = PEAK_TFLOPS[a.dtype]
+            traffic, traffic_src = gram_traffic(a.dtype, D, n_local)
+            roof_extra = {}
         out = {
             "metric": "CCA fit()/sec at n=1e6 d=4096 k=64",
             "value": 1e3 / ms_per_step, "unit": "fit/s",
@@ -1253,10 +1341,10 @@ def main():
                        "device": info["name"], "arch": info["arch"], "compute_units": info["compute_units"]},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "k_gram_f32_fifo" if a.dtype == "f32" else "k_gram_f64_fifo",
-                         "kernel_ms": g_ms, "flop_per_launch": flop,
+                         "kernel": kernel, "k1_route": route,
+                         "kernel_ms": kernel_ms, "flop_per_launch": flop,
                          "bytes_per_launch": float(n_local) * D * (4 if a.dtype == "f32" else 8),
-                         "gram_share_of_step": g_ms / ms_per_step},
+                         "gram_share_of_step": g_ms / ms_per_step, **roof_extra},
             "phases_ms": {"gram": g_ms, "gram_per_rank": k1_ms_per_rank, "colsum": float(np.mean(colsum_ms)),
                           "allreduce": float(np.mean(allreduce_ms)), "allreduce_split": exchange_split,
                           "solve": float(np.mean(solve_ms)), "solve_min": float(np.min(solve_ms))},
@@ -1282,6 +1370,8 @@ def main():
 
             only = set(x for x in a.only.split(",") if x)
             want = lambda tag: not only or tag in only
+            if a.dtype == "f32" and want("routes"):
+                extra["k1_routes"] = k1_routes_extra(h, views, lambda: CCA(latent_dimensions=a.k))
             if not a.no_dcca and want("dcca"):
                 gated("dcca_loss", dcca_extra(gate=gates))
                 extra["dcca_training_step"] = training_step_extra()

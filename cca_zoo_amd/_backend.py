@@ -88,6 +88,7 @@ SIGNATURES = {
     "ccz_moments_last_ms": (_int, [_vp, _pdbl, _pdbl]),
     "ccz_moments_last_pilot": (_int, [_vp, _pint]),
     "ccz_k1_route": (_int, [_vp, _int, _pint]),
+    "ccz_pool_trim": (_int, [_vp, C.POINTER(C.c_size_t)]),
     "ccz_moments_last_route": (_int, [_vp, _pint, _pdbl, _pdbl, _pdbl]),
     "ccz_rcca_solve": (_int, [_vp, _vp, _i64, _pi64, _pdbl, _int, _int, _vp, _vp, _vp, _pint]),
     "ccz_mcca_solve": (_int, [_vp, _vp, _i64, _pi64, _int, _pdbl, _dbl, _int, _int, _vp, _vp, _vp, _pint]),
@@ -381,6 +382,12 @@ class Handle:
         u = C.c_int(0)
         self.check(self.lib.ccz_moments_last_pilot(self._h, C.byref(u)))
         return bool(u.value)
+
+    def pool_trim(self):
+        """Return the handle's cached scratch blocks to the driver (bytes released)."""
+        n = C.c_size_t(0)
+        self.check(self.lib.ccz_pool_trim(self._h, C.byref(n)))
+        return int(n.value)
 
     K1_ROUTES = {"auto": 0, "fp32": 1, "bf16x2": 2, "fp64": 3}
 

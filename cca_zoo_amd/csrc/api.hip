@@ -360,6 +360,18 @@ int ccz_moments_last_ms(ccz_handle h, double* gram_ms, double* colsum_ms) {
   })
 }
 
+int ccz_pool_trim(ccz_handle h, size_t* released_bytes) {
+  CCZ_GUARD(h, {
+    Impl* im = impl(h);
+    CCZ_HIP(hipStreamSynchronize(stream(h)));       // pooled blocks are recycled in stream order: nothing may still use them
+    size_t freed = 0;
+    for (auto it = im->pool.begin(); it != im->pool.end();) {
+      if (!it->used) { freed += it->bytes; (void)hipFree(it->p); it = im->pool.erase(it); } else ++it;
+    }
+    if (released_bytes) *released_bytes = freed;
+  })
+}
+
 int ccz_k1_route(ccz_handle h, int route, int* previous) {
   CCZ_GUARD(h, {
     if (route < -1 || route > CCZ_K1_BF16X2) fail(CCZ_EINVAL, "k1_route: route must be CCZ_K1_AUTO, CCZ_K1_FP32 or CCZ_K1_BF16X2 (or -1 to query)");

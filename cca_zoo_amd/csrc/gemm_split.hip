@@ -1,0 +1,232 @@
+// Sample-side product on the bf16 matrix pipe: the backward of the two-view DCCA loss at sizes where it is a large GEMM
+//   [dz_1 | dz_2] = alpha (*alpha_dev) ([z_1 | z_2] - 1 mean') Gamma           (cca_zoo/deep/objectives.py:61-102 through autograd)
+// M = n samples, N = K = D stacked features.  Same arithmetic as the split-bf16 K1 (split_mma.h): both operands as two bf16
+// planes, hi hi + hi mid + mid hi in one fp32 accumulator, fp32 accumulation over K -- the fp32 kernel it replaces
+// (gemm_big.hip: k_gemm_f32_nn_fifo2) accumulates the same K in fp32.
+//
+// Operand streams.  The contraction runs over the COLUMNS of z, so the A-side blocks hold, per 256-row tile of samples and
+// k-step of 16 columns, [plane][row tile 8][k half 2][row 32][k 8] bf16 -- 8 consecutive columns of one sample per lane.
+// k_splitT_bf16x2 writes them: one pass over the views (coalesced float4 rows in, the shift by the pilot p = fl32(mean) and
+// the hi / mid split in registers, a transpose through an XOR-swizzled LDS image, 4 KiB linear runs out).  The B side is
+// Gamma (rounded to fp32 by the forward) in the K1 layout: its rows are the contraction index, so gram_split.hip's own split
+// pass serves as it is.  The exact centring is finished on the d side:  sum_k (mean_k - p_k) Gamma_kn  is subtracted in the
+// epilogue (a D-vector formed in fp64).
+//
+// Kernel: k_gemm_bf16x2_nn = split_mma_core over all of K for one (256 samples x 256 outputs) tile; tiles are walked in
+// 4 x 8 supertiles per XCD (12 operand streams per 32 workgroups through that XCD's L2), sample-tile groups dealt round-robin
+// to the XCDs.  Epilogue: (acc - corr) * alpha with 16-byte stores into the two gradient tensors.
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
+
+#include "hip_common.h"
+#include "split_mma.h"
+
+namespace ccz {
+
+struct SplitTViews {
+  const float* data[8];
+  int64_t ld[8];
+  int off[9];          // first stacked column of view v; off[m] = K
+  int m;
+};
+
+// ---------------------------------------------------------------------------
+// transposing split pass: rows [r0, r0 + 256 * tiles) of the stacked views -> A-side blocks.  grid = (64-column blocks, row tiles).
+// A thread loads 16 float4 (4 consecutive columns of 16 rows, lanes along the columns: 256-byte row segments), so it holds
+// half of an 8-wide k group per row; the halves meet in the LDS image, which IS the 64 KiB global image of the workgroup's
+// four k-steps (swizzled: the 16 lanes of a row would hit two 8-byte slots; XOR of the row index with (k-step, k half)
+// spreads them over all sixteen).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_splitT_bf16x2(SplitTViews vw, int64_t r0, int64_t M, int64_t K, int64_t S, const double* __restrict__ mean,
+                                                       char* __restrict__ planes) {
+  __shared__ __attribute__((aligned(16))) char img[4 * SP_PSTEP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c4 = lane & 15, rr = lane >> 4;
+  const int64_t col = int64_t(blockIdx.x) * 64 + 4 * c4;
+  const int64_t row_tile = blockIdx.y;
+  const int64_t m0 = r0 + row_tile * 256;
+  // this thread's view and pilot
+  const bool cok = col < K;
+  int v = 0;
+  while (v + 1 < vw.m && col >= vw.off[v + 1]) ++v;
+  const float* X = vw.data[v] + (col - vw.off[v]);
+  const int64_t ld = vw.ld[v];
+  sp_v4f32 p = {0.f, 0.f, 0.f, 0.f};
+  if (cok && mean) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) p[e] = float(mean[col + e]);
+  }
+  sp_v4f32 x[16];
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int64_t m = m0 + wave * 64 + it * 4 + rr;
+    x[it] = p;                                       // d = 0 for padding rows and columns
+    if (cok && m < M) x[it] = *reinterpret_cast<const sp_v4f32*>(X + m * ld);
+  }
+  const int s_l = c4 >> 2, h = (c4 >> 1) & 1, khalf = c4 & 1;
+  const int swz = (s_l * 2 + h) & 7;
+  char* wbase = img + s_l * SP_PSTEP + h * 512 + khalf * 8;
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int rl = wave * 64 + it * 4 + rr;          // row within the 256-row tile
+    const sp_v4f32 d = x[it] - p;
+    const unsigned h0 = sp_pack2(d[0], d[1]), h1 = sp_pack2(d[2], d[3]);
+    const float m0f = d[0] - __builtin_bit_cast(float, h0 << 16), m1f = d[1] - __builtin_bit_cast(float, h0 & 0xffff0000u);
+    const float m2f = d[2] - __builtin_bit_cast(float, h1 << 16), m3f = d[3] - __builtin_bit_cast(float, h1 & 0xffff0000u);
+    const unsigned q0 = sp_pack2(m0f, m1f), q1 = sp_pack2(m2f, m3f);
+    char* w = wbase + (rl >> 5) * 1024 + (((rl & 31) ^ swz) * 16);
+    *reinterpret_cast<uint2*>(w) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(w + SP_PLANE) = make_uint2(q0, q1);
+  }
+  __syncthreads();
+  // image -> global: 16 runs of 4 KiB; logical offset L = it * 4096 + tid * 16 = [s_l 2][plane 1][t 3][h 1][r32 5][16 B]
+  char* out = planes + (row_tile * S + int64_t(blockIdx.x) * 4) * SP_PSTEP;
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int L = it * 4096 + tid * 16;
+    const int sl = L >> 14, hh = (L >> 9) & 1, r32 = (L >> 4) & 31;
+    const int phys = (L & ~(31 << 4)) | ((r32 ^ ((sl * 2 + hh) & 7)) << 4);
+    *reinterpret_cast<sp_v4u32*>(out + L) = *reinterpret_cast<const sp_v4u32*>(img + phys);
+  }
+}
+
+// corr[n] = sum_k (mean_k - fl32(mean_k)) Gamma[k][n]: what the pilot-shifted A side still owes the exact centring
+__global__ __launch_bounds__(256) void k_pilot_corr(const double* __restrict__ mean, const double* __restrict__ gamma, int64_t K, int64_t N,
+                                                    int64_t ldg, double* __restrict__ corr) {
+  const int64_t n = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (n >= N) return;
+  double a = 0.0;
+  for (int64_t k = 0; k < K; ++k) {
+    const double mk = mean[k];
+    a += (mk - double(float(mk))) * gamma[k * ldg + n];
+  }
+  corr[n] = a;
+}
+
+// ---------------------------------------------------------------------------
+// the product
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void k_gemm_bf16x2_nn(int64_t M, int64_t N, int64_t S, int64_t row_tiles, int64_t col_tiles,
+                                                           const char* __restrict__ planesA, const char* __restrict__ planesB, float alpha,
+                                                           const float* __restrict__ alpha_dev, const double* __restrict__ corr,
+                                                           float* __restrict__ C1, int64_t ldc1, float* __restrict__ C2, int64_t ldc2, int64_t nsplit,
+                                                           int64_t m_base) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // blockIdx -> (row tile, column tile): XCD x = b % 8 owns the row-tile groups (4 tiles each) x, x + 8, ...; per group it walks
+  // the column tiles 8 at a time: 32 consecutive workgroups of an XCD = a 4 x 8 supertile sharing 12 operand streams
+  const unsigned x = blockIdx.x & 7u, q = blockIdx.x >> 3;
+  const int64_t cgroups = (col_tiles + 7) / 8;
+  const int64_t per_group = cgroups * 32;
+  const int64_t rg = int64_t(q / per_group) * 8 + x;
+  const unsigned w = unsigned(q % per_group);
+  const int64_t rt = rg * 4 + ((w & 31u) >> 3);
+  const int64_t ct = int64_t(w >> 5) * 8 + (w & 7u);
+  if (rt >= row_tiles || ct >= col_tiles) return;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  sp_v16f32 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  split_mma_core(acc, smem, planesA + rt * S * SP_PSTEP, planesB + ct * S * SP_PSTEP, int(S), wave, lane);
+
+  if (alpha_dev) alpha *= *alpha_dev;
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti) {
+    const int64_t m = m_base + rt * 256 + wr * 128 + ti * 32 + (lane & 31);
+    if (m >= M) continue;
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int64_t n = ct * 256 + wc * 128 + tj * 32 + 8 * g + 4 * (lane >> 5);
+        if (n >= N) continue;
+        sp_v4f32 v = {acc[ti][tj][4 * g], acc[ti][tj][4 * g + 1], acc[ti][tj][4 * g + 2], acc[ti][tj][4 * g + 3]};
+        if (corr) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] -= float(corr[n + e]);
+        }
+        v *= alpha;
+        float* dst = n < nsplit ? C1 + m * ldc1 + n : C2 + m * ldc2 + (n - nsplit);
+        *reinterpret_cast<sp_v4f32*>(dst) = v;
+      }
+  }
+}
+
+// gram_split.hip: the K1-layout split of one fp32 matrix (rows = contraction index) into `ksteps` k-steps per 256-column panel
+void split_k1_layout(ccz_ctx* c, const float* X, int64_t rows, int64_t cols, int64_t ld, int64_t ksteps, char* planes);
+size_t split_scratch_budget(ccz_ctx* c);
+
+bool gemm_split_pair_eligible(int64_t M, int64_t N, int64_t K, int64_t K1, int64_t nsplit, const void* A1, int64_t lda1, const void* A2,
+                              int64_t lda2, const void* C1, int64_t ldc1, const void* C2, int64_t ldc2) {
+  const char* e_on = getenv("CCZ_LOSS_BWD_SPLIT");            // (read per call: tests lower the pay-off threshold)
+  const char* e_fl = getenv("CCZ_SPLIT_MIN_FLOP");
+  const int on = e_on ? atoi(e_on) : 1;
+  const double min_flop = e_fl ? atof(e_fl) : 1e11;
+  if (!on || M < 32768 || 2.0 * double(M) * double(N) * double(K) < 2.0 * min_flop) return false;
+  if (K1 <= 0 || K1 >= K || K1 % 4 != 0 || (K - K1) % 4 != 0 || N % 4 != 0 || nsplit % 4 != 0 || nsplit <= 0 || nsplit >= N) return false;
+  if (lda1 % 4 != 0 || lda2 % 4 != 0 || ldc1 % 4 != 0 || ldc2 % 4 != 0) return false;
+  for (const void* p : {A1, A2, C1, C2})
+    if (!p || reinterpret_cast<uintptr_t>(p) % 16 != 0) return false;
+  return true;
+}
+
+// [C1 | C2] (M x N, split at column nsplit) = alpha (*alpha_dev) ([A1 | A2] - 1 mean') B  with B = gamma32 (K x N fp32, ld N; gamma64 the
+// same matrix in float64, ld ldg, for the centring correction); mean: K column means (float64, device)
+void gemm_split_pair(ccz_ctx* c, int64_t M, int64_t N, int64_t K, int64_t K1, float alpha, const float* alpha_dev, const float* A1, int64_t lda1,
+                     const float* A2, int64_t lda2, const float* gamma32, const double* gamma64, int64_t ldg, const double* mean, float* C1,
+                     int64_t ldc1, float* C2, int64_t ldc2, int64_t nsplit) {
+  hipStream_t st = stream(c);
+  const int64_t S = (K + 63) / 64 * 4;                      // k-steps of 16, whole 64-column blocks of the transposing pass
+  const int64_t col_tiles = (N + SP_T - 1) / SP_T;
+  const size_t bytesB = size_t(col_tiles) * size_t(S) * SP_PSTEP;
+  // rows per launch from the scratch budget (A-side blocks: 4 bytes per element of the padded tile)
+  const size_t per_tile = size_t(S) * SP_PSTEP;
+  const size_t budget = split_scratch_budget(c);
+  int64_t tiles_per_launch = std::max<int64_t>(32, int64_t((budget > bytesB ? budget - bytesB : 0) / per_tile) / 32 * 32);
+  const int64_t row_tiles_all = (M + 255) / 256;
+  tiles_per_launch = std::min(tiles_per_launch, (row_tiles_all + 31) / 32 * 32);
+  char* planesB = static_cast<char*>(dev_alloc(c, bytesB));
+  char* planesA = nullptr;
+  double* corr = static_cast<double*>(dev_alloc(c, size_t(N) * 8));
+  auto release = [&] {
+    if (planesA) dev_free(c, planesA);
+    dev_free(c, corr);
+    dev_free(c, planesB);
+  };
+  try {
+    split_k1_layout(c, gamma32, K, N, N, S, planesB);
+    hipLaunchKernelGGL(k_pilot_corr, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, mean, gamma64, K, N, ldg, corr);
+    planesA = static_cast<char*>(dev_alloc(c, size_t(std::min(tiles_per_launch, row_tiles_all)) * per_tile));
+    SplitTViews vw{};
+    vw.m = 2;
+    vw.data[0] = A1; vw.ld[0] = lda1; vw.off[0] = 0;
+    vw.data[1] = A2; vw.ld[1] = lda2; vw.off[1] = int(K1);
+    vw.off[2] = int(K);
+    const size_t fifo_bytes = size_t(SP_NST) * SP_STAGE;
+    CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_bf16x2_nn), hipFuncAttributeMaxDynamicSharedMemorySize, int(fifo_bytes)));
+    for (int64_t t0 = 0; t0 < row_tiles_all; t0 += tiles_per_launch) {
+      const int64_t tiles = std::min(tiles_per_launch, row_tiles_all - t0);
+      hipLaunchKernelGGL(k_splitT_bf16x2, dim3((unsigned)(S / 4), (unsigned)tiles), dim3(256), 0, st, vw, t0 * 256, M, K, S, mean, planesA);
+      const int64_t rgroups = (tiles + 3) / 4;
+      const int64_t per_group = (col_tiles + 7) / 8 * 32;
+      const int64_t nblocks = (rgroups + 7) / 8 * per_group * 8;
+      if (nblocks > 0x7fffffffLL) fail(CCZ_EUNSUP, "gemm (split route): grid too large");
+      hipLaunchKernelGGL(k_gemm_bf16x2_nn, dim3((unsigned)nblocks), dim3(256), fifo_bytes, st, M, N, S, tiles, col_tiles, planesA, planesB, alpha,
+                         alpha_dev, corr, C1, ldc1, C2, ldc2, nsplit, t0 * 256);
+      CCZ_LAUNCH_CHECK();
+    }
+  } catch (...) {
+    release();
+    throw;
+  }
+  release();
+}
+
+}  // namespace ccz

@@ -39,23 +39,9 @@
 
 #include "hip_common.h"
 #include "gram_map.h"
+#include "split_mma.h"
 
 namespace ccz {
-
-typedef float sp_v16f32 __attribute__((ext_vector_type(16)));
-typedef float sp_v4f32 __attribute__((ext_vector_type(4)));
-typedef __bf16 sp_v8bf16 __attribute__((ext_vector_type(8)));
-typedef __bf16 sp_v2bf16 __attribute__((ext_vector_type(2)));
-typedef float sp_v2f32 __attribute__((ext_vector_type(2)));
-typedef unsigned int sp_v4u32 __attribute__((ext_vector_type(4)));
-
-constexpr int SP_T = 256;            // columns per panel / tile edge
-constexpr int SP_K = 16;             // rows per k-step
-constexpr int SP_PSTEP = 16384;      // bytes of one panel x one k-step: [plane 2][tile 8][half 2][col 32][k 8] bf16
-constexpr int SP_PLANE = 8192;       // bytes of one plane of it
-constexpr int SP_STAGE = 2 * SP_PSTEP;   // LDS slot: A panel | B panel
-constexpr int SP_NST = 4;            // ring slots
-constexpr int SP_RB = 512;           // rows per workgroup of the split pass
 
 struct SplitPanel {
   const float* base;     // first column of the panel in its view, row 0 of the view
@@ -78,12 +64,6 @@ struct SplitTile {
 // pass, the 8 rows of one k half: its 8 float4 loads are one 1 KiB-per-wave row segment each, its stores 64 contiguous
 // bytes per plane.  HBM-bound: 4 bytes in, 4 bytes out per element.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ unsigned sp_pack2(float a, float b) {
-  const sp_v2f32 f = {a, b};
-  const sp_v2bf16 h = __builtin_convertvector(f, sp_v2bf16);      // v_cvt_pk_bf16_f32: round to nearest even
-  return __builtin_bit_cast(unsigned, h);
-}
-
 template <bool ALIGNED>
 __global__ __launch_bounds__(256) void k_split_bf16x2(const SplitPanel* __restrict__ panels, int64_t r0, int64_t nrows, int64_t ksteps,
                                                       const float* __restrict__ pilot, char* __restrict__ planes,
@@ -150,7 +130,7 @@ __global__ __launch_bounds__(256) void k_split_bf16x2(const SplitPanel* __restri
 #pragma unroll
   for (int e = 0; e < 4; ++e) red[rg][c0 + e] = q[e];
   __syncthreads();
-  if (tid < pn.width) {
+  if (msq && tid < pn.width) {
     const double s = double(red[0][tid]) + double(red[1][tid]) + double(red[2][tid]) + double(red[3][tid]);
     unsafeAtomicAdd(msq + pn.gcol0 + tid, s);
   }
@@ -159,16 +139,6 @@ __global__ __launch_bounds__(256) void k_split_bf16x2(const SplitPanel* __restri
 // ---------------------------------------------------------------------------
 // Gram kernel
 // ---------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) void* sp_lds_ptr;
-
-// DMA of this wave's quarter (8 KiB: one plane of one panel) of k-step `soff / SP_PSTEP` into slot `slot`
-#define SP_DMA(slot, soff)                                                                                          \
-  do {                                                                                                              \
-    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_)                                                                \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(src, (sp_lds_ptr)(wr_base + (slot) * SP_STAGE + i_ * 1024), 16,   \
-                                                 voff, (soff) + i_ * 1024, 0, 0);                                   \
-  } while (0)
-
 __global__ __launch_bounds__(256, 1) void k_gram_bf16x2(const SplitTile* __restrict__ tiles, int ntiles, int per_xcd, int64_t ksplit,
                                                         const char* __restrict__ planes, int64_t ksteps, int64_t steps_per_wg,
                                                         float* __restrict__ partial) {
@@ -179,21 +149,9 @@ __global__ __launch_bounds__(256, 1) void k_gram_bf16x2(const SplitTile* __restr
   const int64_t s0 = wi.chunk * steps_per_wg;
   const int64_t s1 = min(ksteps, s0 + steps_per_wg);
   if (s0 >= s1) return;
-  const int nsteps = int(s1 - s0);
-
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
-
-  // this wave's DMA share: plane (wave & 1) of panel (wave < 2 ? A : B); out-of-range k-steps arrive as zeros
-  const int64_t panel = wave < 2 ? t.pa : t.pb;
-  const __amdgpu_buffer_rsrc_t src =
-      panel_rsrc(planes + (panel * ksteps + s0) * SP_PSTEP + (wave & 1) * SP_PLANE, int64_t(nsteps - 1) * SP_PSTEP + SP_PLANE);
-  const int voff = lane * 16;
-  char* wr_base = smem + wave * SP_PLANE;
-  // fragment read bases: A panel tiles 4 wr .. 4 wr + 3, B panel tiles 4 wc .. 4 wc + 3
-  const char* rdA = smem + lane * 16 + wr * 4096;
-  const char* rdB = smem + SP_PSTEP + lane * 16 + wc * 4096;
 
   sp_v16f32 acc[4][4];
 #pragma unroll
@@ -202,75 +160,10 @@ __global__ __launch_bounds__(256, 1) void k_gram_bf16x2(const SplitTile* __restr
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  split_mma_core(acc, smem, planes + (int64_t(t.pa) * ksteps + s0) * SP_PSTEP, planes + (int64_t(t.pb) * ksteps + s0) * SP_PSTEP,
+                 int(s1 - s0), wave, lane);
 
-  sp_v8bf16 ah[2][4], am[2][4], bh[2][4], bm[2][4];
-  int soff = 0;
-#pragma unroll
-  for (int s = 0; s < SP_NST; ++s) {
-    SP_DMA(s, soff);
-    soff += SP_PSTEP;
-  }
-  asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-#pragma unroll
-  for (int ti = 0; ti < 4; ++ti) {
-    ah[0][ti] = *reinterpret_cast<const sp_v8bf16*>(rdA + ti * 1024);
-    bh[0][ti] = *reinterpret_cast<const sp_v8bf16*>(rdB + ti * 1024);
-    bm[0][ti] = *reinterpret_cast<const sp_v8bf16*>(rdB + SP_PLANE + ti * 1024);
-    am[0][ti] = *reinterpret_cast<const sp_v8bf16*>(rdA + SP_PLANE + ti * 1024);
-  }
-
-  const int nloop = (nsteps + SP_NST - 1) / SP_NST;
-  for (int it = 0; it < nloop; ++it) {
-#pragma unroll
-    for (int u = 0; u < SP_NST; ++u) {
-      const int cur = u & 1, nxt = cur ^ 1;
-      const int nslot = (u + 1) % SP_NST;
-      // step s = 4 it + u: its fragments are in set `cur`; steps s+1 .. s+3 are in flight / landed in the other slots
-      asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      SP_DMA(u, soff);                       // step s + 4 -> the slot step s was read from
-      soff += SP_PSTEP;
-      __builtin_amdgcn_sched_barrier(0);
-      const char* nA = rdA + nslot * SP_STAGE;
-      const char* nB = rdB + nslot * SP_STAGE;
-      // ---- hi' hi: acc[ti][tj] += B_hi[tj]' A_hi[ti]  (operands swapped: a lane then holds 4 consecutive j of one i) ----
-#pragma unroll
-      for (int ti = 0; ti < 4; ++ti) {
-        ah[nxt][ti] = *reinterpret_cast<const sp_v8bf16*>(nA + ti * 1024);
-        bh[nxt][ti] = *reinterpret_cast<const sp_v8bf16*>(nB + ti * 1024);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int tj = 0; tj < 4; ++tj)
-          acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[cur][tj], ah[cur][ti], acc[ti][tj], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      // ---- hi' mid ----
-#pragma unroll
-      for (int ti = 0; ti < 4; ++ti) {
-        bm[nxt][ti] = *reinterpret_cast<const sp_v8bf16*>(nB + SP_PLANE + ti * 1024);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int tj = 0; tj < 4; ++tj)
-          acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bm[cur][tj], ah[cur][ti], acc[ti][tj], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      // ---- mid' hi ----
-#pragma unroll
-      for (int ti = 0; ti < 4; ++ti) {
-        am[nxt][ti] = *reinterpret_cast<const sp_v8bf16*>(nA + SP_PLANE + ti * 1024);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int tj = 0; tj < 4; ++tj)
-          acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[cur][tj], am[cur][ti], acc[ti][tj], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the run-ahead DMAs (zeros past the extent) must land before the LDS is handed on
-
-  // epilogue: the chunk's fp32 sums -> this (chunk, tile)'s slot, row-major 256 x 256.  MFMA C layout with the operands swapped:
-  // lane l, register r of tile (ti, tj): i = 32 ti + (l & 31), j = 32 tj + (r & 3) + 8 (r >> 2) + 4 (l >> 5).
+  // epilogue: the chunk's fp32 sums -> this (chunk, tile)'s slot, row-major 256 x 256
   float* pt = partial + (wi.chunk * int64_t(ntiles) + wi.tile) * int64_t(SP_T * SP_T);
 #pragma unroll
   for (int ti = 0; ti < 4; ++ti) {
@@ -306,6 +199,7 @@ __global__ __launch_bounds__(256) void k_split_reduce(const float* __restrict__ 
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     if (j + q >= t.wb) break;
+    if (t.diag && j + q < i) continue;          // below the diagonal of G: not authoritative anywhere (the pilot fix-up skips it too)
     double v = a[q];
     if (t.diag && i == j + q) v += msq[t.out_row + i];
     g[q] += v;
@@ -337,19 +231,51 @@ std::vector<std::pair<int, int>> split_tile_order(int np) {
   return full;
 }
 
+}  // namespace
+
 size_t split_scratch_budget(ccz_ctx* c) {
-  static const double env_gb = [] { const char* e = getenv("CCZ_SPLIT_SCRATCH_GB"); return e ? atof(e) : 48.0; }();
+  const char* e = getenv("CCZ_SPLIT_SCRATCH_GB");         // read per call: tests shrink it to force several row super-chunks
+  const double env_gb = e ? atof(e) : 48.0;
   const double cap = 0.4 * double(impl(c)->props.totalGlobalMem);
-  return size_t(std::max(64.0 * 1048576.0, std::min(env_gb * 1073741824.0, cap)));
+  return size_t(std::max(8.0 * 1048576.0, std::min(env_gb * 1073741824.0, cap)));
 }
 
-}  // namespace
+// The K1-layout planes of ONE fp32 matrix X (rows x cols, ld): panels of 256 columns, `ksteps` k-steps of 16 rows each (rows past
+// `rows` are zero) -- the B side of gemm_split.hip's product (X = Gamma: its rows are the contraction index).  No pilot, no msq.
+void split_k1_layout(ccz_ctx* c, const float* X, int64_t rows, int64_t cols, int64_t ld, int64_t ksteps, char* planes) {
+  std::vector<SplitPanel> panels;
+  for (int64_t c0 = 0; c0 < cols; c0 += SP_T) {
+    SplitPanel p;
+    p.base = X + c0;
+    p.ld = ld;
+    p.width = int32_t(std::min<int64_t>(SP_T, cols - c0));
+    p.gcol0 = int32_t(c0);
+    panels.push_back(p);
+  }
+  const bool aligned = cols % 4 == 0 && ld % 4 == 0 && reinterpret_cast<uintptr_t>(X) % 16 == 0;
+  SplitPanel* d_panels = static_cast<SplitPanel*>(dev_alloc(c, panels.size() * sizeof(SplitPanel)));
+  try {
+    h2d_small(c, d_panels, panels.data(), panels.size() * sizeof(SplitPanel));
+    const dim3 grid((unsigned)((ksteps * SP_K + SP_RB - 1) / SP_RB), (unsigned)panels.size());
+    if (aligned) hipLaunchKernelGGL(k_split_bf16x2<true>, grid, dim3(256), 0, stream(c), d_panels, int64_t(0), rows, ksteps, static_cast<const float*>(nullptr), planes, static_cast<double*>(nullptr));
+    else hipLaunchKernelGGL(k_split_bf16x2<false>, grid, dim3(256), 0, stream(c), d_panels, int64_t(0), rows, ksteps, static_cast<const float*>(nullptr), planes, static_cast<double*>(nullptr));
+    CCZ_LAUNCH_CHECK();
+  } catch (...) {
+    dev_free(c, d_panels);
+    throw;
+  }
+  dev_free(c, d_panels);
+}
 
 // Does the split route pay for this launch?  (auto mode)  It carries an HBM pass over the rows, a reduce over the partial
 // tiles and two small table uploads; below ~1e11 algorithmic flops the fp32 kernel's single launch wins.
 bool gram_split_worthwhile(int64_t n, int64_t D) {
-  static const double min_flop = [] { const char* e = getenv("CCZ_SPLIT_MIN_FLOP"); return e ? atof(e) : 1e11; }();
-  return n >= 2048 && D >= 256 && double(n) * double(D) * double(D + 1) >= min_flop;
+  const char* e_fl = getenv("CCZ_SPLIT_MIN_FLOP");
+  const double min_flop = e_fl ? atof(e_fl) : 1e11;
+  // n >= 32768: from there on the route's error against float64 moments is at or below the fp32 kernel's on the same rows
+  // (the dropped 2^-16 terms average out over the rows, the fp32 kernel's accumulation error grows with them; measured
+  // crossover 20k - 30k rows, tools/k1_route_check.py) -- below it the route is only taken when asked for
+  return n >= 32768 && D >= 256 && double(n) * double(D) * double(D + 1) >= min_flop;
 }
 
 // G (upper tiles) += sum over rows of d d' for d = x - pilot (pilot may be null: d = x), through the split-bf16 route.
@@ -406,7 +332,8 @@ void gram_split_f32(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
 
     // ---- rows per launch (scratch budget) and per workgroup ----
     const int ncu = std::max(1, im->props.multiProcessorCount);
-    static const int64_t max_steps = [] { const char* e = getenv("CCZ_SPLIT_ROWS"); return std::max<int64_t>(1, (e ? atoll(e) : 16384LL) / SP_K); }();
+    const char* rows_env = getenv("CCZ_SPLIT_ROWS");       // fp32 accumulation length (rows per workgroup), default 16384
+    const int64_t max_steps = std::max<int64_t>(1, (rows_env ? atoll(rows_env) : 16384LL) / SP_K);
     const double per_row = double(np) * SP_PSTEP / SP_K + double(ntiles) * (SP_T * SP_T * 4) / double(max_steps * SP_K);
     const size_t budget = split_scratch_budget(c);
     int64_t launch_rows = int64_t(double(budget) / per_row) / (max_steps * SP_K) * (max_steps * SP_K);

@@ -504,7 +504,7 @@ static LossShape loss_shape(const ccz_view* z, int m, int64_t n, int dtype, cons
   return sh;
 }
 
-// state: [Gamma fp64 (D x D) | centring row (D) | Gamma fp32 (D x D)]
+// state: [Gamma fp64 (D x D) | centring row mean' Gamma (D) | batch mean (D) | Gamma fp32 (D x D)]
 int64_t pair_loss_state_bytes_impl(int dtype, const int64_t* dims, int m) {
   if (!dims || m < 2 || m > LMAXV) return -1;
   int64_t D = 0;
@@ -513,7 +513,7 @@ int64_t pair_loss_state_bytes_impl(int dtype, const int64_t* dims, int m) {
     D += dims[a];
   }
   (void)dtype;
-  return (D + 1) * D * 8 + D * D * 4;
+  return (D + 2) * D * 8 + D * D * 4;
 }
 
 void pair_loss_forward_impl(ccz_ctx* c, int dtype, const ccz_view* z, int m, int64_t n, double eps, void* loss_dev, void* state) {
@@ -525,7 +525,7 @@ void pair_loss_forward_impl(ccz_ctx* c, int dtype, const ccz_view* z, int m, int
   const bool want = state != nullptr;
   double* gamma = static_cast<double*>(state);
   double* bias = want ? gamma + D * D : nullptr;
-  float* g32 = (want && dtype == CCZ_F32) ? reinterpret_cast<float*>(gamma + (D + 1) * D) : nullptr;
+  float* g32 = (want && dtype == CCZ_F32) ? reinterpret_cast<float*>(gamma + (D + 2) * D) : nullptr;
   DBuf mean(c, D), acc(c, 1);
   PoolPtr info(c, LMAXV * sizeof(int));
   // fp32 DCCA batch: K1's partial sums feed the preparation directly (no moments, no gather, no fills, no atomics).
@@ -548,6 +548,7 @@ void pair_loss_forward_impl(ccz_ctx* c, int dtype, const ccz_view* z, int m, int
     pair_core(c, mom, n, sh.dims, m, eps, want, acc, gamma, mean, info.as<int>(), bias, nullptr, narrow);
   }
   if (want) {
+    d2d(c, gamma + (D + 1) * D, mean.get(), size_t(D) * 8);      // the batch mean travels with the state (backward: pilot of the split route)
     hipLaunchKernelGGL(k_loss_tail, dim3((unsigned)((D + 63) / 64), (unsigned)((D + 63) / 64)), dim3(256), 0, st, gamma, mean.get(), D, bias, g32,
                        acc.get(), dtype, loss_dev, info.as<int>(), m, loss_status_dev(c));
   } else {
@@ -575,7 +576,16 @@ void pair_loss_backward_impl(ccz_ctx* c, int dtype, const ccz_view* z, int m, in
   hipStream_t st = stream(c);
   const double* gamma = static_cast<const double*>(state);
   const double* bias = gamma + D * D;
-  const float* g32 = reinterpret_cast<const float*>(gamma + (D + 1) * D);
+  const float* g32 = reinterpret_cast<const float*>(gamma + (D + 2) * D);
+  const double* mean = gamma + (D + 1) * D;
+  // a backward that is a large product (the metric shape: n = 1e6, D = 8192) runs on the bf16 pipe with the split arithmetic of K1
+  if (dtype == CCZ_F32 && m == 2 && all && c->k1_route != CCZ_K1_FP32 &&
+      gemm_split_pair_eligible(n, D, D, sh.dims[0], sh.dims[0], z[0].data, z[0].ld, z[1].data, z[1].ld, g[0], ldg[0], g[1], ldg[1])) {
+    gemm_split_pair(c, n, D, D, sh.dims[0], 1.0f, static_cast<const float*>(grad_out), static_cast<const float*>(z[0].data), z[0].ld,
+                    static_cast<const float*>(z[1].data), z[1].ld, g32, gamma, D, mean, static_cast<float*>(g[0]), ldg[0], static_cast<float*>(g[1]),
+                    ldg[1], sh.dims[0]);
+    return;
+  }
   if (dtype == CCZ_F32 && m == 2 && all && narrow_ok(sh.dims, m) &&
       gemm_f32_fifo_pair_eligible(n, D, D, sh.dims[0], sh.dims[0], z[0].data, z[0].ld, z[1].data, z[1].ld, g[0], ldg[0], g[1], ldg[1])) {
     gemm_f32_fifo_pair(c, n, D, D, sh.dims[0], 1.0f, static_cast<const float*>(grad_out), static_cast<const float*>(z[0].data), z[0].ld,

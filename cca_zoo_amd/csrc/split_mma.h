@@ -1,0 +1,130 @@
+// Split-bf16 MFMA core shared by the Gram kernel (gram_split.hip) and the sample-side product (gemm_split.hip): an fp32
+// operand d is carried as two bf16 planes d = hi + mid (+ lo, dropped), and a product of two such operands is
+//   hi_A hi_B + hi_A mid_B + mid_A hi_B      (three v_mfma_f32_32x32x16_bf16 into ONE fp32 accumulator).
+// Both operands arrive as streams of 16 KiB blocks, one per k-step of 16:  [plane H | M][tile t: 8][k half h: 2][index 32][k: 8]
+// bf16 -- 256 indices of the non-contracted dimension x 16 of the contracted one, every 1 KiB run one MFMA operand of one wave.
+#pragma once
+
+#include "hip_common.h"
+#include "gram_map.h"
+
+namespace ccz {
+
+typedef float sp_v16f32 __attribute__((ext_vector_type(16)));
+typedef float sp_v4f32 __attribute__((ext_vector_type(4)));
+typedef __bf16 sp_v8bf16 __attribute__((ext_vector_type(8)));
+typedef __bf16 sp_v2bf16 __attribute__((ext_vector_type(2)));
+typedef float sp_v2f32 __attribute__((ext_vector_type(2)));
+typedef unsigned int sp_v4u32 __attribute__((ext_vector_type(4)));
+
+constexpr int SP_T = 256;            // columns per panel / tile edge
+constexpr int SP_K = 16;             // rows per k-step
+constexpr int SP_PSTEP = 16384;      // bytes of one panel x one k-step: [plane 2][tile 8][half 2][col 32][k 8] bf16
+constexpr int SP_PLANE = 8192;       // bytes of one plane of it
+constexpr int SP_STAGE = 2 * SP_PSTEP;   // LDS slot: A panel | B panel
+constexpr int SP_NST = 4;            // ring slots
+constexpr int SP_RB = 512;           // rows per workgroup of the split pass
+
+__device__ __forceinline__ unsigned sp_pack2(float a, float b) {
+  const sp_v2f32 f = {a, b};
+  const sp_v2bf16 h = __builtin_convertvector(f, sp_v2bf16);      // v_cvt_pk_bf16_f32: round to nearest even
+  return __builtin_bit_cast(unsigned, h);
+}
+
+typedef __attribute__((address_space(3))) void* sp_lds_ptr;
+
+// DMA of this wave's quarter (8 KiB: one plane of one panel) of k-step `soff / SP_PSTEP` into slot `slot`
+#define SP_DMA(slot, soff)                                                                                          \
+  do {                                                                                                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_)                                                                \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(src, (sp_lds_ptr)(wr_base + (slot) * SP_STAGE + i_ * 1024), 16,   \
+                                                 voff, (soff) + i_ * 1024, 0, 0);                                   \
+  } while (0)
+
+// The pipeline of one workgroup: acc (this wave's 128 x 128 quadrant, 4 x 4 MFMA tiles) += sum over `nsteps` k-steps of
+//   hi_A' hi_B + hi_A' mid_B + mid_A' hi_B
+// for an "A side" and a "B side" block stream (one 16 KiB block [H | M] per k-step each, consecutive in memory).  baseA /
+// baseB point at the first block of this workgroup's range; k-steps past nsteps arrive as zeros (buffer range check).
+// MFMA operands are swapped (A operand <- B side, B operand <- A side) so that a lane ends up with 4 CONSECUTIVE B-side
+// indices j of ONE A-side index i: lane l, register r of tile (ti, tj):  i = 32 ti + (l & 31),  j = 32 tj + (r & 3) + 8 (r >> 2)
+// + 4 (l >> 5) -- 16-byte stores along j in the epilogues.
+__device__ __forceinline__ void split_mma_core(sp_v16f32 (&acc)[4][4], char* smem, const char* baseA, const char* baseB, int nsteps,
+                                               int wave, int lane) {
+  const int wr = wave >> 1, wc = wave & 1;
+  // this wave's DMA share: plane (wave & 1) of the A side (waves 0, 1) or the B side (waves 2, 3)
+  const __amdgpu_buffer_rsrc_t src =
+      panel_rsrc((wave < 2 ? baseA : baseB) + (wave & 1) * SP_PLANE, int64_t(nsteps - 1) * SP_PSTEP + SP_PLANE);
+  const int voff = lane * 16;
+  char* wr_base = smem + wave * SP_PLANE;
+  // fragment read bases: A side tiles 4 wr .. 4 wr + 3, B side tiles 4 wc .. 4 wc + 3
+  const char* rdA = smem + lane * 16 + wr * 4096;
+  const char* rdB = smem + SP_PSTEP + lane * 16 + wc * 4096;
+
+  sp_v8bf16 ah[2][4], am[2][4], bh[2][4], bm[2][4];
+  int soff = 0;
+#pragma unroll
+  for (int s = 0; s < SP_NST; ++s) {
+    SP_DMA(s, soff);
+    soff += SP_PSTEP;
+  }
+  asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti) {
+    ah[0][ti] = *reinterpret_cast<const sp_v8bf16*>(rdA + ti * 1024);
+    bh[0][ti] = *reinterpret_cast<const sp_v8bf16*>(rdB + ti * 1024);
+    bm[0][ti] = *reinterpret_cast<const sp_v8bf16*>(rdB + SP_PLANE + ti * 1024);
+    am[0][ti] = *reinterpret_cast<const sp_v8bf16*>(rdA + SP_PLANE + ti * 1024);
+  }
+
+  const int nloop = (nsteps + SP_NST - 1) / SP_NST;
+  for (int it = 0; it < nloop; ++it) {
+#pragma unroll
+    for (int u = 0; u < SP_NST; ++u) {
+      const int cur = u & 1, nxt = cur ^ 1;
+      const int nslot = (u + 1) % SP_NST;
+      // step s = 4 it + u: its fragments are in set `cur`; steps s+1 .. s+3 are in flight / landed in the other slots
+      asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      SP_DMA(u, soff);                       // step s + 4 -> the slot step s was read from
+      soff += SP_PSTEP;
+      __builtin_amdgcn_sched_barrier(0);
+      const char* nA = rdA + nslot * SP_STAGE;
+      const char* nB = rdB + nslot * SP_STAGE;
+      // ---- hi' hi ----
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti) {
+        ah[nxt][ti] = *reinterpret_cast<const sp_v8bf16*>(nA + ti * 1024);
+        bh[nxt][ti] = *reinterpret_cast<const sp_v8bf16*>(nB + ti * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+          acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[cur][tj], ah[cur][ti], acc[ti][tj], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // ---- hi' mid ----
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti) {
+        bm[nxt][ti] = *reinterpret_cast<const sp_v8bf16*>(nB + SP_PLANE + ti * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+          acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bm[cur][tj], ah[cur][ti], acc[ti][tj], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // ---- mid' hi ----
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti) {
+        am[nxt][ti] = *reinterpret_cast<const sp_v8bf16*>(nA + SP_PLANE + ti * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+          acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[cur][tj], am[cur][ti], acc[ti][tj], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the run-ahead DMAs (zeros past the extent) must land before the LDS is handed on
+}
+
+}  // namespace ccz

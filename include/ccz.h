@@ -97,6 +97,10 @@ CCZ_API int ccz_dev_free(ccz_handle h, void* p);
 CCZ_API int ccz_memcpy_h2d(ccz_handle h, void* dst_dev, const void* src_host, size_t bytes);
 CCZ_API int ccz_memcpy_d2h(ccz_handle h, void* dst_host, const void* src_dev, size_t bytes);
 CCZ_API int ccz_memset0(ccz_handle h, void* dst_dev, size_t bytes);
+/* The handle keeps released scratch (solver blocks, the split route's bf16 planes and partial tiles: tens of GB at
+ * n = 1e6) in a pool for the next call.  ccz_pool_trim waits for the handle's stream and returns every unused block to
+ * the driver -- for callers about to allocate most of HBM themselves (torch.cuda.empty_cache() is the analogue). */
+CCZ_API int ccz_pool_trim(ccz_handle h, size_t* released_bytes);
 
 /* ---- K1: second moments ---------------------------------------------------
  * moments = [ G (D x D, ld = D) | colsum (D) ]  float64, D = sum cols, device.
@@ -196,7 +200,8 @@ CCZ_API int ccz_moments_last_pilot(ccz_handle h, int* used);
  *                  products hi'hi + hi'mid + mid'hi as three v_mfma_f32_32x32x16_bf16 into one fp32 accumulator,
  *                  diag(sum mid^2) added back exactly -- 3 bf16 MFMAs for each fp32 one at 16x the rate; agreement
  *                  with float64 moments is measured beside the fp32 route's in bench.py (k1_rel_err);
- *   CCZ_K1_AUTO    (default) CCZ_K1_BF16X2 where it pays (n D (D+1) >= 1e11, n >= 2048, D >= 256), else CCZ_K1_FP32.
+ *   CCZ_K1_AUTO    (default) CCZ_K1_BF16X2 where it pays AND is at least as accurate as the fp32 kernel (n >= 32768 rows,
+ *                  n D (D+1) >= 1e11, D >= 256), else CCZ_K1_FP32.
  * The environment variable CCZ_K1_ROUTE = fp32 | bf16x2 overrides AUTO.  route = -1 only queries; *previous (may be
  * NULL) receives the handle's setting before the call. */
 #define CCZ_K1_AUTO 0

@@ -511,6 +511,22 @@ int ccz_randn_fill(ccz_handle, int dtype, void* out, int64_t rows, int64_t cols,
   return CCZ_OK;
 }
 int ccz_moments_last_pilot(ccz_handle, int* used) { if (used) *used = 0; return CCZ_OK; }
+// the double multiplies in float64 on the host: one "route"; the setting is stored and echoed like the product's
+int ccz_k1_route(ccz_handle h, int route, int* previous) {
+  if (!h || route < -1 || route > CCZ_K1_BF16X2) return CCZ_EINVAL;
+  if (previous) *previous = h->k1_route;
+  if (route >= 0) h->k1_route = route;
+  return CCZ_OK;
+}
+int ccz_moments_last_route(ccz_handle h, int* route, double* split_ms, double* mfma_ms, double* reduce_ms) {
+  if (!h) return CCZ_EINVAL;
+  if (route) *route = h->last_route;
+  if (split_ms) *split_ms = 0.0;
+  if (mfma_ms) *mfma_ms = 0.0;
+  if (reduce_ms) *reduce_ms = 0.0;
+  return CCZ_OK;
+}
+int ccz_pool_trim(ccz_handle h, size_t* released_bytes) { if (!h) return CCZ_EINVAL; if (released_bytes) *released_bytes = 0; return CCZ_OK; }
 
 int ccz_moments(ccz_handle h, int dtype, const ccz_view* views, int n_views, int64_t n_rows, int /*on_device*/,
                 double* mom, int accumulate) {

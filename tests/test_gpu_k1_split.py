@@ -1,0 +1,228 @@
+"""GPU parity of the split-bf16 K1 route (include/ccz.h: ccz_k1_route, csrc/gram_split.hip) through the C ABI: second
+moments of fp32 views from two bf16 planes against float64 NumPy, next to the fp32 MFMA route on the same rows; the
+estimators on top of it against the oracle.  Reference arithmetic to stay at or above: float32
+(cca_zoo/_utils/_linalg.py:28, cca_zoo/linear/_rcca.py:96)."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def H():
+    from cca_zoo_amd import _backend
+
+    h = _backend.default_handle(0)
+    yield h
+    h.k1_route("auto")
+
+
+def _moments(H, views, route, accumulate_from=None, on_device=True):
+    from cca_zoo_amd import _backend
+
+    n = views[0].shape[0]
+    D = sum(v.shape[1] for v in views)
+    mom = accumulate_from if accumulate_from is not None else H.alloc((D * D + D) * 8)
+    keep, descr = [], []
+    for v in views:
+        if on_device:
+            b = H.to_device(np.ascontiguousarray(v))
+            keep.append(b)
+            descr.append((b.ptr, v.shape[1], v.shape[1]))
+        else:
+            descr.append((v, v.shape[1], v.strides[0] // v.itemsize))
+    prev = H.k1_route(route)
+    try:
+        H.moments(descr, n, _backend.F32, on_device, mom.ptr, accumulate=accumulate_from is not None)
+        taken = H.moments_last_route()[0]
+    finally:
+        H.k1_route(prev)
+    flat = H.to_host(mom, (D * D + D,))
+    return flat[: D * D].reshape(D, D), flat[D * D:], taken, mom
+
+
+def _ref(views):
+    X = np.hstack([v.astype(np.float64) for v in views])
+    return X.T @ X, X.sum(axis=0)
+
+
+def _rel(G, Gr):
+    iu = np.triu_indices(G.shape[0])
+    scale = np.sqrt(np.outer(np.diag(Gr), np.diag(Gr)))
+    return float((np.abs(G - Gr) / scale)[iu].max())
+
+
+def _latent(n, dims, seed, shift=0.0, k=6):
+    rng = np.random.default_rng(seed)
+    z = rng.standard_normal((n, k))
+    return [(z @ rng.standard_normal((k, d)) + rng.standard_normal((n, d)) + shift).astype(np.float32) for d in dims]
+
+
+def test_route_setting_round_trip(H):
+    assert H.k1_route(None) == "auto"
+    assert H.k1_route("bf16x2") == "auto"
+    assert H.k1_route(None) == "bf16x2"
+    assert H.k1_route("fp32") == "bf16x2"
+    assert H.k1_route("auto") == "fp32"
+    from cca_zoo_amd._backend import CCZError
+
+    with pytest.raises((ValueError, CCZError)):
+        H.k1_route(7)
+
+
+@pytest.mark.parametrize("n,dims,shift", [
+    (8192, [512, 512], 0.0),          # whole panels, whole k-steps
+    (5000, [300, 520], 0.0),          # ragged panels (300 = 256 + 44), row tail inside a k-step
+    (4099, [257, 63], 0.0),           # one-column panel remainder, 3 rows in the last k-step
+    (20000, [256, 256], 10.0),        # every column mean 10 sigma away from zero: the pilot shift
+    (33000, [128, 384, 200], 0.5),    # three views, more than two row chunks
+    (40000, [1000], 0.0),             # one view (svd_whiten seam)
+])
+def test_split_route_matches_float64(H, n, dims, shift):
+    views = _latent(n, dims, seed=n + len(dims), shift=shift)
+    Gr, sr = _ref(views)
+    G2, s2, taken2, _ = _moments(H, views, "bf16x2")
+    G1, s1, taken1, _ = _moments(H, views, "fp32")
+    assert (taken1, taken2) == ("fp32", "bf16x2")
+    e1, e2 = _rel(G1, Gr), _rel(G2, Gr)
+    # float32 bar of the path (BASELINE north_star: 1e-3 on weights); K1 itself is held to a few 1e-6 like the fp32 kernel
+    assert e2 < 2e-6, (e1, e2)
+    np.testing.assert_allclose(s2, sr, rtol=1e-12, atol=1e-7)
+    np.testing.assert_array_equal(s1, s2)           # the column sums do not depend on the route (exact fp64 pass)
+
+
+def test_split_route_error_not_above_fp32_route_on_long_inputs(H):
+    """The gate of the route: on inputs long enough for auto mode to choose it, its error against
+    float64 moments is not above the fp32 kernel's on the same rows."""
+    views = _latent(131072, [512, 512], seed=5)
+    Gr, _ = _ref(views)
+    G2, _, _, _ = _moments(H, views, "bf16x2")
+    G1, _, _, _ = _moments(H, views, "fp32")
+    assert _rel(G2, Gr) <= 1.05 * _rel(G1, Gr), (_rel(G1, Gr), _rel(G2, Gr))
+
+
+def test_auto_route_thresholds(H):
+    small = _latent(3000, [256, 256], seed=1)
+    _, _, taken, _ = _moments(H, small, "auto")
+    assert taken == "fp32"                                   # below the route's pay-off: the fp32 kernel's single launch
+    big = _latent(65536, [1024, 512], seed=2)
+    _, _, taken, _ = _moments(H, big, "auto")
+    assert taken == "bf16x2"
+    from cca_zoo_amd import _backend
+
+    v64 = [v.astype(np.float64) for v in small]
+    mom = H.alloc((512 * 512 + 512) * 8)
+    H.k1_route("bf16x2")
+    try:
+        bufs = [H.to_device(v) for v in v64]
+        H.moments([(b.ptr, 256, 256) for b in bufs], 3000, _backend.F64, True, mom.ptr)
+        assert H.moments_last_route()[0] == "fp64"           # float64 views never leave the float64 pipe
+    finally:
+        H.k1_route("auto")
+
+
+def test_split_route_row_super_chunks_and_accumulate(H, monkeypatch):
+    """A scratch budget of a few MB forces several row super-chunks (planes + partial tiles re-used), 256-row chunks per
+    workgroup; a second call accumulates into the same moments."""
+    monkeypatch.setenv("CCZ_SPLIT_SCRATCH_GB", "0.008")
+    monkeypatch.setenv("CCZ_SPLIT_ROWS", "256")
+    a = _latent(6000, [300, 200], seed=11)
+    b = _latent(2500, [300, 200], seed=12, shift=3.0)
+    Ga, sa = _ref(a)
+    Gb, sb = _ref(b)
+    G, s, taken, mom = _moments(H, a, "bf16x2")
+    assert taken == "bf16x2" and _rel(G, Ga) < 2e-6
+    G, s, taken, _ = _moments(H, b, "bf16x2", accumulate_from=mom)
+    assert _rel(G, Ga + Gb) < 2e-6
+    np.testing.assert_allclose(s, sa + sb, rtol=1e-12, atol=1e-7)
+
+
+def test_split_route_host_views_streamed(H, monkeypatch):
+    """Pageable host inputs: every streamed chunk takes the split route (its own pilot), strided view included."""
+    monkeypatch.setenv("CCZ_H2D_CHUNK_MB", "8")
+    n = 40000
+    views = _latent(n, [384, 256], seed=21, shift=1.0)
+    wide = np.zeros((n, 300), dtype=np.float32)
+    wide[:, :256] = views[1]
+    views[1] = wide[:, :256]                                 # leading dimension 300
+    Gr, sr = _ref(views)
+    G, s, taken, _ = _moments(H, views, "bf16x2", on_device=False)
+    assert taken == "bf16x2"
+    assert _rel(G, Gr) < 2e-6
+    np.testing.assert_allclose(s, sr, rtol=1e-12, atol=1e-7)
+
+
+def test_nonfinite_input_reaches_the_moments(H):
+    views = _latent(4096, [256, 256], seed=3)
+    views[0][17, 5] = np.inf
+    G, s, _, _ = _moments(H, views, "bf16x2")
+    assert not np.isfinite(s[5])                             # what compute_moments turns into the ValueError of the estimators
+
+
+@pytest.mark.parametrize("est", ["rcca", "mcca", "gcca"])
+def test_estimators_on_split_route_match_oracle(H, est):
+    """configs[1]-like widths with the route forced: weights / correlations against the
+    oracle's float64 restatement at the path's float32 bar (1e-3), sign-aligned, separated spectrum."""
+    import torch
+
+    from conftest import col_rel_err
+    from cca_zoo_amd.linear import GCCA, MCCA, rCCA
+    from oracle import reference_form as rf
+
+    n, k = (4096 if est == "gcca" else 40000), 8          # (the oracle's GCCA forms the n x n matrix of the reference)
+    rng = np.random.default_rng(7)
+    z = rng.standard_normal((n, k)) * np.linspace(2.0, 0.5, k)
+    dims = [320, 256] if est == "rcca" else [256, 192, 128]
+    views = [(z @ rng.standard_normal((k, d)) + rng.standard_normal((n, d))).astype(np.float32) for d in dims]
+    tv = [torch.from_numpy(v).cuda() for v in views]
+    prev = H.k1_route("bf16x2")
+    try:
+        if est == "rcca":
+            model = rCCA(latent_dimensions=k, c=0.1).fit(tv)
+            W_ref, _ = rf.rcca_weights([v.astype(np.float64) for v in views], k, c=0.1)
+        elif est == "mcca":
+            model = MCCA(latent_dimensions=k, c=0.1).fit(tv)
+            W_ref = rf.mcca_weights([v.astype(np.float64) for v in views], k, c=0.1)[0]
+        else:
+            model = GCCA(latent_dimensions=k, c=0.1).fit(tv)
+            W_ref = rf.gcca_weights([v.astype(np.float64) for v in views], k, c=0.1)[0]
+        assert H.moments_last_route()[0] == "bf16x2"
+    finally:
+        H.k1_route(prev)
+    for w, r in zip(model.weights_, W_ref):
+        assert col_rel_err(np.asarray(w), r) < 1e-3
+
+
+def test_loss_backward_on_the_split_route_matches_closed_form(H, monkeypatch):
+    """The two-view loss whose backward is a large product (gemm_split.hip): value and gradients against the oracle's closed
+    form at the float32 bar, and against the fp32-route gradients of the same batch (CCZ_SPLIT_MIN_FLOP lowered so that a
+    batch the oracle finishes in seconds takes the route).  Reference: cca_zoo/deep/objectives.py:61-102."""
+    import torch
+
+    from cca_zoo_amd.deep.objectives import CCALoss
+    from oracle import losses as ol
+
+    monkeypatch.setenv("CCZ_SPLIT_MIN_FLOP", "1e9")
+    n, d = 40000, 384
+    torch.manual_seed(3)
+    z1 = (torch.randn(n, d, device="cuda") + 1.5).requires_grad_(True)           # off-centre, like post-activation embeddings
+    z2 = (0.5 * z1.detach() + torch.randn(n, d, device="cuda")).requires_grad_(True)
+    grads = {}
+    for route in ("bf16x2", "fp32"):
+        prev = H.k1_route(route)
+        try:
+            z1.grad = z2.grad = None
+            loss = CCALoss(eps=1e-4)([z1, z2])
+            (3.0 * loss).backward()
+            torch.cuda.synchronize()
+            grads[route] = (float(loss), z1.grad.cpu().numpy().copy(), z2.grad.cpu().numpy().copy())
+        finally:
+            H.k1_route(prev)
+    l_ref, g1, g2 = ol.cca_loss_closed_form(z1.detach().cpu().numpy(), z2.detach().cpu().numpy(), 1e-4)
+    for route, (l, a, b) in grads.items():
+        assert abs(l - l_ref) < 1e-3 * abs(l_ref), (route, l, l_ref)
+        assert np.linalg.norm(a - 3.0 * g1) < 1e-3 * np.linalg.norm(3.0 * g1), route
+        assert np.linalg.norm(b - 3.0 * g2) < 1e-3 * np.linalg.norm(3.0 * g2), route
+    # the two routes agree far inside the bar
+    assert np.linalg.norm(grads["bf16x2"][1] - grads["fp32"][1]) < 2e-5 * np.linalg.norm(grads["fp32"][1])

@@ -204,7 +204,8 @@ def test_pilot_moments_match_fp64_at_mean_100_sigma(H):
     # centred data keeps the FIFO kernel; host-resident offset data takes the pilot path chunk by chunk
     zero_mean = [t - t.mean(0) for t in tv]
     compute_moments(zero_mean, H)
-    assert not H.moments_last_pilot()
+    if H.moments_last_route()[0] == "fp32":                 # (the split-bf16 route always shifts: the subtraction rides in its split pass)
+        assert not H.moments_last_pilot()
     mom2, keep2, _, _, _ = compute_moments(views, H)
     assert H.moments_last_pilot()
     flat2 = H.to_host(mom2, (D * D + D,))
