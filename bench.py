@@ -672,12 +672,25 @@ def dcca_extra(steps=20, warmup=3, batch=8192, d=512, label="BASELINE configs[3]
     dt = (time.perf_counter() - t0) / reps
     check_async_errors()
     # forward Gram n D (D + 1) with D = 2 d, backward (n x 2d) @ (2d x 2d)
-    flops = float(batch) * (2 * d) * (2 * d + 1) + 2.0 * batch * (2 * d) * (2 * d)
+    f_fwd = float(batch) * (2 * d) * (2 * d + 1)
+    f_bwd = 2.0 * batch * (2 * d) * (2 * d)
+    flops = f_fwd + f_bwd
+    # arithmetic route of each half (ccz_loss_last_route): the split-bf16 route EXECUTES three bf16 products per algorithmic one,
+    # so the roofline is stated on executed flops against the pipe each half ran on (a blended peak when the halves differ)
+    from cca_zoo_amd import _backend
+
+    r_fwd, r_bwd = _backend.handle_for([z1, z2]).loss_last_route()
+    ex_fwd, pk_fwd = (3.0 * f_fwd, PEAK_TFLOPS["bf16"]) if r_fwd == "bf16x2" else (f_fwd, PEAK_TFLOPS["f32"])
+    ex_bwd, pk_bwd = (3.0 * f_bwd, PEAK_TFLOPS["bf16"]) if r_bwd == "bf16x2" else (f_bwd, PEAK_TFLOPS["f32"])
+    executed = ex_fwd + ex_bwd
+    t_at_peak = ex_fwd / (pk_fwd * 1e12) + ex_bwd / (pk_bwd * 1e12)
     out = {"metric": f"DCCA CCALoss fwd+bwd/sec (batch {batch}, 2x{d}, fp32; {label})", "value": 1.0 / dt, "ms": dt * 1e3,
            "ms_sync_each": dt_sync * 1e3, "ms_min_sync_each": float(min(ts)) * 1e3, "tflops": flops / dt / 1e12, "flop": flops,
-           "roofline": {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": PEAK_TFLOPS["f32"], "unit": "TFLOP/s",
-                        "frac": flops / dt / 1e12 / PEAK_TFLOPS["f32"],
-                        "note": "algorithmic flops of the whole fwd+bwd (K1 + gradient GEMM) over its wall time"}}
+           "routes": {"forward_k1": r_fwd, "backward_product": r_bwd},
+           "roofline": {"bound": "mfma", "achieved": executed / dt / 1e12, "peak": executed / t_at_peak / 1e12, "unit": "TFLOP/s",
+                        "frac": t_at_peak / dt, "executed_flop": executed, "algorithmic_tflops": flops / dt / 1e12,
+                        "note": "executed flops of the whole fwd+bwd (K1 + gradient GEMM; 3 bf16 products per algorithmic one on the "
+                                "split route) over its wall time; peak = the dense MFMA peak of the pipe(s) those flops ran on"}}
     if gate:
         out["parity_gate"] = loss_parity_gate(z1, z2, 1e-6, loss.item())
     # stated context, never the target: what a user of the reference sees on THIS GPU -- its own loss (torch.linalg.eigh +

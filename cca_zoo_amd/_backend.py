@@ -89,6 +89,7 @@ SIGNATURES = {
     "ccz_moments_last_pilot": (_int, [_vp, _pint]),
     "ccz_k1_route": (_int, [_vp, _int, _pint]),
     "ccz_pool_trim": (_int, [_vp, C.POINTER(C.c_size_t)]),
+    "ccz_loss_last_route": (_int, [_vp, _pint, _pint]),
     "ccz_moments_last_route": (_int, [_vp, _pint, _pdbl, _pdbl, _pdbl]),
     "ccz_rcca_solve": (_int, [_vp, _vp, _i64, _pi64, _pdbl, _int, _int, _vp, _vp, _vp, _pint]),
     "ccz_mcca_solve": (_int, [_vp, _vp, _i64, _pi64, _int, _pdbl, _dbl, _int, _int, _vp, _vp, _vp, _pint]),
@@ -404,6 +405,14 @@ class Handle:
         r, a, b, d = C.c_int(0), C.c_double(), C.c_double(), C.c_double()
         self.check(self.lib.ccz_moments_last_route(self._h, C.byref(r), C.byref(a), C.byref(b), C.byref(d)))
         return {v: k for k, v in self.K1_ROUTES.items()}.get(r.value, "none"), a.value, b.value, d.value
+
+    def loss_last_route(self):
+        """(forward K1 route, backward product route) of the last loss on this handle, by name ("none" before the first)."""
+        f, b = C.c_int(0), C.c_int(0)
+        self.check(self.lib.ccz_loss_last_route(self._h, C.byref(f), C.byref(b)))
+        names = {v: k for k, v in self.K1_ROUTES.items()}
+        names[0] = "none"
+        return names.get(f.value, "none"), names.get(b.value, "none")
 
     # -- fused solves ----------------------------------------------------------------------
     def _solve_out(self, dims, k):

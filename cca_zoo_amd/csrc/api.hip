@@ -389,6 +389,13 @@ int ccz_moments_last_route(ccz_handle h, int* route, double* split_ms, double* m
   })
 }
 
+int ccz_loss_last_route(ccz_handle h, int* forward_route, int* backward_route) {
+  CCZ_GUARD(h, {
+    if (forward_route) *forward_route = h->last_route;
+    if (backward_route) *backward_route = h->last_bwd_route;
+  })
+}
+
 int ccz_moments_last_pilot(ccz_handle h, int* used) {
   CCZ_GUARD(h, {
     if (used) *used = h->last_pilot;

@@ -29,6 +29,7 @@ struct ccz_ctx {
   int last_pilot = 0;      // 1 if the last ccz_moments launch used the pilot-mean (shifted) Gram kernel
   int k1_route = 0;        // CCZ_K1_AUTO / CCZ_K1_FP32 / CCZ_K1_BF16X2 (ccz_k1_route): arithmetic route of fp32 views through K1
   int last_route = 0;      // route the last ccz_moments launch took (CCZ_K1_FP32, CCZ_K1_BF16X2; CCZ_K1_FP64 for fp64 views)
+  int last_bwd_route = 0;  // route of the last loss backward product on this handle (CCZ_K1_FP32 / CCZ_K1_BF16X2 / CCZ_K1_FP64; 0: none yet)
   double last_split_ms = 0.0, last_mfma_ms = 0.0, last_reduce_ms = 0.0;   // stages of the last split-route launch (timed calls)
   void* impl = nullptr;    // backend-private (memory pool, events, device props)
 };

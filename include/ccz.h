@@ -305,6 +305,11 @@ CCZ_API int ccz_pair_loss_backward(ccz_handle h, int dtype, const ccz_view* z_de
  * before its NEXT loss call); synchronise = 1 drains the handle's stream first.  (The reference clamps eigenvalues at
  * eps instead, deep/objectives.py:9-21, and cannot fail; with eps > 0 neither can this, short of NaN inputs.) */
 CCZ_API int ccz_loss_status(ccz_handle h, int synchronise, int* view, int* pivot);
+/* Arithmetic routes of the last loss on this handle: *forward_route = route of its K1 (as ccz_moments_last_route),
+ * *backward_route = route of the gradient product ([dz_1 | dz_2] = ([z_1 | z_2] - 1 mean') Gamma): CCZ_K1_BF16X2 when a
+ * two-view fp32 backward is a large product (n >= 32768, 2 n D^2 >= 2e11) and the handle's ccz_k1_route is not CCZ_K1_FP32 --
+ * the same split arithmetic as K1's (csrc/gemm_split.hip) -- else CCZ_K1_FP32 / CCZ_K1_FP64; 0 before the first backward. */
+CCZ_API int ccz_loss_last_route(ccz_handle h, int* forward_route, int* backward_route);
 /* The same loss for a batch that is row-sharded over ranks: `moments_dev` holds the batch moments of
  * [z1 | z2] summed over all shards (ccz_moments per rank + one all-reduce), n_rows the total batch size.
  * Returns the loss (host) and, if gamma_dev != NULL, the (d1+d2) x (d1+d2) matrix Gamma and the batch mean

@@ -526,6 +526,7 @@ int ccz_moments_last_route(ccz_handle h, int* route, double* split_ms, double* m
   if (reduce_ms) *reduce_ms = 0.0;
   return CCZ_OK;
 }
+int ccz_loss_last_route(ccz_handle h, int* f, int* b) { if (!h) return CCZ_EINVAL; if (f) *f = h->last_route; if (b) *b = h->last_bwd_route; return CCZ_OK; }
 int ccz_pool_trim(ccz_handle h, size_t* released_bytes) { if (!h) return CCZ_EINVAL; if (released_bytes) *released_bytes = 0; return CCZ_OK; }
 
 int ccz_moments(ccz_handle h, int dtype, const ccz_view* views, int n_views, int64_t n_rows, int /*on_device*/,
