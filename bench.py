@@ -56,12 +56,26 @@ def parse():
     ap.add_argument("--cpu-runs", type=int, default=3, help="repeats of the rCCA CPU comparator at n = 2 d (a run is ~25 s; the median is reported)")
     ap.add_argument("--no-gates", action="store_true", help="skip the parity gates of the extras (the headline gate always runs)")
     ap.add_argument("--only", default="", help="comma-separated subset of the extras to run (routes, dcca, grid, host, metric_loss, configs, evd)")
-    ap.add_argument("--transport", choices=["torch", "ccz"], default=os.environ.get("CCZ_BENCH_TRANSPORT", "torch"),
+    ap.add_argument("--transport", choices=["torch", "ccz", "gloo-staged"], default=os.environ.get("CCZ_BENCH_TRANSPORT", "torch"),
                     help="exchange step of the sharded fit: torch.distributed (nccl = RCCL) all-reduces, or libccz's own RCCL collective "
                          "behind the C ABI (ccz_moments_exchange); both run the two-part exchange that overlaps the factorization")
     ap.add_argument("--launch-test", action="store_true",
                     help="(CPU test of the launcher) rendezvous over gloo, one all-reduce, ONE JSON line on rank 0; no GPU work")
     return ap.parse_args()
+
+
+def dist_all_reduce(t, op=None):
+    """``dist.all_reduce`` that also serves ``--transport gloo-staged`` (two ranks on ONE GPU: CUDA tensors over a gloo group go
+    through a host copy; cca_zoo_amd._dist.staged_over_gloo is the product-side twin)."""
+    import torch.distributed as dist
+
+    op = op if op is not None else dist.ReduceOp.SUM
+    if t.is_cuda and dist.get_backend() == "gloo":
+        c = t.cpu()
+        dist.all_reduce(c, op=op)
+        t.copy_(c)
+    else:
+        dist.all_reduce(t, op=op)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -220,7 +234,7 @@ def check_fit_properties(model, views, jd, seed, row0=0, sharded=False, n_check=
         import torch.distributed as dist
 
         flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=views[0].device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        dist_all_reduce(flag, op=dist.ReduceOp.MIN)
         ok = bool(flag.item() > 0.5)
     rep["ok"] = bool(ok)
     return rep
@@ -249,7 +263,7 @@ def topk_certificate(model, views, sharded=False, chunk=32768):
         import torch.distributed as dist
 
         for t in (G, sm, n_tot):
-            dist.all_reduce(t)
+            dist_all_reduce(t)
     if sharded:
         import torch.distributed as dist
 
@@ -1175,6 +1189,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    one_gpu = a.transport == "gloo-staged"                   # test transport: every rank on cuda:0, collectives staged over gloo
+    if one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     os.environ["CCZ_DEVICE"] = str(local)
     # One BLAS / OpenMP thread per usable core for the WHOLE process (the gates run LAPACK on the host): the default is one
@@ -1197,7 +1214,10 @@ def main():
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     from cca_zoo_amd import _backend, row_sharded, shard_bounds
     from cca_zoo_amd.datasets import JointData
@@ -1278,7 +1298,7 @@ def main():
     gc.enable()
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist_all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / a.steps * 1e3
     # the exchange on the device time line: head = pack -> first all-reduce done; tail = first done -> second unpacked
@@ -1298,7 +1318,7 @@ def main():
         rccl_ranks = dist.get_world_size()
         gt = torch.zeros(world, dtype=torch.float64, device=f"cuda:{local}")
         gt[rank] = float(np.mean(gram_ms))
-        dist.all_reduce(gt)
+        dist_all_reduce(gt)
         k1_ms_per_rank = [float(x) for x in gt.cpu().tolist()]
 
     # ---- parity gate on the views that were timed (every rank takes part: transform / score all-reduce) ----
@@ -1344,7 +1364,8 @@ def main():
         out = {
             "metric": "CCA fit()/sec at n=1e6 d=4096 k=64",
             "value": 1e3 / ms_per_step, "unit": "fit/s",
-            "n_gpus": world, "rccl_ranks": rccl_ranks, "transport": (a.transport if distributed else None),
+            "n_gpus": world, "rccl_ranks": (0 if one_gpu else rccl_ranks), "ranks_on_one_gpu": (world if one_gpu else None),
+            "transport": (a.transport if distributed else None),
             "ccz_comm_ranks": ccz_comm_ranks, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
             "step_ms": [round(x, 2) for x in step_ms],
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,

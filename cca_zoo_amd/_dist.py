@@ -147,6 +147,31 @@ def unsharded():
         _state.on, _state.group = prev
 
 
+def staged_over_gloo(t, group=None) -> bool:
+    """True for a CUDA tensor reduced over a ``gloo`` group: the collective then runs on a pinned host copy (d2h ->
+    gloo all-reduce -> h2d).  A TEST transport -- RCCL refuses two ranks on one device, gloo does not care -- that lets two
+    processes share ONE GPU and still run every rank-dependent line of the sharded path with the real kernels
+    (tests/test_gpu_two_ranks_one_gpu.py, ``bench.py --transport gloo-staged``).  Production groups are nccl (= RCCL)."""
+    import torch.distributed as dist
+
+    return bool(getattr(t, "is_cuda", False)) and dist.get_backend(group) == "gloo"
+
+
+def all_reduce_sum(t, group=None):
+    """SUM all-reduce of a torch tensor in place over a torch.distributed group (CUDA over gloo: staged, see above)."""
+    import torch
+    import torch.distributed as dist
+
+    if staged_over_gloo(t, group):
+        host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        host.copy_(t)                                   # waits for the producing stream
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(host, non_blocking=True)
+        torch.cuda.current_stream(t.device).synchronize()       # `host` may go once the copy has run
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
 def allreduce_moments(buf, group=None):
     """SUM-reduce ``buf`` IN PLACE and return the global row count.
 
@@ -170,9 +195,7 @@ def allreduce_moments(buf, group=None):
         h.allreduce_sum_f64(buf.data_ptr(), buf.numel())
         h.release(sp)
         return int(round(float(buf[-1].item())))
-    import torch.distributed as dist
-
-    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    all_reduce_sum(buf, group)
     return int(round(float(buf[-1].item())))
 
 
@@ -197,5 +220,5 @@ def allreduce_small(values, device, group=None):
     import torch.distributed as dist
 
     t = torch.as_tensor(np.ascontiguousarray(values, dtype=np.float64), device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    all_reduce_sum(t, group)
     return t.cpu().numpy()

@@ -83,6 +83,17 @@ def _side_stream(h, dev):
     return st
 
 
+def settle_deferred(h):
+    """Error path of a fit that called ``compute_moments(defer_offdiag=True)``: the deferred half of the exchange may still be
+    writing into the moments buffer on another stream.  Wait for it on the device (``ccz_solve_defer(NULL)`` also clears the
+    registration) and then for the handle, so that the buffer can be dropped safely."""
+    try:
+        h.solve_defer(None)
+        h.sync()
+    except Exception:
+        pass
+
+
 def compute_moments(views, handle=None, defer_offdiag=False):
     """``defer_offdiag`` (the estimators' ``fit`` inside ``row_sharded()``): the exchange is issued in two parts --
     diagonal blocks + column sums + row count first, the off-diagonal blocks second -- and this function returns as soon
@@ -177,9 +188,27 @@ def compute_moments(views, handle=None, defer_offdiag=False):
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
         t_ar = time.perf_counter()
-        w_head = dist.all_reduce(head, op=dist.ReduceOp.SUM, group=group, async_op=True)
-        w_tail = dist.all_reduce(tail, op=dist.ReduceOp.SUM, group=group, async_op=True) if n_tail > 0 else None
-        w_head.wait()
+        staged = cuda and _dist.staged_over_gloo(packed, group)
+        if staged:
+            # test transport (two ranks on ONE GPU, _dist.staged_over_gloo): the same two-part order with the collectives on
+            # pinned host copies; the tail's result goes back on the side stream and is unpacked there behind the deferral
+            # event exactly as on the nccl route (the host does block for the tail's collective here)
+            host = torch.empty(n_head + n_tail, dtype=torch.float64, pin_memory=True)
+            host.copy_(packed)
+            dist.all_reduce(host[:n_head], op=dist.ReduceOp.SUM, group=group)
+            head.copy_(host[:n_head], non_blocking=True)
+            keep.append(host)
+
+            class _Tail:
+                def wait(self_inner):
+                    dist.all_reduce(host[n_head:], op=dist.ReduceOp.SUM, group=group)
+                    tail.copy_(host[n_head:], non_blocking=True)     # on the stream that is current when waited for
+
+            w_head, w_tail = None, (_Tail() if n_tail > 0 else None)
+        else:
+            w_head = dist.all_reduce(head, op=dist.ReduceOp.SUM, group=group, async_op=True)
+            w_tail = dist.all_reduce(tail, op=dist.ReduceOp.SUM, group=group, async_op=True) if n_tail > 0 else None
+            w_head.wait()
         if timed:
             ev1.record()
             _last_events = (ev0, ev1, None)
@@ -213,6 +242,8 @@ def compute_moments(views, handle=None, defer_offdiag=False):
     # check_array(force_all_finite) ValueError without a host pass over the data
     sums = h.to_host(mom_ptr, (D,), offset_bytes=D * D * 8)
     if not np.all(np.isfinite(sums)):
+        if sharded and defer_offdiag:
+            settle_deferred(h)                           # the tail may still be in flight into mom: no solve will consume it
         bad = int(np.flatnonzero(~np.isfinite(sums))[0])
         raise ValueError(f"Input contains NaN or infinity (first affected stacked column: {bad}).")
     # no symmetrisation pass: the solvers read the upper triangle (authoritative) on both sides

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_bf16x2_nn(int64_t M, int64_t N,
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  split_mma_core(acc, smem, planesA + rt * S * SP_PSTEP, planesB + ct * S * SP_PSTEP, int(S), wave, lane);
+  split_mma_core<0>(acc, smem, planesA + rt * S * SP_PSTEP, planesB + ct * S * SP_PSTEP, int(S), wave, lane, wr, wc);
 
   if (alpha_dev) alpha *= *alpha_dev;
 #pragma unroll

@@ -1211,7 +1211,28 @@ bool launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
   }
   if (time_it) CCZ_HIP(hipEventRecord(im->ev[2], st));
   int64_t off = 0;
-  for (int v = 0; v < n_views; ++v) {
+  float* pilot = nullptr;
+  if (split) {
+    // Split route: the exact column sums ride in the split pass (one read of the rows instead of two), so the pilot cannot be
+    // their mean -- it is the mean of a strided sample of <= 2048 rows spread over the whole launch (sorted / drifting inputs
+    // included).  Any pilot near the mean serves: the fix-up  sum x x' = sum (x-p)(x-p)' + p s' + s p' - n p p'  is exact in p.
+    const int64_t nsamp = std::min<int64_t>(n, 2048), stride = n / nsamp;
+    double* samp = static_cast<double*>(dev_alloc(c, size_t(D) * 8));
+    zero(c, samp, size_t(D) * 8);
+    for (int v = 0; v < n_views; ++v) {
+      const int64_t colblocks = (views[v].cols + 255) / 256;
+      int64_t rpb = 256;
+      while (rpb > 16 && colblocks * ((nsamp + rpb - 1) / rpb) < 2 * int64_t(ncu)) rpb /= 2;
+      dim3 grid((unsigned)colblocks, (unsigned)((nsamp + rpb - 1) / rpb));
+      hipLaunchKernelGGL((k_colsum<T, false>), grid, dim3(256), 0, st, static_cast<const T*>(views[v].data), nsamp, views[v].cols,
+                         views[v].ld * stride, samp + off, static_cast<double*>(nullptr), rpb);
+      off += views[v].cols;
+    }
+    pilot = static_cast<float*>(dev_alloc(c, size_t(D) * 4));
+    hipLaunchKernelGGL(k_pilot_from_sums, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, st, samp, D, 1.0 / double(nsamp), pilot);
+    dev_free(c, samp);
+  }
+  for (int v = 0; v < n_views && !split; ++v) {
     // enough row blocks to cover the chip even for narrow / short views
     const int64_t colblocks = (views[v].cols + 255) / 256;
     int64_t rpb = 2048;
@@ -1243,8 +1264,7 @@ bool launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
     }
     use_pilot = worst > pilot_thr;
   }
-  float* pilot = nullptr;
-  if (use_pilot) {
+  if (use_pilot && !split) {
     pilot = static_cast<float*>(dev_alloc(c, size_t(D) * 4));
     hipLaunchKernelGGL(k_pilot_from_sums, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, st, s_launch, D, 1.0 / double(n), pilot);
   }
@@ -1265,7 +1285,7 @@ bool launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
     if (bytes <= partial_cap) partial = static_cast<float*>(dev_alloc(c, size_t(bytes)));
   }
   if (split) {
-    gram_split_f32(c, views, n_views, n, G, D, pilot, time_it);
+    gram_split_f32(c, views, n_views, n, G, D, pilot, s_launch, time_it);
   } else if (is32) {
     if (fifo_pilot) {
       const size_t fifo_bytes = size_t(4) * FR * FSLOT;

@@ -67,8 +67,9 @@ struct SplitTile {
 template <bool ALIGNED>
 __global__ __launch_bounds__(256) void k_split_bf16x2(const SplitPanel* __restrict__ panels, int64_t r0, int64_t nrows, int64_t ksteps,
                                                       const float* __restrict__ pilot, char* __restrict__ planes,
-                                                      double* __restrict__ msq) {
+                                                      double* __restrict__ msq, double* __restrict__ csum) {
   __shared__ float red[4][256];
+  __shared__ double redc[4][256];
   const SplitPanel pn = panels[blockIdx.y];
   const int tid = threadIdx.x, cg = tid & 63, rg = tid >> 6;
   const int64_t rows_pad = ksteps * SP_K;
@@ -84,6 +85,7 @@ __global__ __launch_bounds__(256) void k_split_bf16x2(const SplitPanel* __restri
   const float* __restrict__ X = pn.base + c0;
   char* out = planes + int64_t(blockIdx.y) * ksteps * SP_PSTEP + (cg >> 3) * 1024 + (cg & 7) * 64;
   sp_v4f32 q = {0.f, 0.f, 0.f, 0.f};
+  double cs[4] = {0.0, 0.0, 0.0, 0.0};               // exact column sums of x (not of x - p): the means, and the pilot fix-up's s
   for (int pass = 0; pass < SP_RB / 32; ++pass) {
     const int64_t row = rb0 + pass * 32 + rg * 8;          // first of this thread's 8 rows (within the launch)
     if (row >= rows_pad) break;
@@ -100,6 +102,10 @@ __global__ __launch_bounds__(256) void k_split_bf16x2(const SplitPanel* __restri
         for (int e = 0; e < 4; ++e) v[k][e] = cok[e] ? src[e] : 0.f;
       }
       if (!rok) v[k] = p;                                  // d = 0 exactly for the rows that pad the last k-step
+      else if (csum) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cs[e] += cok[e] ? double(v[k][e]) : 0.0;
+      }
     }
     sp_v4u32 hw[4], mw[4];
 #pragma unroll
@@ -129,11 +135,16 @@ __global__ __launch_bounds__(256) void k_split_bf16x2(const SplitPanel* __restri
   // msq: the four row groups of the workgroup -> one fp64 atomic per column
 #pragma unroll
   for (int e = 0; e < 4; ++e) red[rg][c0 + e] = q[e];
+  if (csum) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) redc[rg][c0 + e] = cs[e];
+  }
   __syncthreads();
   if (msq && tid < pn.width) {
     const double s = double(red[0][tid]) + double(red[1][tid]) + double(red[2][tid]) + double(red[3][tid]);
     unsafeAtomicAdd(msq + pn.gcol0 + tid, s);
   }
+  if (csum && tid < pn.width) unsafeAtomicAdd(csum + pn.gcol0 + tid, (redc[0][tid] + redc[1][tid]) + (redc[2][tid] + redc[3][tid]));
 }
 
 // ---------------------------------------------------------------------------
@@ -160,21 +171,42 @@ __global__ __launch_bounds__(256, 1) void k_gram_bf16x2(const SplitTile* __restr
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  split_mma_core(acc, smem, planes + (int64_t(t.pa) * ksteps + s0) * SP_PSTEP, planes + (int64_t(t.pb) * ksteps + s0) * SP_PSTEP,
-                 int(s1 - s0), wave, lane);
+  const char* srcA = planes + (int64_t(t.pa) * ksteps + s0) * SP_PSTEP;
+  const char* srcB = planes + (int64_t(t.pb) * ksteps + s0) * SP_PSTEP;
+  const int nsteps = int(s1 - s0);
+  // a diagonal tile (A side == B side): the two symmetric quadrants compute their upper MFMA tiles, and the wave of the
+  // redundant quadrant (1, 0) takes the lower half of quadrant (0, 1) -- 30 MFMAs per k-step for the slowest wave instead of 48.
+  // What is not computed lies below the diagonal of G and is never read (k_split_reduce skips it).
+  int qr = wr, qc = wc, ti0 = 0, ti1 = 4;
+  bool sym = false;
+  if (t.diag && wr == wc) {
+    sym = true;
+    split_mma_core<1>(acc, smem, srcA, srcB, nsteps, wave, lane, qr, qc);
+  } else if (t.diag && wr == 0) {
+    ti1 = 2;
+    split_mma_core<2>(acc, smem, srcA, srcB, nsteps, wave, lane, qr, qc);
+  } else if (t.diag) {
+    qr = 0; qc = 1; ti0 = 2;
+    split_mma_core<3>(acc, smem, srcA, srcB, nsteps, wave, lane, qr, qc);
+  } else {
+    split_mma_core<0>(acc, smem, srcA, srcB, nsteps, wave, lane, qr, qc);
+  }
 
   // epilogue: the chunk's fp32 sums -> this (chunk, tile)'s slot, row-major 256 x 256
   float* pt = partial + (wi.chunk * int64_t(ntiles) + wi.tile) * int64_t(SP_T * SP_T);
 #pragma unroll
   for (int ti = 0; ti < 4; ++ti) {
-    float* prow = pt + (wr * 128 + ti * 32 + (lane & 31)) * SP_T + wc * 128 + 4 * (lane >> 5);
+    if (ti < ti0 || ti >= ti1) continue;
+    float* prow = pt + (qr * 128 + ti * 32 + (lane & 31)) * SP_T + qc * 128 + 4 * (lane >> 5);
 #pragma unroll
-    for (int tj = 0; tj < 4; ++tj)
+    for (int tj = 0; tj < 4; ++tj) {
+      if (sym && tj < ti) continue;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const sp_v4f32 v = {acc[ti][tj][4 * g], acc[ti][tj][4 * g + 1], acc[ti][tj][4 * g + 2], acc[ti][tj][4 * g + 3]};
         *reinterpret_cast<sp_v4f32*>(prow + tj * 32 + 8 * g) = v;
       }
+    }
   }
 }
 
@@ -257,8 +289,8 @@ void split_k1_layout(ccz_ctx* c, const float* X, int64_t rows, int64_t cols, int
   try {
     h2d_small(c, d_panels, panels.data(), panels.size() * sizeof(SplitPanel));
     const dim3 grid((unsigned)((ksteps * SP_K + SP_RB - 1) / SP_RB), (unsigned)panels.size());
-    if (aligned) hipLaunchKernelGGL(k_split_bf16x2<true>, grid, dim3(256), 0, stream(c), d_panels, int64_t(0), rows, ksteps, static_cast<const float*>(nullptr), planes, static_cast<double*>(nullptr));
-    else hipLaunchKernelGGL(k_split_bf16x2<false>, grid, dim3(256), 0, stream(c), d_panels, int64_t(0), rows, ksteps, static_cast<const float*>(nullptr), planes, static_cast<double*>(nullptr));
+    if (aligned) hipLaunchKernelGGL(k_split_bf16x2<true>, grid, dim3(256), 0, stream(c), d_panels, int64_t(0), rows, ksteps, static_cast<const float*>(nullptr), planes, static_cast<double*>(nullptr), static_cast<double*>(nullptr));
+    else hipLaunchKernelGGL(k_split_bf16x2<false>, grid, dim3(256), 0, stream(c), d_panels, int64_t(0), rows, ksteps, static_cast<const float*>(nullptr), planes, static_cast<double*>(nullptr), static_cast<double*>(nullptr));
     CCZ_LAUNCH_CHECK();
   } catch (...) {
     dev_free(c, d_panels);
@@ -278,10 +310,12 @@ bool gram_split_worthwhile(int64_t n, int64_t D) {
   return n >= 32768 && D >= 256 && double(n) * double(D) * double(D + 1) >= min_flop;
 }
 
-// G (upper tiles) += sum over rows of d d' for d = x - pilot (pilot may be null: d = x), through the split-bf16 route.
+// G (upper tiles) += sum over rows of d d' for d = x - pilot (pilot may be null: d = x), through the split-bf16 route;
+// colsum (may be null) += the exact fp64 column sums of x, gathered by the split pass on its way over the rows.
 // Everything is enqueued on the handle's stream; with time_it the three stages are timed with HIP events (one host wait per
 // row super-chunk) into c->last_split_ms / last_mfma_ms / last_reduce_ms.
-void gram_split_f32(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, double* G, int64_t D, const float* pilot, bool time_it) {
+void gram_split_f32(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, double* G, int64_t D, const float* pilot, double* colsum,
+                    bool time_it) {
   Impl* im = impl(c);
   hipStream_t st = stream(c);
   // ---- panels and tiles ----
@@ -385,8 +419,8 @@ void gram_split_f32(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
       if (time_it) CCZ_HIP(hipEventRecord(im->sp_ev[0], st));
       {
         const dim3 grid((unsigned)((ksteps * SP_K + SP_RB - 1) / SP_RB), (unsigned)np);
-        if (aligned) hipLaunchKernelGGL(k_split_bf16x2<true>, grid, dim3(256), 0, st, d_panels, r0, rows, ksteps, pilot, planes, msq);
-        else hipLaunchKernelGGL(k_split_bf16x2<false>, grid, dim3(256), 0, st, d_panels, r0, rows, ksteps, pilot, planes, msq);
+        if (aligned) hipLaunchKernelGGL(k_split_bf16x2<true>, grid, dim3(256), 0, st, d_panels, r0, rows, ksteps, pilot, planes, msq, colsum);
+        else hipLaunchKernelGGL(k_split_bf16x2<false>, grid, dim3(256), 0, st, d_panels, r0, rows, ksteps, pilot, planes, msq, colsum);
       }
       if (time_it) CCZ_HIP(hipEventRecord(im->sp_ev[1], st));
       hipLaunchKernelGGL(k_gram_bf16x2, dim3((unsigned)nblocks), dim3(256), fifo_bytes, st, d_tiles, ntiles, per_xcd, ksplit, planes, ksteps,

@@ -173,7 +173,8 @@ struct GramPartials {
 // gram_split.hip: the same sums through two bf16 planes per view on the bf16 matrix pipe (hi'hi + hi'mid + mid'hi in one fp32
 // accumulator, the diagonal's mid'mid added back exactly): G (upper tiles) += sum_rows (x - pilot)(x - pilot)'.
 bool gram_split_worthwhile(int64_t n, int64_t D);
-void gram_split_f32(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, double* G, int64_t D, const float* pilot, bool time_it);
+void gram_split_f32(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, double* G, int64_t D, const float* pilot, double* colsum,
+                    bool time_it);
 // gemm_split.hip: the two-view loss backward [C1 | C2] = alpha (*alpha_dev) ([A1 | A2] - 1 mean') Gamma on the bf16 pipe (same split arithmetic)
 bool gemm_split_pair_eligible(int64_t M, int64_t N, int64_t K, int64_t K1, int64_t nsplit, const void* A1, int64_t lda1, const void* A2,
                               int64_t lda2, const void* C1, int64_t ldc1, const void* C2, int64_t ldc2);

@@ -41,24 +41,29 @@ typedef __attribute__((address_space(3))) void* sp_lds_ptr;
                                                  voff, (soff) + i_ * 1024, 0, 0);                                   \
   } while (0)
 
-// The pipeline of one workgroup: acc (this wave's 128 x 128 quadrant, 4 x 4 MFMA tiles) += sum over `nsteps` k-steps of
+// The pipeline of one workgroup: acc (a 128 x 128 quadrant of the 256 x 256 tile, 4 x 4 MFMA tiles) += sum over `nsteps` k-steps of
 //   hi_A' hi_B + hi_A' mid_B + mid_A' hi_B
 // for an "A side" and a "B side" block stream (one 16 KiB block [H | M] per k-step each, consecutive in memory).  baseA /
 // baseB point at the first block of this workgroup's range; k-steps past nsteps arrive as zeros (buffer range check).
 // MFMA operands are swapped (A operand <- B side, B operand <- A side) so that a lane ends up with 4 CONSECUTIVE B-side
 // indices j of ONE A-side index i: lane l, register r of tile (ti, tj):  i = 32 ti + (l & 31),  j = 32 tj + (r & 3) + 8 (r >> 2)
 // + 4 (l >> 5) -- 16-byte stores along j in the epilogues.
+// (qr, qc): the quadrant this wave computes (its DMA share is fixed by `wave`).  MODE restricts the MFMA tiles of the quadrant --
+// the diagonal tiles of a Gram matrix (A side == B side) hold only three distinct quadrants, two of them symmetric:
+//   0 all 16;  1 ti <= tj (a symmetric quadrant: 10 tiles);  2 ti in {0, 1};  3 ti in {2, 3} (two waves share quadrant (0, 1)).
+// Every wave runs every barrier; a diagonal workgroup's k-step costs 30 MFMAs instead of 48.
+template <int MODE>
 __device__ __forceinline__ void split_mma_core(sp_v16f32 (&acc)[4][4], char* smem, const char* baseA, const char* baseB, int nsteps,
-                                               int wave, int lane) {
-  const int wr = wave >> 1, wc = wave & 1;
+                                               int wave, int lane, int qr, int qc) {
+  constexpr int TI0 = MODE == 3 ? 2 : 0, TI1 = MODE == 2 ? 2 : 4;
   // this wave's DMA share: plane (wave & 1) of the A side (waves 0, 1) or the B side (waves 2, 3)
   const __amdgpu_buffer_rsrc_t src =
       panel_rsrc((wave < 2 ? baseA : baseB) + (wave & 1) * SP_PLANE, int64_t(nsteps - 1) * SP_PSTEP + SP_PLANE);
   const int voff = lane * 16;
   char* wr_base = smem + wave * SP_PLANE;
-  // fragment read bases: A side tiles 4 wr .. 4 wr + 3, B side tiles 4 wc .. 4 wc + 3
-  const char* rdA = smem + lane * 16 + wr * 4096;
-  const char* rdB = smem + SP_PSTEP + lane * 16 + wc * 4096;
+  // fragment read bases: A side tiles 4 qr .. 4 qr + 3, B side tiles 4 qc .. 4 qc + 3
+  const char* rdA = smem + lane * 16 + qr * 4096;
+  const char* rdB = smem + SP_PSTEP + lane * 16 + qc * 4096;
 
   sp_v8bf16 ah[2][4], am[2][4], bh[2][4], bm[2][4];
   int soff = 0;
@@ -71,10 +76,12 @@ __device__ __forceinline__ void split_mma_core(sp_v16f32 (&acc)[4][4], char* sme
   __builtin_amdgcn_s_barrier();
 #pragma unroll
   for (int ti = 0; ti < 4; ++ti) {
-    ah[0][ti] = *reinterpret_cast<const sp_v8bf16*>(rdA + ti * 1024);
+    if (ti >= TI0 && ti < TI1) {
+      ah[0][ti] = *reinterpret_cast<const sp_v8bf16*>(rdA + ti * 1024);
+      am[0][ti] = *reinterpret_cast<const sp_v8bf16*>(rdA + SP_PLANE + ti * 1024);
+    }
     bh[0][ti] = *reinterpret_cast<const sp_v8bf16*>(rdB + ti * 1024);
     bm[0][ti] = *reinterpret_cast<const sp_v8bf16*>(rdB + SP_PLANE + ti * 1024);
-    am[0][ti] = *reinterpret_cast<const sp_v8bf16*>(rdA + SP_PLANE + ti * 1024);
   }
 
   const int nloop = (nsteps + SP_NST - 1) / SP_NST;
@@ -94,12 +101,14 @@ __device__ __forceinline__ void split_mma_core(sp_v16f32 (&acc)[4][4], char* sme
       // ---- hi' hi ----
 #pragma unroll
       for (int ti = 0; ti < 4; ++ti) {
-        ah[nxt][ti] = *reinterpret_cast<const sp_v8bf16*>(nA + ti * 1024);
+        if (ti >= TI0 && ti < TI1) ah[nxt][ti] = *reinterpret_cast<const sp_v8bf16*>(nA + ti * 1024);
         bh[nxt][ti] = *reinterpret_cast<const sp_v8bf16*>(nB + ti * 1024);
         __builtin_amdgcn_sched_barrier(0);
+        if (ti >= TI0 && ti < TI1) {
 #pragma unroll
-        for (int tj = 0; tj < 4; ++tj)
-          acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[cur][tj], ah[cur][ti], acc[ti][tj], 0, 0, 0);
+          for (int tj = (MODE == 1 ? ti : 0); tj < 4; ++tj)
+            acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[cur][tj], ah[cur][ti], acc[ti][tj], 0, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
       // ---- hi' mid ----
@@ -107,19 +116,23 @@ __device__ __forceinline__ void split_mma_core(sp_v16f32 (&acc)[4][4], char* sme
       for (int ti = 0; ti < 4; ++ti) {
         bm[nxt][ti] = *reinterpret_cast<const sp_v8bf16*>(nB + SP_PLANE + ti * 1024);
         __builtin_amdgcn_sched_barrier(0);
+        if (ti >= TI0 && ti < TI1) {
 #pragma unroll
-        for (int tj = 0; tj < 4; ++tj)
-          acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bm[cur][tj], ah[cur][ti], acc[ti][tj], 0, 0, 0);
+          for (int tj = (MODE == 1 ? ti : 0); tj < 4; ++tj)
+            acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bm[cur][tj], ah[cur][ti], acc[ti][tj], 0, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
       // ---- mid' hi ----
 #pragma unroll
       for (int ti = 0; ti < 4; ++ti) {
-        am[nxt][ti] = *reinterpret_cast<const sp_v8bf16*>(nA + SP_PLANE + ti * 1024);
+        if (ti >= TI0 && ti < TI1) am[nxt][ti] = *reinterpret_cast<const sp_v8bf16*>(nA + SP_PLANE + ti * 1024);
         __builtin_amdgcn_sched_barrier(0);
+        if (ti >= TI0 && ti < TI1) {
 #pragma unroll
-        for (int tj = 0; tj < 4; ++tj)
-          acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[cur][tj], am[cur][ti], acc[ti][tj], 0, 0, 0);
+          for (int tj = (MODE == 1 ? ti : 0); tj < 4; ++tj)
+            acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[cur][tj], am[cur][ti], acc[ti][tj], 0, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }

@@ -70,7 +70,11 @@ class GCCA(BaseModel):
         mom, keep, n_total, dims, kind = compute_moments(views_, h, defer_offdiag=True)
         t1 = time.perf_counter()
         self.n_samples_ = int(n_total)            # inside row_sharded(): the global row count
-        self._fit_moments(h, mom, n_total, dims, kind)
+        try:
+            self._fit_moments(h, mom, n_total, dims, kind)
+        except BaseException:
+            _moments.settle_deferred(h)       # parameter / solver errors: the exchange's deferred half must not outlive `mom`
+            raise
         # wall-clock split of this fit (K1 incl. the all-reduce | the d x d solve incl. the copy of the weights to the host)
         self.timings_ = {"moments_ms": (t1 - t0) * 1e3, "allreduce_ms": _moments.LAST["allreduce_ms"],
                          "solve_ms": (time.perf_counter() - t1) * 1e3}
