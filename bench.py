@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", dest="n", type=int, default=1_000_000)
-    ap.add_argument("--d", type=int, default=4096)
+    ap.add_argument("--d", "--dim", dest="d", type=int, default=4096)
     ap.add_argument("--k", type=int, default=64)
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
     ap.add_argument("--k1-route", choices=["auto", "fp32", "bf16x2"], default=os.environ.get("CCZ_BENCH_K1_ROUTE", "auto"),

@@ -492,7 +492,15 @@ def test_ns_shape_against_oracle(n, d):
     tv = jd.sample_device(device="cuda", dtype=torch.float32, n_samples=n, seed=5)
     m = CCA(latent_dimensions=k).fit(tv)
     G, s = _gram_fp64_chunked(tv)
-    W, means, sv = gf.rcca_from_moments(G, s, n, [d, d], k, c=[0.0, 0.0], fast=True)
+
+    def solve():
+        W_, means_, sv_ = gf.rcca_from_moments(G, s, n, [d, d], k, c=[0.0, 0.0], fast=True)
+        return {"W0": W_[0], "W1": W_[1], "mean0": means_[0], "mean1": means_[1], "sv": sv_}
+
+    from conftest import host_solve_cached, moments_probe
+
+    o = host_solve_cached(f"ns_cca_{n}_{d}", moments_probe(G, s), solve)       # the oracle's 50 s of host LAPACK at n = 1e6
+    W, means, sv = [o["W0"], o["W1"]], [o["mean0"], o["mean1"]], o["sv"]
     C = gf.covariance_from_moments(G, s, n)
     for i, (w, r) in enumerate(zip(m.weights_, W)):
         assert w.shape == (d, k) and w.dtype == np.float32
@@ -545,7 +553,15 @@ def test_c3_mcca_shape_against_oracle_and_certificate(H):
     tv = jd.sample_device(device="cuda", dtype=torch.float64, n_samples=n, seed=3)
     m = MCCA(latent_dimensions=k, c=0.1).fit(tv)
     G, s = _device_moments_fp64(tv)
-    W, means, lam = gf.mcca_from_moments(G, s, n, dims, k, c=[0.1] * 4, fast=True)
+
+    def solve():
+        W_, means_, lam_ = gf.mcca_from_moments(G, s, n, dims, k, c=[0.1] * 4, fast=True)
+        return {**{f"W{i}": w for i, w in enumerate(W_)}, "lam": lam_}
+
+    from conftest import host_solve_cached, moments_probe
+
+    o = host_solve_cached("c3_mcca_16384", moments_probe(G, s), solve)
+    W, lam = [o[f"W{i}"] for i in range(4)], o["lam"]
     for w, r in zip(m.weights_, W):
         assert w.shape == (2048, k) and col_rel_err(w, r) < 1e-5
     np.testing.assert_allclose(m.eigenvalues_, lam, rtol=1e-8)

@@ -121,7 +121,7 @@ def test_bench_two_ranks_on_one_gpu_prints_one_json_line():
     ONE JSON line) with two ranks on the one GPU; a reduced n keeps it to seconds."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--transport", "gloo-staged", "--steps", "2", "--warmup", "1",
-           "--no-extras", "--no-cpu-baseline", "--rows", "131072", "--d", "1024", "--k", "16"]
+           "--no-extras", "--no-cpu-baseline", "--rows", "131072", "--dim", "1024", "--k", "16"]     # (--dim: torch.distributed.run would take "--d" for one of its own options)
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-4000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")]
