@@ -131,7 +131,7 @@ print("child ok")
 """
 
 
-_SWITCHES = [
+@pytest.mark.parametrize("env", [
     {"CCZ_CHOLINV_CHAIN": "0"},                           # launch-per-link form, 16-column panels
     {"CCZ_CHOLINV_CHAIN": "0", "CCZ_CHOLINV_MFMA": "1"},  # ... with the 4-column panels of rounds 2-4
     {"CCZ_CHOLINV_MFMA": "1"},                            # chain kernel on the 4-column panels
@@ -139,21 +139,13 @@ _SWITCHES = [
     {"CCZ_CHAIN_WGS": "24"},
     {"CCZ_LOSS_FAST": "0"},                               # the general route of the loss (moments + k_loss_prep)
     {"CCZ_LOSS_SPLITK": "1"},
-]
-
-
-def test_switches_in_child_processes():
-    """Every A/B switch is read once per process: one child per setting, all started together (they share the GPU; the
-    seven imports of torch used to run one after the other: 35 s of the suite)."""
-    procs = []
-    for env in _SWITCHES:
-        e = dict(os.environ)
-        e.update(env)
-        procs.append((env, subprocess.Popen([sys.executable, "-c", _CHILD % (ROOT, os.path.join(ROOT, "tests"))], env=e, stdout=subprocess.PIPE,
-                                            stderr=subprocess.PIPE, text=True)))
-    for env, p in procs:
-        out, err = p.communicate(timeout=900)
-        assert p.returncode == 0 and "child ok" in out, f"{env}: " + out[-2000:] + err[-4000:]
+])
+def test_switches_in_a_child_process(env):
+    # (one child at a time: seven processes sharing the GPU with their persistent chain kernels did not finish in 10 minutes)
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-c", _CHILD % (ROOT, os.path.join(ROOT, "tests"))], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 # ---------------------------------------------------------------------------------------------
