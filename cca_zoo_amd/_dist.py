@@ -38,7 +38,7 @@ class CczComm:
     def from_file(cls, path, world, rank, handle=None, timeout_s=120.0, tag=None):
         """Ship the communicator id through ``path`` on a file system every rank sees.  The file carries a 32-byte run tag
         behind the 128-byte id: ``tag`` (any string; default: the launcher's ``MASTER_ADDR:MASTER_PORT:TORCHELASTIC_RUN_ID``
-        when present) -- readers ignore a file whose tag is not theirs, so an id left behind by an earlier run is never
+        when a run id is present -- without one a ``tag`` is required) -- readers ignore a file whose tag is not theirs, so an id left behind by an earlier run is never
         joined.  Rank 0 removes a stale file first and deletes its own in :meth:`close`.  Without a launcher and without
         ``tag`` the path must be fresh per run."""
         import hashlib
@@ -49,7 +49,13 @@ class CczComm:
 
         h = handle or _backend.default_handle()
         if tag is None:
-            tag = ":".join(os.environ.get(k, "") for k in ("MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"))
+            run_id = os.environ.get("TORCHELASTIC_RUN_ID", "")
+            if run_id in ("", "none"):
+                # a static rendezvous (fixed port, no run id) gives the SAME default tag to every run: a rank could join the
+                # id file a crashed run left behind and hang in ncclCommInitRank -- ask for a tag instead
+                raise ValueError("CczComm.from_file: no per-run launcher id in the environment (TORCHELASTIC_RUN_ID); pass tag=<a string "
+                                 "unique to this run> or use a fresh path")
+            tag = ":".join((os.environ.get("MASTER_ADDR", ""), os.environ.get("MASTER_PORT", ""), run_id))
         mark = hashlib.sha256(str(tag).encode()).digest()
         if rank == 0:
             try:

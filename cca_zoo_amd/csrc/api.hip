@@ -103,7 +103,7 @@ int ccz_destroy(ccz_handle h) {
     for (auto& b : im->pool) (void)hipFree(b.p);
     for (auto& t : im->tile_tabs) if (t.dev) (void)hipFree(t.dev);
     for (auto& e : im->chain_sync) if (e.second) (void)hipFree(e.second);
-    if (im->colsum_counters) (void)hipFree(im->colsum_counters);
+    for (auto& e : im->colsum_sync) if (e.second) (void)hipFree(e.second);
     for (auto& e : im->k1_plans) if (e.dev) (void)hipFree(e.dev);
     if (im->chain_dbg) (void)hipFree(im->chain_dbg);
     if (im->xchg_buf) (void)hipFree(im->xchg_buf);

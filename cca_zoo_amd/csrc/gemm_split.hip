@@ -91,17 +91,23 @@ __global__ __launch_bounds__(256) void k_splitT_bf16x2(SplitTViews vw, int64_t r
   }
 }
 
-// corr[n] = sum_k (mean_k - fl32(mean_k)) Gamma[k][n]: what the pilot-shifted A side still owes the exact centring
+// corr[n] += sum_k (mean_k - fl32(mean_k)) Gamma[k][n]: what the pilot-shifted A side still owes the exact centring.
+// grid = (column blocks of 256, row slabs of 64): the K rows are spread over the chip (a thread per column walking all K
+// rows alone was 8192 dependent loads long); corr is zeroed by the caller.
 __global__ __launch_bounds__(256) void k_pilot_corr(const double* __restrict__ mean, const double* __restrict__ gamma, int64_t K, int64_t N,
                                                     int64_t ldg, double* __restrict__ corr) {
   const int64_t n = int64_t(blockIdx.x) * 256 + threadIdx.x;
   if (n >= N) return;
-  double a = 0.0;
-  for (int64_t k = 0; k < K; ++k) {
-    const double mk = mean[k];
-    a += (mk - double(float(mk))) * gamma[k * ldg + n];
+  const int64_t k0 = int64_t(blockIdx.y) * 64, k1 = min(K, k0 + 64);
+  double a0 = 0.0, a1 = 0.0;
+  int64_t k = k0;
+  for (; k + 1 < k1; k += 2) {
+    const double m0 = mean[k], m1 = mean[k + 1];
+    a0 += (m0 - double(float(m0))) * gamma[k * ldg + n];
+    a1 += (m1 - double(float(m1))) * gamma[(k + 1) * ldg + n];
   }
-  corr[n] = a;
+  if (k < k1) { const double m0 = mean[k]; a0 += (m0 - double(float(m0))) * gamma[k * ldg + n]; }
+  unsafeAtomicAdd(corr + n, a0 + a1);
 }
 
 // ---------------------------------------------------------------------------
@@ -202,7 +208,8 @@ void gemm_split_pair(ccz_ctx* c, int64_t M, int64_t N, int64_t K, int64_t K1, fl
   };
   try {
     split_k1_layout(c, gamma32, K, N, N, S, planesB);
-    hipLaunchKernelGGL(k_pilot_corr, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, mean, gamma64, K, N, ldg, corr);
+    zero(c, corr, size_t(N) * 8);
+    hipLaunchKernelGGL(k_pilot_corr, dim3((unsigned)((N + 255) / 256), (unsigned)((K + 63) / 64)), dim3(256), 0, st, mean, gamma64, K, N, ldg, corr);
     planesA = static_cast<char*>(dev_alloc(c, size_t(std::min(tiles_per_launch, row_tiles_all)) * per_tile));
     SplitTViews vw{};
     vw.m = 2;

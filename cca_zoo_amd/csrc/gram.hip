@@ -1479,9 +1479,16 @@ bool gram_partials_f32(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n
   int64_t rpb = 2048;
   while (rpb > 32 && colblocks * ((n + rpb - 1) / rpb) < int64_t(ncu)) rpb /= 2;
   const int64_t rowblocks = (n + rpb - 1) / rpb;
-  if (!im->colsum_counters) {
-    CCZ_HIP(hipMalloc(reinterpret_cast<void**>(&im->colsum_counters), 64 * sizeof(unsigned)));
-    CCZ_HIP(hipMemsetAsync(im->colsum_counters, 0, 64 * sizeof(unsigned), st));
+  // arrival counters of k_colsum_pilot: one block of 64 words per STREAM (like the chain kernel's sync block): two losses on
+  // one handle enqueued on different streams may overlap, and shared counters would elect the wrong "last row block"
+  unsigned* counters = nullptr;
+  for (auto& e : im->colsum_sync)
+    if (e.first == static_cast<void*>(st)) { counters = static_cast<unsigned*>(e.second); break; }
+  if (!counters) {
+    if (im->colsum_sync.size() >= 32) return false;         // (a caller cycling through streams: the general route)
+    CCZ_HIP(hipMalloc(reinterpret_cast<void**>(&counters), 64 * sizeof(unsigned)));
+    CCZ_HIP(hipMemsetAsync(counters, 0, 64 * sizeof(unsigned), st));
+    im->colsum_sync.emplace_back(static_cast<void*>(st), static_cast<void*>(counters));
   }
   out->colsum = static_cast<double*>(dev_alloc(c, size_t(D) * 8));
   out->pilot = static_cast<float*>(dev_alloc(c, size_t(D) * 4));
@@ -1496,7 +1503,7 @@ bool gram_partials_f32(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n
     cv.ld[v] = views[v].ld;
     cv.off[v + 1] = cv.off[v] + int(views[v].cols);
   }
-  hipLaunchKernelGGL(k_colsum_pilot, dim3((unsigned)colblocks, (unsigned)rowblocks), dim3(256), 0, st, cv, n, D, rpb, part, im->colsum_counters,
+  hipLaunchKernelGGL(k_colsum_pilot, dim3((unsigned)colblocks, (unsigned)rowblocks), dim3(256), 0, st, cv, n, D, rpb, part, counters,
                      out->colsum, out->pilot);
   const size_t lds_bytes = size_t(2) * 2 * BK * T32 * sizeof(float);
   if (fifo_plan_ok) {

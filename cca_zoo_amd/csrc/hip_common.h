@@ -78,7 +78,7 @@ struct Impl {
   struct K1Plan { uint64_t key; void* dev; int wgs; };
   std::vector<K1Plan> k1_plans;          // gram.hip: per-tile row splits of k_gram_f32_fifo_small, by batch shape
   hipEvent_t sp_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // gram_split.hip: stage boundaries of a timed split-route launch
-  unsigned* colsum_counters = nullptr;   // gram.hip: arrival counters of k_colsum_pilot (64 words, zero between launches)
+  std::vector<std::pair<void*, void*>> colsum_sync;   // gram.hip: per-stream arrival counters of k_colsum_pilot (64 words each, zero between launches)
   // comm.hip: ccz_moments_exchange -- the packed blocks buffer the handle keeps between fits (grown on demand), the stream its
   // collectives run on and the events that tie it to the handle's stream
   void* xchg_buf = nullptr;

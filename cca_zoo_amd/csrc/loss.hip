@@ -413,7 +413,9 @@ void pair_core(ccz_ctx* c, const double* mom, int64_t n, const int64_t* dims, in
     }
     launch(pr);
   }
-  // (the centring row mean' Gamma: k_loss_tail, or k_bias_row for the callers that keep their own tail)
+  // The centring row mean' Gamma is NOT formed here: bias_dev is only zeroed by the preparation kernel (it is an accumulation
+  // target); every caller that passes bias_dev launches k_loss_tail next, which fills it (there is no k_bias_row
+  // any more -- a caller without that tail must compute the row itself).
 }
 
 void check_info(ccz_ctx* c, const int* info_dev, int m, const char* what) {

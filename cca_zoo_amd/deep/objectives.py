@@ -27,6 +27,7 @@ from __future__ import annotations
 import ctypes as C
 
 import torch
+from torch.autograd.function import once_differentiable
 import torch.nn as nn
 
 from cca_zoo_amd import _backend
@@ -170,6 +171,7 @@ class _PairLossFn(torch.autograd.Function):
         return loss
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, grad_out):
         state, *vs = ctx.saved_tensors
         m = len(vs)
@@ -213,19 +215,24 @@ class _InvSqrtmFn(torch.autograd.Function):
         Vr = torch.empty((d, d), dtype=torch.float64, device=A.device)   # row i = eigenvector i
         sp = _stream_ptr(A)
         h.acquire(sp)
-        h.check(h.lib.ccz_syevj(h.raw, C.c_void_p(a64.data_ptr()), d, C.c_void_p(w.data_ptr()), C.c_void_p(Vr.data_ptr()), None))
-        h.release(sp)
+        try:                                                         # (ENOCONV / out of memory must not leave torch's stream un-joined)
+            h.check(h.lib.ccz_syevj(h.raw, C.c_void_p(a64.data_ptr()), d, C.c_void_p(w.data_ptr()), C.c_void_p(Vr.data_ptr()), None))
+        finally:
+            h.release(sp)
         f = torch.clamp(w, min=eps).rsqrt()
         scaled = (Vr * f[:, None]).contiguous()                      # diag(f) V'
         out = torch.empty((d, d), dtype=torch.float64, device=A.device)
         h.acquire(sp)
-        h.gemm(True, False, d, d, d, 1.0, Vr.data_ptr(), d, scaled.data_ptr(), d, 0.0, out.data_ptr(), d)   # V diag(f) V'
-        h.release(sp)
+        try:
+            h.gemm(True, False, d, d, d, 1.0, Vr.data_ptr(), d, scaled.data_ptr(), d, 0.0, out.data_ptr(), d)   # V diag(f) V'
+        finally:
+            h.release(sp)
         ctx.save_for_backward(w, Vr, f)
         ctx.eps, ctx.dtype = float(eps), A.dtype
         return out.to(A.dtype)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, G):
         w, Vr, f = ctx.saved_tensors
         d = int(w.shape[0])
@@ -240,14 +247,18 @@ class _InvSqrtmFn(torch.autograd.Function):
         M = torch.empty((d, d), dtype=torch.float64, device=Vr.device)
         sp = _stream_ptr(Vr)
         h.acquire(sp)
-        h.gemm(False, False, d, d, d, 1.0, Vr.data_ptr(), d, g64.data_ptr(), d, 0.0, t1.data_ptr(), d)      # V' G   (rows of Vr = eigenvectors)
-        h.gemm(False, True, d, d, d, 1.0, t1.data_ptr(), d, Vr.data_ptr(), d, 0.0, M.data_ptr(), d)        # V' G V
-        h.release(sp)
+        try:
+            h.gemm(False, False, d, d, d, 1.0, Vr.data_ptr(), d, g64.data_ptr(), d, 0.0, t1.data_ptr(), d)      # V' G   (rows of Vr = eigenvectors)
+            h.gemm(False, True, d, d, d, 1.0, t1.data_ptr(), d, Vr.data_ptr(), d, 0.0, M.data_ptr(), d)        # V' G V
+        finally:
+            h.release(sp)
         MK = (M * K).contiguous()
         h.acquire(sp)
-        h.gemm(True, False, d, d, d, 1.0, Vr.data_ptr(), d, MK.data_ptr(), d, 0.0, t1.data_ptr(), d)       # V (M o K)
-        h.gemm(False, False, d, d, d, 1.0, t1.data_ptr(), d, Vr.data_ptr(), d, 0.0, M.data_ptr(), d)       # ... V'
-        h.release(sp)
+        try:
+            h.gemm(True, False, d, d, d, 1.0, Vr.data_ptr(), d, MK.data_ptr(), d, 0.0, t1.data_ptr(), d)       # V (M o K)
+            h.gemm(False, False, d, d, d, 1.0, t1.data_ptr(), d, Vr.data_ptr(), d, 0.0, M.data_ptr(), d)       # ... V'
+        finally:
+            h.release(sp)
         return M.to(ctx.dtype), None
 
 
