@@ -33,6 +33,11 @@ __device__ __forceinline__ unsigned sp_pack2(float a, float b) {
 
 typedef __attribute__((address_space(3))) void* sp_lds_ptr;
 
+// one of the eight 1 KiB DMAs of this wave's quarter of a k-step
+#define SP_DMA1(slot, soff, i_)                                                                                     \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(src, (sp_lds_ptr)(wr_base + (slot) * SP_STAGE + (i_) * 1024), 16, voff,  \
+                                           (soff) + (i_) * 1024, 0, 0)
+
 // DMA of this wave's quarter (8 KiB: one plane of one panel) of k-step `soff / SP_PSTEP` into slot `slot`
 #define SP_DMA(slot, soff)                                                                                          \
   do {                                                                                                              \
@@ -93,48 +98,44 @@ __device__ __forceinline__ void split_mma_core(sp_v16f32 (&acc)[4][4], char* sme
       // step s = 4 it + u: its fragments are in set `cur`; steps s+1 .. s+3 are in flight / landed in the other slots
       asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      SP_DMA(u, soff);                       // step s + 4 -> the slot step s was read from
-      soff += SP_PSTEP;
       __builtin_amdgcn_sched_barrier(0);
       const char* nA = rdA + nslot * SP_STAGE;
       const char* nB = rdB + nslot * SP_STAGE;
-      // ---- hi' hi ----
-#pragma unroll
-      for (int ti = 0; ti < 4; ++ti) {
-        if (ti >= TI0 && ti < TI1) ah[nxt][ti] = *reinterpret_cast<const sp_v8bf16*>(nA + ti * 1024);
-        bh[nxt][ti] = *reinterpret_cast<const sp_v8bf16*>(nB + ti * 1024);
-        __builtin_amdgcn_sched_barrier(0);
-        if (ti >= TI0 && ti < TI1) {
-#pragma unroll
-          for (int tj = (MODE == 1 ? ti : 0); tj < 4; ++tj)
-            acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[cur][tj], ah[cur][ti], acc[ti][tj], 0, 0, 0);
+      // The step's other instructions -- NR = 2 NA + 8 fragment reads of step s + 1 and the 8 DMAs of step s + 4 (into the slot
+      // step s was read from) -- ride ONE PER MFMA behind the first NR + 8 MFMAs: an in-order wave hides about five issue
+      // slots per 32-cycle MFMA (MI355X_MICROARCH.md), and blocks of ten between MFMA groups kept the matrix pipe waiting.
+      constexpr int NA = TI1 - TI0, NR = 2 * NA + 8;
+      int fi = 0;                                   // filler index: a compile-time constant after unrolling
+      auto filler = [&](int k) {
+        // k < 16: reads and DMAs alternate (read k / 2, DMA k / 2); from 16 on: reads 8 .. NR - 1
+        const bool is_dma = k < 16 && (k & 1);
+        const int r = k < 16 ? (k >> 1) : k - 8;
+        if (is_dma) {
+          SP_DMA1(u, soff, k >> 1);
+        } else if (r < NR) {
+          // read order: A hi (NA), B hi (4), B mid (4), A mid (NA)
+          if (r < NA) ah[nxt][TI0 + r] = *reinterpret_cast<const sp_v8bf16*>(nA + (TI0 + r) * 1024);
+          else if (r < NA + 4) bh[nxt][r - NA] = *reinterpret_cast<const sp_v8bf16*>(nB + (r - NA) * 1024);
+          else if (r < NA + 8) bm[nxt][r - NA - 4] = *reinterpret_cast<const sp_v8bf16*>(nB + SP_PLANE + (r - NA - 4) * 1024);
+          else am[nxt][TI0 + r - NA - 8] = *reinterpret_cast<const sp_v8bf16*>(nA + SP_PLANE + (TI0 + r - NA - 8) * 1024);
         }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      // ---- hi' mid ----
+      };
 #pragma unroll
-      for (int ti = 0; ti < 4; ++ti) {
-        bm[nxt][ti] = *reinterpret_cast<const sp_v8bf16*>(nB + SP_PLANE + ti * 1024);
-        __builtin_amdgcn_sched_barrier(0);
-        if (ti >= TI0 && ti < TI1) {
+      for (int g = 0; g < 3; ++g) {                 // 0: hi' hi, 1: hi' mid, 2: mid' hi
 #pragma unroll
-          for (int tj = (MODE == 1 ? ti : 0); tj < 4; ++tj)
-            acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bm[cur][tj], ah[cur][ti], acc[ti][tj], 0, 0, 0);
+        for (int ti = TI0; ti < TI1; ++ti) {
+#pragma unroll
+          for (int tj = (MODE == 1 ? ti : 0); tj < 4; ++tj) {
+            const sp_v8bf16 opB = g == 1 ? bm[cur][tj] : bh[cur][tj];
+            const sp_v8bf16 opA = g == 2 ? am[cur][ti] : ah[cur][ti];
+            acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(opB, opA, acc[ti][tj], 0, 0, 0);
+            if (fi < NR + 8) filler(fi);
+            ++fi;
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
-        __builtin_amdgcn_sched_barrier(0);
       }
-      // ---- mid' hi ----
-#pragma unroll
-      for (int ti = 0; ti < 4; ++ti) {
-        if (ti >= TI0 && ti < TI1) am[nxt][ti] = *reinterpret_cast<const sp_v8bf16*>(nA + SP_PLANE + ti * 1024);
-        __builtin_amdgcn_sched_barrier(0);
-        if (ti >= TI0 && ti < TI1) {
-#pragma unroll
-          for (int tj = (MODE == 1 ? ti : 0); tj < 4; ++tj)
-            acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[cur][tj], am[cur][ti], acc[ti][tj], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      soff += SP_PSTEP;
     }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the run-ahead DMAs (zeros past the extent) must land before the LDS is handed on
