@@ -28,7 +28,7 @@ def test_header_symbols_all_exported(libpath):
     for name in declared:
         assert hasattr(lib, name), name
     _backend.bind(lib, strict=True)
-    assert lib.ccz_version() == 140
+    assert lib.ccz_version() == 150
 
 
 def test_no_gpu_fails_loudly(libpath):

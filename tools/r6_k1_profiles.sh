@@ -19,4 +19,4 @@ grep -h "iter" $O/pmcs_1.log | tail -4 >> $O/r06_k_gram_bf16x2_pmc_raw.md
 rm -rf /tmp/pmcs_*
 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/p_k1 -o k1 -- python $R/tools/gram_probe.py --n $N --d 4096 --views 2 --route bf16x2 --fill latent --iters 3 > $O/k1_stats.log 2>&1
 f=$(find /tmp/p_k1 -name "*results.db" | head -1); python $R/tools/rocpd_stats.py $f > $O/r06_k1_kernel_stats.md 2>&1; rm -rf /tmp/p_k1
-cd $R; tail -3 $O/fill_*.log; cat $O/r06_k_gram_bf16x2_pmc_raw.md; head -20 $O/r06_k1_kernel_stats.md
+cd $R; for f in $O/fill_*.log; do tail -n 3 $f; done; cat $O/r06_k_gram_bf16x2_pmc_raw.md; head -20 $O/r06_k1_kernel_stats.md

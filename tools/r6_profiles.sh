@@ -3,7 +3,7 @@
 # DVFS check, kernel statistics of a short bench run, of the metric-shape loss and of the configs[3] loss.  -> gpurun_out/r6p/
 R=$PWD; O=$R/gpurun_out/r6p; mkdir -p $O; export TMPDIR=/tmp; cd /tmp
 N=262144
-bash $R/tools/r6_k1_profiles.sh $N > $O/k1_profiles.log 2>&1
+(cd $R && bash tools/r6_k1_profiles.sh $N) > $O/k1_profiles.log 2>&1
 python $R/tools/pmc_to_traffic.py $O/r06_k_gram_bf16x2_pmc_raw.md $N 8192 > $O/r06_gram_traffic.json 2>> $O/k1_profiles.log
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/p_bench -o b -- python $R/bench.py --steps 3 --warmup 1 --no-extras --no-cpu-baseline > $O/bench_profiled.json 2> $O/bench_profiled.err
 f=$(find /tmp/p_bench -name "*results.db" | head -1); python $R/tools/rocpd_stats.py $f > $O/r06_bench_kernel_stats.md 2>&1; rm -rf /tmp/p_bench
