@@ -53,6 +53,11 @@ static void transform_impl(ccz_ctx* c, int dtype, const void* X, int64_t n, int6
                            const double* W, int64_t k, void* out, int64_t ldo) {
   if (dtype != CCZ_F32 && dtype != CCZ_F64) fail(CCZ_EUNSUP, "transform: dtype must be CCZ_F32 or CCZ_F64");
   if (!X || !W || !out || n < 1 || d < 1 || k < 1 || ld < d || ldo < k) fail(CCZ_EINVAL, "transform: bad argument");
+  if (dtype == CCZ_F32 && project_split_eligible(c, n, d, k, ld, X, ldo)) {
+    // large fp32 projections: the split arithmetic of K1 with the conversion in registers (project_split.hip) -- HBM-bound
+    project_split(c, static_cast<const float*>(X), n, d, ld, mean, W, k, static_cast<float*>(out), ldo);
+    return;
+  }
   DBuf bias(c, k);
   if (mean) gemm(c, false, false, 1, k, d, 1.0, mean, d, W, k, 0.0, bias, k);
   gemm_mixed(c, dtype, n, k, d, 1.0, X, ld, W, k, 0.0, out, ldo, mean ? bias.get() : nullptr);

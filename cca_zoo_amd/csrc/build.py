@@ -23,7 +23,7 @@ OBJ = os.path.join(HERE, "_obj")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIB_DIR, "libccz.so")
 ARCH = "gfx950"
-SOURCES = ["api.hip", "comm.hip", "ops_hip.hip", "gram.hip", "gram_split.hip", "gemm_split.hip", "gemm_big.hip", "gemm64_big.hip", "gemm64_skinny.hip", "cholinv.hip", "evd_block.hip", "loss.hip", "rng.hip", "solve.cpp"]
+SOURCES = ["api.hip", "comm.hip", "ops_hip.hip", "gram.hip", "gram_split.hip", "gemm_split.hip", "project_split.hip", "gemm_big.hip", "gemm64_big.hip", "gemm64_skinny.hip", "cholinv.hip", "evd_block.hip", "loss.hip", "rng.hip", "solve.cpp"]
 HEADERS = ["ops.h", "hip_common.h", "gram_map.h", "split_mma.h", "jacobi_dev.h", "rng_hash.h", os.path.join(ROOT, "include", "ccz.h")]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 HIPFLAGS = [f"--offload-arch={ARCH}", "-munsafe-fp-atomics", "-fgpu-rdc" if False else "-fno-gpu-rdc"]

@@ -181,6 +181,10 @@ bool gemm_split_pair_eligible(int64_t M, int64_t N, int64_t K, int64_t K1, int64
 void gemm_split_pair(ccz_ctx* c, int64_t M, int64_t N, int64_t K, int64_t K1, float alpha, const float* alpha_dev, const float* A1, int64_t lda1,
                      const float* A2, int64_t lda2, const float* gamma32, const double* gamma64, int64_t ldg, const double* mean, float* C1,
                      int64_t ldc1, float* C2, int64_t ldc2, int64_t nsplit);
+// project_split.hip: out (n x k <= 64, fp32) = (X - 1 mean') W with the split arithmetic, X converted in registers (no extra pass)
+bool project_split_eligible(ccz_ctx* c, int64_t n, int64_t d, int64_t k, int64_t ld, const void* X, int64_t ldo);
+void project_split(ccz_ctx* c, const float* X, int64_t n, int64_t d, int64_t ld, const double* mean, const double* W, int64_t k, float* out,
+                   int64_t ldo);
 bool gram_partials_f32(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, GramPartials* out);
 void gram_partials_release(ccz_ctx* c, GramPartials* gp);
 

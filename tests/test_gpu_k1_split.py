@@ -103,6 +103,10 @@ def test_split_route_error_not_above_fp32_route_on_long_inputs(H):
 
 
 def test_auto_route_thresholds(H):
+    import os
+
+    if os.environ.get("CCZ_K1_ROUTE"):
+        pytest.skip("CCZ_K1_ROUTE overrides the automatic choice in this process")
     small = _latent(3000, [256, 256], seed=1)
     _, _, taken, _ = _moments(H, small, "auto")
     assert taken == "fp32"                                   # below the route's pay-off: the fp32 kernel's single launch
