@@ -21,15 +21,22 @@
 namespace ccz {
 
 constexpr int PJ_MT = 2;                          // row tiles (32 samples) per wave
-constexpr int PJ_R = 4;                           // ring slots per wave
 constexpr int PJ_XB = PJ_MT * 2048;               // bytes of X per slot
-constexpr int PJ_SLOT = PJ_XB + 4096;             // + the k-step's W planes [plane 2][j tile 2][1 KiB]
-constexpr int PJ_MAXD = 8128;                     // the pilot row lives in LDS behind the rings (128 KiB of rings + 4 d bytes <= 160 KiB)
+constexpr int PJ_MAXD = 8128;                     // the pilot row lives in LDS behind the rings (<= 128 KiB of rings + 4 d bytes <= 160 KiB)
+// PLANES = 2: x = hi + mid, three products (error of an output ~ 2^-17 of its scale: the dropped hi lo / mid mid terms do not
+//             average out in a projection as they do in K1's coherent sums: measured 4.5e-6 against the fp32 kernel's 1.3e-6);
+// PLANES = 3: x = hi + mid + lo, five products (+ hi lo + lo hi; mid mid ~ 2^-18 stays out): at the fp32 kernel's accuracy.
+template <int PLANES> struct PJ {
+  static constexpr int R = PLANES == 2 ? 4 : 3;              // ring slots per wave
+  static constexpr int WB = PLANES * 2048;                   // bytes of W planes per k-step: [plane][j tile 2][1 KiB]
+  static constexpr int SLOT = PJ_XB + WB;
+  static constexpr int PER = 2 * PJ_MT + PLANES * 2;         // DMAs per k-step
+};
 
 // W (d x k, fp64, ld ldw) -> planes[k-step s][plane H|M][j tile 2][k half 2][j 32][k 8] bf16 (columns >= k are zero),
 // pilot[c] = fl32(mean[c]) and corr[j] += sum_c (mean_c - pilot_c) W_cj.  grid = d / 16 blocks of 128 threads.
 __global__ __launch_bounds__(128) void k_project_prep(const double* __restrict__ W, int64_t d, int k, int64_t ldw, const double* __restrict__ mean,
-                                                      char* __restrict__ planes, float* __restrict__ pilot, double* __restrict__ corr) {
+                                                      char* __restrict__ planes, float* __restrict__ pilot, double* __restrict__ corr, int nplanes) {
   const int s = blockIdx.x, t = threadIdx.x;
   const int jt = t >> 6, l = t & 63, h = l >> 5, j = jt * 32 + (l & 31);
   float v[8];
@@ -44,16 +51,20 @@ __global__ __launch_bounds__(128) void k_project_prep(const double* __restrict__
       cpart += (m - double(float(m))) * w;
     }
   }
-  sp_v4u32 hw, mw;
+  sp_v4u32 hw, mw, lw;
 #pragma unroll
   for (int kk = 0; kk < 8; kk += 2) {
     const unsigned hb = sp_pack2(v[kk], v[kk + 1]);
     hw[kk >> 1] = hb;
-    mw[kk >> 1] = sp_pack2(v[kk] - __builtin_bit_cast(float, hb << 16), v[kk + 1] - __builtin_bit_cast(float, hb & 0xffff0000u));
+    const float r0 = v[kk] - __builtin_bit_cast(float, hb << 16), r1 = v[kk + 1] - __builtin_bit_cast(float, hb & 0xffff0000u);
+    const unsigned mb = sp_pack2(r0, r1);
+    mw[kk >> 1] = mb;
+    lw[kk >> 1] = sp_pack2(r0 - __builtin_bit_cast(float, mb << 16), r1 - __builtin_bit_cast(float, mb & 0xffff0000u));
   }
-  char* dst = planes + int64_t(s) * 4096 + jt * 1024 + l * 16;
+  char* dst = planes + int64_t(s) * (nplanes * 2048) + jt * 1024 + l * 16;
   *reinterpret_cast<sp_v4u32*>(dst) = hw;
   *reinterpret_cast<sp_v4u32*>(dst + 2048) = mw;
+  if (nplanes == 3) *reinterpret_cast<sp_v4u32*>(dst + 4096) = lw;
   if (t < 16) {
     const int64_t c = int64_t(s) * 16 + t;
     if (c < d) pilot[c] = mean ? float(mean[c]) : 0.f;
@@ -61,13 +72,15 @@ __global__ __launch_bounds__(128) void k_project_prep(const double* __restrict__
   if (mean && j < k) unsafeAtomicAdd(corr + j, cpart);
 }
 
-__global__ __launch_bounds__(256, 1) void k_project_bf16x2(const float* __restrict__ X, int64_t n, int64_t d, int64_t ld, const float* __restrict__ pilot,
+template <int PLANES>
+__global__ __launch_bounds__(256, 1) void k_project_split(const float* __restrict__ X, int64_t n, int64_t d, int64_t ld, const float* __restrict__ pilot,
                                                            const char* __restrict__ planes, const double* __restrict__ corr, float* __restrict__ out,
                                                            int64_t ldo, int k) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // the pilot row behind the rings (read by every wave: one barrier, the only one)
+  constexpr int PJ_R = PJ<PLANES>::R, PJ_SLOT = PJ<PLANES>::SLOT, PJ_WB = PJ<PLANES>::WB;
   float* pl = reinterpret_cast<float*>(smem + 4 * PJ_R * PJ_SLOT);
   for (int64_t c = tid; c < d; c += 256) pl[c] = pilot[c];
   __syncthreads();
@@ -78,7 +91,7 @@ __global__ __launch_bounds__(256, 1) void k_project_bf16x2(const float* __restri
   char* ring = smem + wave * (PJ_R * PJ_SLOT);
   const char* rd = ring + lane * 16;
   const __amdgpu_buffer_rsrc_t srcX = panel_rsrc(X + m0 * ld, ((rows - 1) * ld + d) * 4);
-  const __amdgpu_buffer_rsrc_t srcW = panel_rsrc(planes, int64_t(nsteps) * 4096);
+  const __amdgpu_buffer_rsrc_t srcW = panel_rsrc(planes, int64_t(nsteps) * PJ_WB);
   int voffX[PJ_MT][2];
 #pragma unroll
   for (int mt = 0; mt < PJ_MT; ++mt)
@@ -96,17 +109,17 @@ __global__ __launch_bounds__(256, 1) void k_project_bf16x2(const float* __restri
 
   // one k-step's DMAs: 2 PJ_MT pieces of X (rows past the shard, steps past the end: zeros) + 4 KiB of W planes
   auto dma = [&](int slot, int step) {
-    const int soX = step * 64, soW = step * 4096;
+    const int soX = step * 64, soW = step * PJ_WB;
 #pragma unroll
     for (int mt = 0; mt < PJ_MT; ++mt)
 #pragma unroll
       for (int p = 0; p < 2; ++p)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(srcX, (sp_lds_ptr)(ring + slot * PJ_SLOT + (mt * 2 + p) * 1024), 16, voffX[mt][p], soX, 0, 0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2 * PLANES; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(srcW, (sp_lds_ptr)(ring + slot * PJ_SLOT + PJ_XB + i * 1024), 16, voffW, soW + i * 1024, 0, 0);
   };
-  constexpr int PER = 2 * PJ_MT + 4;              // DMAs per k-step
+  static_assert(PJ<PLANES>::PER * (PJ<PLANES>::R - 2) == (PLANES == 2 ? 16 : 10), "the counted waits below assume this many DMAs in flight");
 #pragma unroll
   for (int s = 0; s < PJ_R - 1; ++s) dma(s, s);
   const int nloop = (nsteps + PJ_R - 1) / PJ_R;
@@ -115,16 +128,21 @@ __global__ __launch_bounds__(256, 1) void k_project_bf16x2(const float* __restri
     for (int u = 0; u < PJ_R; ++u) {
       const int step = it * PJ_R + u;
       // step's data: everything but the two newest k-steps has landed
-      if (PER * 2 == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (PLANES == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // 2 x 8
+      else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                  // 1 x 10
+      if (step >= nsteps) {                       // (ring periods past the last k-step: keep the DMA count, skip the arithmetic)
+        dma((u + PJ_R - 1) % PJ_R, step + PJ_R - 1);
+        continue;
+      }
       const char* sl = rd + u * PJ_SLOT;
       const sp_v4f32 p0 = *reinterpret_cast<const sp_v4f32*>(pl + step * 16 + 8 * (lane >> 5));
       const sp_v4f32 p1 = *reinterpret_cast<const sp_v4f32*>(pl + step * 16 + 8 * (lane >> 5) + 4);
-      sp_v8bf16 wh[2], wm[2];
+      sp_v8bf16 wh[2], wm[2], wl[2];
 #pragma unroll
       for (int jt = 0; jt < 2; ++jt) {
         wh[jt] = *reinterpret_cast<const sp_v8bf16*>(sl + PJ_XB + jt * 1024);
         wm[jt] = *reinterpret_cast<const sp_v8bf16*>(sl + PJ_XB + 2048 + jt * 1024);
+        if (PLANES == 3) wl[jt] = *reinterpret_cast<const sp_v8bf16*>(sl + PJ_XB + 4096 + jt * 1024);
       }
       sp_v4f32 xa[PJ_MT], xb[PJ_MT];
 #pragma unroll
@@ -132,23 +150,33 @@ __global__ __launch_bounds__(256, 1) void k_project_bf16x2(const float* __restri
         xa[mt] = *reinterpret_cast<const sp_v4f32*>(sl + (mt * 2) * 1024);
         xb[mt] = *reinterpret_cast<const sp_v4f32*>(sl + (mt * 2 + 1) * 1024);
       }
-      // refill the slot of step - 1 with step + 3 (its fragments were consumed a whole k-step ago)
+      // refill the slot of step - 1 with step + R - 1 (its fragments were consumed a whole k-step ago)
       dma((u + PJ_R - 1) % PJ_R, step + PJ_R - 1);
 #pragma unroll
       for (int mt = 0; mt < PJ_MT; ++mt) {
         const sp_v4f32 da = xa[mt] - p0, db = xb[mt] - p1;
-        sp_v4u32 hw, mw;
-        hw[0] = sp_pack2(da[0], da[1]); hw[1] = sp_pack2(da[2], da[3]); hw[2] = sp_pack2(db[0], db[1]); hw[3] = sp_pack2(db[2], db[3]);
-        mw[0] = sp_pack2(da[0] - __builtin_bit_cast(float, hw[0] << 16), da[1] - __builtin_bit_cast(float, hw[0] & 0xffff0000u));
-        mw[1] = sp_pack2(da[2] - __builtin_bit_cast(float, hw[1] << 16), da[3] - __builtin_bit_cast(float, hw[1] & 0xffff0000u));
-        mw[2] = sp_pack2(db[0] - __builtin_bit_cast(float, hw[2] << 16), db[1] - __builtin_bit_cast(float, hw[2] & 0xffff0000u));
-        mw[3] = sp_pack2(db[2] - __builtin_bit_cast(float, hw[3] << 16), db[3] - __builtin_bit_cast(float, hw[3] & 0xffff0000u));
+        const float dv[8] = {da[0], da[1], da[2], da[3], db[0], db[1], db[2], db[3]};
+        sp_v4u32 hw, mw, lw;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const unsigned hb = sp_pack2(dv[2 * q], dv[2 * q + 1]);
+          hw[q] = hb;
+          const float r0 = dv[2 * q] - __builtin_bit_cast(float, hb << 16), r1 = dv[2 * q + 1] - __builtin_bit_cast(float, hb & 0xffff0000u);
+          const unsigned mb = sp_pack2(r0, r1);
+          mw[q] = mb;
+          if (PLANES == 3) lw[q] = sp_pack2(r0 - __builtin_bit_cast(float, mb << 16), r1 - __builtin_bit_cast(float, mb & 0xffff0000u));
+        }
         const sp_v8bf16 xh = __builtin_bit_cast(sp_v8bf16, hw), xm = __builtin_bit_cast(sp_v8bf16, mw);
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt) {
           acc[mt][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[jt], xh, acc[mt][jt], 0, 0, 0);
           acc[mt][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm[jt], xh, acc[mt][jt], 0, 0, 0);
           acc[mt][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[jt], xm, acc[mt][jt], 0, 0, 0);
+          if (PLANES == 3) {
+            const sp_v8bf16 xl = __builtin_bit_cast(sp_v8bf16, lw);
+            acc[mt][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[jt], xh, acc[mt][jt], 0, 0, 0);
+            acc[mt][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[jt], xl, acc[mt][jt], 0, 0, 0);
+          }
         }
       }
     }
@@ -184,8 +212,7 @@ bool project_split_eligible(ccz_ctx* c, int64_t n, int64_t d, int64_t k, int64_t
   const char* e_on = getenv("CCZ_PROJECT_SPLIT");
   if (e_on && atoi(e_on) == 0) return false;
   if (c->k1_route == CCZ_K1_FP32) return false;
-  if (k < 1 || k > 64 || d % 64 != 0 || d > PJ_MAXD ||     // (whole ring periods of k-steps: no step past the last column)
-      ld % 4 != 0 || reinterpret_cast<uintptr_t>(X) % 16 != 0 || ldo < k) return false;
+  if (k < 1 || k > 64 || d % 16 != 0 || d > PJ_MAXD || ld % 4 != 0 || reinterpret_cast<uintptr_t>(X) % 16 != 0 || ldo < k) return false;
   if (double(n) * double(d) < double(int64_t(1) << 26) || n < 32768) return false;        // small projections keep the fp32 kernel
   if ((int64_t(32 * PJ_MT) * ld + d) * 4 > 0x7fffffffLL) return false;
   return true;
@@ -196,16 +223,25 @@ void project_split(ccz_ctx* c, const float* X, int64_t n, int64_t d, int64_t ld,
                    int64_t ldo) {
   hipStream_t st = stream(c);
   const int64_t nsteps = d / 16;
-  char* planes = static_cast<char*>(dev_alloc(c, size_t(nsteps) * 4096));
+  // CCZ_PROJECT_PLANES=2: two planes, three products (faster by ~x, 3.5x the fp32 kernel's error); default 3 planes, five products
+  const char* e_pl = getenv("CCZ_PROJECT_PLANES");
+  const int nplanes = (e_pl && atoi(e_pl) == 2) ? 2 : 3;
+  char* planes = static_cast<char*>(dev_alloc(c, size_t(nsteps) * size_t(nplanes) * 2048));
   float* pilot = static_cast<float*>(dev_alloc(c, size_t(d) * 4));
   double* corr = static_cast<double*>(dev_alloc(c, 64 * 8));
   try {
     zero(c, corr, 64 * 8);
-    hipLaunchKernelGGL(k_project_prep, dim3((unsigned)nsteps), dim3(128), 0, st, W, d, int(k), k, mean, planes, pilot, corr);
-    const size_t lds = size_t(4) * PJ_R * PJ_SLOT + size_t(d) * 4;
-    CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project_bf16x2), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+    hipLaunchKernelGGL(k_project_prep, dim3((unsigned)nsteps), dim3(128), 0, st, W, d, int(k), k, mean, planes, pilot, corr, nplanes);
     const int64_t wgs = (n + 4 * 32 * PJ_MT - 1) / (4 * 32 * PJ_MT);
-    hipLaunchKernelGGL(k_project_bf16x2, dim3((unsigned)wgs), dim3(256), lds, st, X, n, d, ld, pilot, planes, mean ? corr : nullptr, out, ldo, int(k));
+    if (nplanes == 2) {
+      const size_t lds = size_t(4) * PJ<2>::R * PJ<2>::SLOT + size_t(d) * 4;
+      CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project_split<2>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+      hipLaunchKernelGGL(k_project_split<2>, dim3((unsigned)wgs), dim3(256), lds, st, X, n, d, ld, pilot, planes, mean ? corr : nullptr, out, ldo, int(k));
+    } else {
+      const size_t lds = size_t(4) * PJ<3>::R * PJ<3>::SLOT + size_t(d) * 4;
+      CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project_split<3>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+      hipLaunchKernelGGL(k_project_split<3>, dim3((unsigned)wgs), dim3(256), lds, st, X, n, d, ld, pilot, planes, mean ? corr : nullptr, out, ldo, int(k));
+    }
     CCZ_LAUNCH_CHECK();
   } catch (...) {
     dev_free(c, corr); dev_free(c, pilot); dev_free(c, planes);
