@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="rows of the rCCA CPU comparator's sample (0: 2 d)")
     ap.add_argument("--cpu-runs", type=int, default=3, help="repeats of the rCCA CPU comparator at n = 2 d (a run is ~25 s; the median is reported)")
     ap.add_argument("--no-gates", action="store_true", help="skip the parity gates of the extras (the headline gate always runs)")
-    ap.add_argument("--only", default="", help="comma-separated subset of the extras to run (routes, dcca, grid, host, metric_loss, configs, evd)")
+    ap.add_argument("--only", default="", help="comma-separated subset of the extras to run (routes, transform, dcca, grid, host, metric_loss, configs, evd)")
     ap.add_argument("--transport", choices=["torch", "ccz", "gloo-staged"], default=os.environ.get("CCZ_BENCH_TRANSPORT", "torch"),
                     help="exchange step of the sharded fit: torch.distributed (nccl = RCCL) all-reduces, or libccz's own RCCL collective "
                          "behind the C ABI (ccz_moments_exchange); both run the two-part exchange that overlaps the factorization")
@@ -787,6 +787,48 @@ def training_step_extra(batch=8192, d_in=784, hidden=1024, d_out=512, steps=30, 
             "note": "loss_increment ~ loss_alone means the objective adds its own kernel time and no queue drain"}
 
 
+def transform_extra(h, views, model):
+    """``transform`` of the first timed view (n x d fp32 -> n x k): HBM-bound by its algorithmic bytes n d 4.
+    The fp32 kernel (what ``auto`` runs) and the opt-in split projection (``ccz_k1_route(bf16x2)``), each against a float64
+    product on 65536 rows."""
+    import ctypes as C
+
+    import numpy as np
+    import torch
+
+    from cca_zoo_amd import _backend
+
+    X = views[0]
+    n, d = int(X.shape[0]), int(X.shape[1])
+    W = torch.as_tensor(np.ascontiguousarray(model.weights_[0], dtype=np.float64), device=X.device)
+    mean = torch.as_tensor(np.asarray(model.means_[0], dtype=np.float64), device=X.device)
+    k = int(W.shape[1])
+    out = torch.empty((n, k), dtype=torch.float32, device=X.device)
+    ref = (X[:65536].double() - mean) @ W
+    res = {"metric": f"transform of one {n} x {d} fp32 view onto k = {k} directions", "bytes": float(n) * d * 4}
+    prev = h.k1_route(None)
+    try:
+        for route in ("auto", "bf16x2"):
+            h.k1_route(route)
+            ts = []
+            for _ in range(5):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                h.check(h.lib.ccz_transform(h.raw, _backend.F32, C.c_void_p(X.data_ptr()), n, d, X.stride(0), C.c_void_p(mean.data_ptr()),
+                                            C.c_void_p(W.data_ptr()), k, C.c_void_p(out.data_ptr()), out.stride(0)))
+                h.sync()
+                ts.append((time.perf_counter() - t0) * 1e3)
+            ms = float(np.median(ts[1:]))
+            err = float((out[:65536].double() - ref).norm() / ref.norm())
+            res["fp32_kernel" if route == "auto" else "split_projection_opt_in"] = {
+                "ms": ms, "rel_err_vs_float64": err,
+                "roofline": {"bound": "hbm", "achieved": n * d * 4 / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                             "frac": n * d * 4 / (ms * 1e-3) / 1e9 / 8000.0}}
+    finally:
+        h.k1_route(prev)
+    return res
+
+
 def timed_fit(make_model, views, runs):
     import numpy as np
     import torch
@@ -1409,6 +1451,8 @@ def main():
             if not a.no_dcca and want("dcca"):
                 gated("dcca_loss", dcca_extra(gate=gates))
                 extra["dcca_training_step"] = training_step_extra()
+            if a.dtype == "f32" and want("transform"):
+                extra["transform"] = transform_extra(h, views, model)
             if want("grid"):
                 extra["grid_search"] = grid_extra(views, a.k, ms_per_step)
             if want("host"):

@@ -211,7 +211,11 @@ __global__ __launch_bounds__(256, 1) void k_project_split(const float* __restric
 bool project_split_eligible(ccz_ctx* c, int64_t n, int64_t d, int64_t k, int64_t ld, const void* X, int64_t ldo) {
   const char* e_on = getenv("CCZ_PROJECT_SPLIT");
   if (e_on && atoi(e_on) == 0) return false;
-  if (c->k1_route == CCZ_K1_FP32) return false;
+  // OPT-IN: only when the handle's route was set to CCZ_K1_BF16X2 explicitly.  A projection is a random-walk sum, so the dropped
+  // 2^-17 terms do not average out as in K1's coherent sums: outputs agree with a float64 product to 4.5e-6 (two planes) / 2.9e-6
+  // (three planes, five products) of their scale against the fp32 kernel's 1.3e-6 -- inside the path's 1e-3 bar, but narrower
+  // than the reference's float32 product, so `auto` keeps the fp32 kernel (4.07 / 4.63 ms against 5.2 ms per 1e6 x 4096 view).
+  if (c->k1_route != CCZ_K1_BF16X2) return false;
   if (k < 1 || k > 64 || d % 16 != 0 || d > PJ_MAXD || ld % 4 != 0 || reinterpret_cast<uintptr_t>(X) % 16 != 0 || ldo < k) return false;
   if (double(n) * double(d) < double(int64_t(1) << 26) || n < 32768) return false;        // small projections keep the fp32 kernel
   if ((int64_t(32 * PJ_MT) * ld + d) * 4 > 0x7fffffffLL) return false;
@@ -223,9 +227,9 @@ void project_split(ccz_ctx* c, const float* X, int64_t n, int64_t d, int64_t ld,
                    int64_t ldo) {
   hipStream_t st = stream(c);
   const int64_t nsteps = d / 16;
-  // CCZ_PROJECT_PLANES=2: two planes, three products (faster by ~x, 3.5x the fp32 kernel's error); default 3 planes, five products
+  // two planes / three products by default (4.07 ms, 4.5e-6); CCZ_PROJECT_PLANES=3: three planes / five products (4.63 ms, 2.9e-6)
   const char* e_pl = getenv("CCZ_PROJECT_PLANES");
-  const int nplanes = (e_pl && atoi(e_pl) == 2) ? 2 : 3;
+  const int nplanes = (e_pl && atoi(e_pl) == 3) ? 3 : 2;
   char* planes = static_cast<char*>(dev_alloc(c, size_t(nsteps) * size_t(nplanes) * 2048));
   float* pilot = static_cast<float*>(dev_alloc(c, size_t(d) * 4));
   double* corr = static_cast<double*>(dev_alloc(c, 64 * 8));

@@ -230,3 +230,38 @@ def test_loss_backward_on_the_split_route_matches_closed_form(H, monkeypatch):
         assert np.linalg.norm(b - 3.0 * g2) < 1e-3 * np.linalg.norm(3.0 * g2), route
     # the two routes agree far inside the bar
     assert np.linalg.norm(grads["bf16x2"][1] - grads["fp32"][1]) < 2e-5 * np.linalg.norm(grads["fp32"][1])
+
+
+@pytest.mark.parametrize("planes", ["2", "3"])
+def test_projection_on_the_split_arithmetic_is_opt_in_and_matches_float64(H, monkeypatch, planes):
+    """``ccz_transform`` with the handle's route set to bf16x2 EXPLICITLY (csrc/project_split.hip): (X - mean) W against a
+    float64 product, ragged row count, k < 64, off-centre data; ``auto`` keeps the fp32 kernel for projections (their error is
+    not averaged over the rows like K1's).  Reference: cca_zoo/_base.py:108-123."""
+    import ctypes as C
+
+    import torch
+
+    from cca_zoo_amd import _backend
+
+    monkeypatch.setenv("CCZ_PROJECT_PLANES", planes)
+    n, d, k = 40003, 2048, 24
+    g = torch.Generator(device="cuda").manual_seed(5)
+    X = torch.randn(n, d, device="cuda", generator=g) * 1.5 + 3.0
+    mean = X.double().mean(0)
+    W = torch.randn(d, k, dtype=torch.float64, device="cuda", generator=g) / d ** 0.5
+    ref = (X.double() - mean) @ W
+    res = {}
+    for route in ("auto", "bf16x2"):
+        out = torch.full((n, k), float("nan"), device="cuda")
+        prev = H.k1_route(route)
+        try:
+            torch.cuda.synchronize()
+            H.check(H.lib.ccz_transform(H.raw, _backend.F32, C.c_void_p(X.data_ptr()), n, d, X.stride(0), C.c_void_p(mean.data_ptr()),
+                                        C.c_void_p(W.data_ptr()), k, C.c_void_p(out.data_ptr()), out.stride(0)))
+            H.sync()
+        finally:
+            H.k1_route(prev)
+        res[route] = float((out.double() - ref).norm() / ref.norm())
+        assert torch.isfinite(out).all()
+    assert res["auto"] < 5e-6 and res["bf16x2"] < 2e-5, res
+    assert res["bf16x2"] != res["auto"]                      # the opt-in route really ran
