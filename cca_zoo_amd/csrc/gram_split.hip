@@ -382,6 +382,9 @@ void gram_split_f32(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
     }
     c->last_split_ms = c->last_mfma_ms = c->last_reduce_ms = 0.0;
     size_t planes_cap = 0, partial_cap = 0;
+    bool launched = false;
+   retry_smaller:
+    try {
     for (int64_t r0 = 0; r0 < n; r0 += launch_rows) {
       const int64_t rows = std::min(launch_rows, n - r0);
       const int64_t ksteps = (rows + SP_K - 1) / SP_K;
@@ -415,6 +418,7 @@ void gram_split_f32(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
       const size_t partial_bytes = size_t(ksplit) * size_t(ntiles) * (SP_T * SP_T * 4);
       if (planes_bytes > planes_cap) { if (planes) dev_free(c, planes); planes = static_cast<char*>(dev_alloc(c, planes_bytes)); planes_cap = planes_bytes; }
       if (partial_bytes > partial_cap) { if (partial) dev_free(c, partial); partial = static_cast<float*>(dev_alloc(c, partial_bytes)); partial_cap = partial_bytes; }
+      launched = true;                     // (from here on the super-chunks are no larger than this one: no further allocation)
       zero(c, msq, size_t(D) * 8);
       if (time_it) CCZ_HIP(hipEventRecord(im->sp_ev[0], st));
       {
@@ -439,6 +443,16 @@ void gram_split_f32(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
         c->last_mfma_ms += b;
         c->last_reduce_ms += d;
       }
+    }
+    } catch (const Error& e) {
+      // the scratch did not fit (another library holds most of HBM): halve the row super-chunk and start over -- nothing has
+      // been enqueued yet when the FIRST super-chunk's buffers cannot be allocated
+      if (e.code != CCZ_ENOMEM || launched || launch_rows <= max_steps * SP_K) throw;
+      if (planes) { dev_free(c, planes); planes = nullptr; }
+      if (partial) { dev_free(c, partial); partial = nullptr; }
+      planes_cap = partial_cap = 0;
+      launch_rows = std::max<int64_t>(max_steps * SP_K, launch_rows / 2 / (max_steps * SP_K) * (max_steps * SP_K));
+      goto retry_smaller;
     }
   } catch (...) {
     release();

@@ -583,11 +583,15 @@ void pair_loss_backward_impl(ccz_ctx* c, int dtype, const ccz_view* z, int m, in
   // a backward that is a large product (the metric shape: n = 1e6, D = 8192) runs on the bf16 pipe with the split arithmetic of K1
   if (dtype == CCZ_F32 && m == 2 && all && c->k1_route != CCZ_K1_FP32 &&
       gemm_split_pair_eligible(n, D, D, sh.dims[0], sh.dims[0], z[0].data, z[0].ld, z[1].data, z[1].ld, g[0], ldg[0], g[1], ldg[1])) {
-    c->last_bwd_route = CCZ_K1_BF16X2;
-    gemm_split_pair(c, n, D, D, sh.dims[0], 1.0f, static_cast<const float*>(grad_out), static_cast<const float*>(z[0].data), z[0].ld,
-                    static_cast<const float*>(z[1].data), z[1].ld, g32, gamma, D, mean, static_cast<float*>(g[0]), ldg[0], static_cast<float*>(g[1]),
-                    ldg[1], sh.dims[0]);
-    return;
+    try {
+      c->last_bwd_route = CCZ_K1_BF16X2;
+      gemm_split_pair(c, n, D, D, sh.dims[0], 1.0f, static_cast<const float*>(grad_out), static_cast<const float*>(z[0].data), z[0].ld,
+                      static_cast<const float*>(z[1].data), z[1].ld, g32, gamma, D, mean, static_cast<float*>(g[0]), ldg[0], static_cast<float*>(g[1]),
+                      ldg[1], sh.dims[0]);
+      return;
+    } catch (const Error& e) {
+      if (e.code != CCZ_ENOMEM) throw;       // no room for the operand planes (what it enqueued so far only wrote scratch): the fp32 product below
+    }
   }
   c->last_bwd_route = dtype == CCZ_F32 ? CCZ_K1_FP32 : CCZ_K1_FP64;
   if (dtype == CCZ_F32 && m == 2 && all && narrow_ok(sh.dims, m) &&
