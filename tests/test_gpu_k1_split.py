@@ -265,3 +265,31 @@ def test_projection_on_the_split_arithmetic_is_opt_in_and_matches_float64(H, mon
         assert torch.isfinite(out).all()
     assert res["auto"] < 5e-6 and res["bf16x2"] < 2e-5, res
     assert res["bf16x2"] != res["auto"]                      # the opt-in route really ran
+
+
+def test_pool_trim_returns_the_split_routes_scratch(H):
+    """The planes and partial tiles of the split route stay pooled with the handle between fits; ``ccz_pool_trim`` hands every
+    unused block back to the driver (and the next launch simply allocates again)."""
+    views = _latent(40000, [512, 256], seed=9)
+    Gr, _ = _ref(views)
+    G, _, taken, _ = _moments(H, views, "bf16x2")
+    assert taken == "bf16x2"
+    freed = H.pool_trim()
+    assert freed >= 40000 * 768 * 4                              # at least the two planes of this launch
+    assert H.pool_trim() == 0
+    G2, _, _, _ = _moments(H, views, "bf16x2")
+    assert _rel(G2, Gr) < 2e-6
+
+
+def test_loss_reports_the_routes_it_took(H):
+    import torch
+
+    from cca_zoo_amd.deep.objectives import CCALoss
+
+    z1 = torch.randn(4096, 64, device="cuda", requires_grad=True)
+    z2 = torch.randn(4096, 64, device="cuda", requires_grad=True)
+    CCALoss(eps=1e-3)([z1, z2]).backward()
+    torch.cuda.synchronize()
+    fwd, bwd = H.loss_last_route()
+    assert bwd == "fp32"                                          # a small batch keeps the fp32 product (and the fast K1 path)
+    assert fwd in ("fp32", "none", "bf16x2")
