@@ -67,7 +67,8 @@ class rCCA(BaseModel):
             raise
         # wall-clock split of this fit (K1 incl. the all-reduce | the d x d solve incl. the copy of the weights to the host)
         self.timings_ = {"moments_ms": (t1 - t0) * 1e3, "allreduce_ms": _moments.LAST["allreduce_ms"],
-                         "solve_ms": (time.perf_counter() - t1) * 1e3}
+                         "solve_ms": (time.perf_counter() - t1) * 1e3,
+                         "k1_route": h.moments_last_route()[0]}
         del keep
         return self
 
