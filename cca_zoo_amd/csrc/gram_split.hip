@@ -60,20 +60,20 @@ struct SplitTile {
 
 // ---------------------------------------------------------------------------
 // split pass: fp32 rows [r0, r0 + nrows) of every view -> the two bf16 planes of this launch (k-steps [0, ksteps)),
-// and msq[j] += sum_k mid_kj^2.  grid = (row blocks of SP_RB rows, panels).  A thread owns 4 consecutive columns and, per
+// and msq[j] += sum_k mid_kj^2.  grid = (row blocks of rb <= SP_RB rows, panels).  A thread owns 4 consecutive columns and, per
 // pass, the 8 rows of one k half: its 8 float4 loads are one 1 KiB-per-wave row segment each, its stores 64 contiguous
 // bytes per plane.  HBM-bound: 4 bytes in, 4 bytes out per element.
 // ---------------------------------------------------------------------------
 template <bool ALIGNED>
 __global__ __launch_bounds__(256) void k_split_bf16x2(const SplitPanel* __restrict__ panels, int64_t r0, int64_t nrows, int64_t ksteps,
                                                       const float* __restrict__ pilot, char* __restrict__ planes,
-                                                      double* __restrict__ msq, double* __restrict__ csum) {
+                                                      double* __restrict__ msq, double* __restrict__ csum, int rb) {
   __shared__ float red[4][256];
   __shared__ double redc[4][256];
   const SplitPanel pn = panels[blockIdx.y];
   const int tid = threadIdx.x, cg = tid & 63, rg = tid >> 6;
   const int64_t rows_pad = ksteps * SP_K;
-  const int64_t rb0 = int64_t(blockIdx.x) * SP_RB;
+  const int64_t rb0 = int64_t(blockIdx.x) * rb;             // rb rows per workgroup (a multiple of 32, <= SP_RB)
   const int c0 = 4 * cg;
   sp_v4f32 p = {0.f, 0.f, 0.f, 0.f};
   bool cok[4];
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void k_split_bf16x2(const SplitPanel* __restri
   char* out = planes + int64_t(blockIdx.y) * ksteps * SP_PSTEP + (cg >> 3) * 1024 + (cg & 7) * 64;
   sp_v4f32 q = {0.f, 0.f, 0.f, 0.f};
   double cs[4] = {0.0, 0.0, 0.0, 0.0};               // exact column sums of x (not of x - p): the means, and the pilot fix-up's s
-  for (int pass = 0; pass < SP_RB / 32; ++pass) {
+  for (int pass = 0; pass < rb / 32; ++pass) {
     const int64_t row = rb0 + pass * 32 + rg * 8;          // first of this thread's 8 rows (within the launch)
     if (row >= rows_pad) break;
     sp_v4f32 v[8];
@@ -272,6 +272,14 @@ size_t split_scratch_budget(ccz_ctx* c) {
   return size_t(std::max(8.0 * 1048576.0, std::min(env_gb * 1073741824.0, cap)));
 }
 
+// rows per workgroup of the split pass: SP_RB on large inputs (fewer atomics), down to 32 so that short inputs (a DCCA batch,
+// the Gamma matrix of a backward) still spread over the chip
+static int split_rows_per_block(int64_t rows_pad, int64_t npanels, int ncu) {
+  int rb = SP_RB;
+  while (rb > 32 && ((rows_pad + rb - 1) / rb) * npanels < 2 * int64_t(ncu)) rb /= 2;
+  return rb;
+}
+
 // The K1-layout planes of ONE fp32 matrix X (rows x cols, ld): panels of 256 columns, `ksteps` k-steps of 16 rows each (rows past
 // `rows` are zero) -- the B side of gemm_split.hip's product (X = Gamma: its rows are the contraction index).  No pilot, no msq.
 void split_k1_layout(ccz_ctx* c, const float* X, int64_t rows, int64_t cols, int64_t ld, int64_t ksteps, char* planes) {
@@ -288,9 +296,10 @@ void split_k1_layout(ccz_ctx* c, const float* X, int64_t rows, int64_t cols, int
   SplitPanel* d_panels = static_cast<SplitPanel*>(dev_alloc(c, panels.size() * sizeof(SplitPanel)));
   try {
     h2d_small(c, d_panels, panels.data(), panels.size() * sizeof(SplitPanel));
-    const dim3 grid((unsigned)((ksteps * SP_K + SP_RB - 1) / SP_RB), (unsigned)panels.size());
-    if (aligned) hipLaunchKernelGGL(k_split_bf16x2<true>, grid, dim3(256), 0, stream(c), d_panels, int64_t(0), rows, ksteps, static_cast<const float*>(nullptr), planes, static_cast<double*>(nullptr), static_cast<double*>(nullptr));
-    else hipLaunchKernelGGL(k_split_bf16x2<false>, grid, dim3(256), 0, stream(c), d_panels, int64_t(0), rows, ksteps, static_cast<const float*>(nullptr), planes, static_cast<double*>(nullptr), static_cast<double*>(nullptr));
+    const int rb = split_rows_per_block(ksteps * SP_K, int64_t(panels.size()), std::max(1, impl(c)->props.multiProcessorCount));
+    const dim3 grid((unsigned)((ksteps * SP_K + rb - 1) / rb), (unsigned)panels.size());
+    if (aligned) hipLaunchKernelGGL(k_split_bf16x2<true>, grid, dim3(256), 0, stream(c), d_panels, int64_t(0), rows, ksteps, static_cast<const float*>(nullptr), planes, static_cast<double*>(nullptr), static_cast<double*>(nullptr), rb);
+    else hipLaunchKernelGGL(k_split_bf16x2<false>, grid, dim3(256), 0, stream(c), d_panels, int64_t(0), rows, ksteps, static_cast<const float*>(nullptr), planes, static_cast<double*>(nullptr), static_cast<double*>(nullptr), rb);
     CCZ_LAUNCH_CHECK();
   } catch (...) {
     dev_free(c, d_panels);
@@ -422,9 +431,10 @@ void gram_split_f32(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
       zero(c, msq, size_t(D) * 8);
       if (time_it) CCZ_HIP(hipEventRecord(im->sp_ev[0], st));
       {
-        const dim3 grid((unsigned)((ksteps * SP_K + SP_RB - 1) / SP_RB), (unsigned)np);
-        if (aligned) hipLaunchKernelGGL(k_split_bf16x2<true>, grid, dim3(256), 0, st, d_panels, r0, rows, ksteps, pilot, planes, msq, colsum);
-        else hipLaunchKernelGGL(k_split_bf16x2<false>, grid, dim3(256), 0, st, d_panels, r0, rows, ksteps, pilot, planes, msq, colsum);
+        const int rb = split_rows_per_block(ksteps * SP_K, np, ncu);
+        const dim3 grid((unsigned)((ksteps * SP_K + rb - 1) / rb), (unsigned)np);
+        if (aligned) hipLaunchKernelGGL(k_split_bf16x2<true>, grid, dim3(256), 0, st, d_panels, r0, rows, ksteps, pilot, planes, msq, colsum, rb);
+        else hipLaunchKernelGGL(k_split_bf16x2<false>, grid, dim3(256), 0, st, d_panels, r0, rows, ksteps, pilot, planes, msq, colsum, rb);
       }
       if (time_it) CCZ_HIP(hipEventRecord(im->sp_ev[1], st));
       hipLaunchKernelGGL(k_gram_bf16x2, dim3((unsigned)nblocks), dim3(256), fifo_bytes, st, d_tiles, ntiles, per_xcd, ksplit, planes, ksteps,
