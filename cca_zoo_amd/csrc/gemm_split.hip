@@ -10,7 +10,7 @@
 // the hi / mid split in registers, a transpose through an XOR-swizzled LDS image, 4 KiB linear runs out).  The B side is
 // Gamma (rounded to fp32 by the forward) in the K1 layout: its rows are the contraction index, so gram_split.hip's own split
 // pass serves as it is.  The exact centring is finished on the d side:  sum_k (mean_k - p_k) Gamma_kn  is subtracted in the
-// epilogue (a D-vector formed in fp64).
+// epilogue (a D-vector formed in fp64 by the forward, next to the centring row).
 //
 // Kernel: k_gemm_bf16x2_nn = split_mma_core over all of K for one (256 samples x 256 outputs) tile; tiles are walked in
 // 4 x 8 supertiles per XCD (12 operand streams per 32 workgroups through that XCD's L2), sample-tile groups dealt round-robin
@@ -89,25 +89,6 @@ __global__ __launch_bounds__(256) void k_splitT_bf16x2(SplitTViews vw, int64_t r
     const int phys = (L & ~(31 << 4)) | ((r32 ^ ((sl * 2 + hh) & 7)) << 4);
     *reinterpret_cast<sp_v4u32*>(out + L) = *reinterpret_cast<const sp_v4u32*>(img + phys);
   }
-}
-
-// corr[n] += sum_k (mean_k - fl32(mean_k)) Gamma[k][n]: what the pilot-shifted A side still owes the exact centring.
-// grid = (column blocks of 256, row slabs of 64): the K rows are spread over the chip (a thread per column walking all K
-// rows alone was 8192 dependent loads long); corr is zeroed by the caller.
-__global__ __launch_bounds__(256) void k_pilot_corr(const double* __restrict__ mean, const double* __restrict__ gamma, int64_t K, int64_t N,
-                                                    int64_t ldg, double* __restrict__ corr) {
-  const int64_t n = int64_t(blockIdx.x) * 256 + threadIdx.x;
-  if (n >= N) return;
-  const int64_t k0 = int64_t(blockIdx.y) * 64, k1 = min(K, k0 + 64);
-  double a0 = 0.0, a1 = 0.0;
-  int64_t k = k0;
-  for (; k + 1 < k1; k += 2) {
-    const double m0 = mean[k], m1 = mean[k + 1];
-    a0 += (m0 - double(float(m0))) * gamma[k * ldg + n];
-    a1 += (m1 - double(float(m1))) * gamma[(k + 1) * ldg + n];
-  }
-  if (k < k1) { const double m0 = mean[k]; a0 += (m0 - double(float(m0))) * gamma[k * ldg + n]; }
-  unsafeAtomicAdd(corr + n, a0 + a1);
 }
 
 // ---------------------------------------------------------------------------
@@ -203,10 +184,11 @@ bool gemm_split_pair_eligible(int64_t M, int64_t N, int64_t K, int64_t K1, int64
   return true;
 }
 
-// [C1 | C2] (M x N, split at column nsplit) = alpha (*alpha_dev) ([A1 | A2] - 1 mean') B  with B = gamma32 (K x N fp32, ld N; gamma64 the
-// same matrix in float64, ld ldg, for the centring correction); mean: K column means (float64, device)
+// [C1 | C2] (M x N, split at column nsplit) = alpha (*alpha_dev) ([A1 | A2] - 1 mean') B  with B = gamma32 (K x N fp32, ld N);
+// mean: K column means (float64, device: the A side is shifted by fl32(mean)); corr: N doubles, (mean - fl32(mean))' B, formed by
+// the forward next to the centring row (loss.hip: k_loss_tail)
 void gemm_split_pair(ccz_ctx* c, int64_t M, int64_t N, int64_t K, int64_t K1, float alpha, const float* alpha_dev, const float* A1, int64_t lda1,
-                     const float* A2, int64_t lda2, const float* gamma32, const double* gamma64, int64_t ldg, const double* mean, float* C1,
+                     const float* A2, int64_t lda2, const float* gamma32, const double* corr, const double* mean, float* C1,
                      int64_t ldc1, float* C2, int64_t ldc2, int64_t nsplit) {
   hipStream_t st = stream(c);
   const int64_t S = (K + 63) / 64 * 4;                      // k-steps of 16, whole 64-column blocks of the transposing pass
@@ -220,16 +202,12 @@ void gemm_split_pair(ccz_ctx* c, int64_t M, int64_t N, int64_t K, int64_t K1, fl
   tiles_per_launch = std::min(tiles_per_launch, (row_tiles_all + 31) / 32 * 32);
   char* planesB = static_cast<char*>(dev_alloc(c, bytesB));
   char* planesA = nullptr;
-  double* corr = static_cast<double*>(dev_alloc(c, size_t(N) * 8));
   auto release = [&] {
     if (planesA) dev_free(c, planesA);
-    dev_free(c, corr);
     dev_free(c, planesB);
   };
   try {
     split_k1_layout(c, gamma32, K, N, N, S, planesB);
-    zero(c, corr, size_t(N) * 8);
-    hipLaunchKernelGGL(k_pilot_corr, dim3((unsigned)((N + 255) / 256), (unsigned)((K + 63) / 64)), dim3(256), 0, st, mean, gamma64, K, N, ldg, corr);
     planesA = static_cast<char*>(dev_alloc(c, size_t(std::min(tiles_per_launch, row_tiles_all)) * per_tile));
     SplitTViews vw{};
     vw.m = 2;

@@ -852,8 +852,11 @@ struct ColsumViews {
 };
 
 __global__ __launch_bounds__(256) void k_colsum_pilot(ColsumViews cv, int64_t n, int64_t D, int64_t rows_per_block, double* __restrict__ part,
-                                                      unsigned* __restrict__ counters, double* __restrict__ sums, float* __restrict__ pilot) {
+                                                      unsigned* __restrict__ counters, double* __restrict__ sums, float* __restrict__ pilot,
+                                                      double* __restrict__ zero_me, int64_t nzero) {
   __shared__ int last;
+  if (zero_me && blockIdx.y == 0)                      // a rider: clear an accumulation target of the NEXT kernel (the split pass's msq)
+    for (int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x; e < nzero; e += int64_t(gridDim.x) * 256) zero_me[e] = 0.0;
   const int64_t j = int64_t(blockIdx.x) * 256 + threadIdx.x;
   const int64_t r0 = int64_t(blockIdx.y) * rows_per_block;
   const int64_t r1 = min(n, r0 + rows_per_block);
@@ -1197,7 +1200,7 @@ bool launch_moments(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
       return 0;
     }();
     const int route = c->k1_route != CCZ_K1_AUTO ? c->k1_route : route_env;
-    split = route == CCZ_K1_BF16X2 || (route == CCZ_K1_AUTO && gram_split_worthwhile(n, D));
+    split = (route == CCZ_K1_BF16X2 || (route == CCZ_K1_AUTO && gram_split_worthwhile(n, D))) && n_views <= 16;
     if (split) pilot_mode = 2;
   }
   c->last_route = !is32 ? CCZ_K1_FP64 : (split ? CCZ_K1_BF16X2 : CCZ_K1_FP32);
@@ -1403,6 +1406,43 @@ void pack_rows(char* dst, const ccz_view* views, int n_views, size_t es, int64_t
 
 }  // namespace
 
+bool colsum_pilot_f32(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, int64_t D, double* colsum, float* pilot, double* zero_me,
+                      int64_t nzero) {
+  Impl* im = impl(c);
+  hipStream_t st = stream(c);
+  if (n_views < 1 || n_views > 8) return false;
+  const int ncu = std::max(1, im->props.multiProcessorCount);
+  const int64_t colblocks = (D + 255) / 256;
+  if (colblocks > 64) return false;
+  int64_t rpb = 2048;
+  while (rpb > 32 && colblocks * ((n + rpb - 1) / rpb) < int64_t(ncu)) rpb /= 2;
+  const int64_t rowblocks = (n + rpb - 1) / rpb;
+  // arrival counters of k_colsum_pilot: one block of 64 words per STREAM (like the chain kernel's sync block): two losses on
+  // one handle enqueued on different streams may overlap, and shared counters would elect the wrong "last row block"
+  unsigned* counters = nullptr;
+  for (auto& e : im->colsum_sync)
+    if (e.first == static_cast<void*>(st)) { counters = static_cast<unsigned*>(e.second); break; }
+  if (!counters) {
+    if (im->colsum_sync.size() >= 32) return false;         // (a caller cycling through streams: the general route)
+    CCZ_HIP(hipMalloc(reinterpret_cast<void**>(&counters), 64 * sizeof(unsigned)));
+    CCZ_HIP(hipMemsetAsync(counters, 0, 64 * sizeof(unsigned), st));
+    im->colsum_sync.emplace_back(static_cast<void*>(st), static_cast<void*>(counters));
+  }
+  double* part = static_cast<double*>(dev_alloc(c, size_t(rowblocks) * D * 8));
+  ColsumViews cv{};
+  cv.m = n_views;
+  cv.off[0] = 0;
+  for (int v = 0; v < n_views; ++v) {
+    cv.data[v] = static_cast<const float*>(views[v].data);
+    cv.ld[v] = views[v].ld;
+    cv.off[v + 1] = cv.off[v] + int(views[v].cols);
+  }
+  hipLaunchKernelGGL(k_colsum_pilot, dim3((unsigned)colblocks, (unsigned)rowblocks), dim3(256), 0, st, cv, n, D, rpb, part, counters, colsum, pilot,
+                     zero_me, nzero);
+  dev_free(c, part);                    // stream-ordered pool: reused only behind the kernel above
+  return true;
+}
+
 // Loss fast path: the pilot-shifted batch Gram of a DCCA batch as per-(row chunk, tile) fp32 partial sums + the exact column
 // sums, in TWO launches (k_colsum_pilot, k_gram_f32 on the views where they lie: no gathered copy, no atomics, no fills,
 // no read-back).  The consumer (loss.hip: k_loss_prep_partials) adds the chunks up in fp64 and undoes the shift.
@@ -1414,6 +1454,7 @@ bool gram_partials_f32(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n
   if (n_views < 1 || n_views > 8 || n < 2) return false;
   int64_t D = 0;
   for (int v = 0; v < n_views; ++v) D += views[v].cols;
+  if (gram_partials_split_f32(c, views, n_views, n, out)) return true;      // DCCA batches from 4096 rows on: the split route
   const TileTable tt = build_tile_table<float>(c, views, n_views, nullptr);
   const RowPlan rp = plan_rows<float>(c, views, n_views, n, tt.ntiles, tt.fast);
   static const int64_t partial_cap = [] { const char* e = getenv("CCZ_GRAM_PARTIAL_MB"); return (e ? atoll(e) : 192LL) << 20; }();
@@ -1474,37 +1515,15 @@ bool gram_partials_f32(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n
     }
   }
   // column sums + pilot
-  const int64_t colblocks = (D + 255) / 256;
-  if (colblocks > 64) return false;
-  int64_t rpb = 2048;
-  while (rpb > 32 && colblocks * ((n + rpb - 1) / rpb) < int64_t(ncu)) rpb /= 2;
-  const int64_t rowblocks = (n + rpb - 1) / rpb;
-  // arrival counters of k_colsum_pilot: one block of 64 words per STREAM (like the chain kernel's sync block): two losses on
-  // one handle enqueued on different streams may overlap, and shared counters would elect the wrong "last row block"
-  unsigned* counters = nullptr;
-  for (auto& e : im->colsum_sync)
-    if (e.first == static_cast<void*>(st)) { counters = static_cast<unsigned*>(e.second); break; }
-  if (!counters) {
-    if (im->colsum_sync.size() >= 32) return false;         // (a caller cycling through streams: the general route)
-    CCZ_HIP(hipMalloc(reinterpret_cast<void**>(&counters), 64 * sizeof(unsigned)));
-    CCZ_HIP(hipMemsetAsync(counters, 0, 64 * sizeof(unsigned), st));
-    im->colsum_sync.emplace_back(static_cast<void*>(st), static_cast<void*>(counters));
-  }
+  if ((D + 255) / 256 > 64) return false;
   out->colsum = static_cast<double*>(dev_alloc(c, size_t(D) * 8));
   out->pilot = static_cast<float*>(dev_alloc(c, size_t(D) * 4));
   out->partial = static_cast<float*>(dev_alloc(c, size_t(bytes)));
   out->tile_plan = fifo_plan_ok ? fifo_plan_dev : nullptr;   // owned by the handle
-  double* part = static_cast<double*>(dev_alloc(c, size_t(rowblocks) * D * 8));
-  ColsumViews cv{};
-  cv.m = n_views;
-  cv.off[0] = 0;
-  for (int v = 0; v < n_views; ++v) {
-    cv.data[v] = static_cast<const float*>(views[v].data);
-    cv.ld[v] = views[v].ld;
-    cv.off[v + 1] = cv.off[v] + int(views[v].cols);
+  if (!colsum_pilot_f32(c, views, n_views, n, D, out->colsum, out->pilot, nullptr, 0)) {
+    gram_partials_release(c, out);
+    return false;
   }
-  hipLaunchKernelGGL(k_colsum_pilot, dim3((unsigned)colblocks, (unsigned)rowblocks), dim3(256), 0, st, cv, n, D, rpb, part, counters,
-                     out->colsum, out->pilot);
   const size_t lds_bytes = size_t(2) * 2 * BK * T32 * sizeof(float);
   if (fifo_plan_ok) {
     const size_t fifo_bytes = size_t(4) * FR * FSLOT;
@@ -1521,7 +1540,6 @@ bool gram_partials_f32(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n
                        static_cast<double*>(nullptr), D, out->pilot, out->partial, int64_t(0));
   }
   CCZ_LAUNCH_CHECK();
-  dev_free(c, part);                    // stream-ordered pool: reused only behind the kernels above
   out->tiles = tt.dev;
   out->ntiles = tt.ntiles;
   out->ksplit = rp.ksplit;
@@ -1530,6 +1548,9 @@ bool gram_partials_f32(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n
 }
 
 void gram_partials_release(ccz_ctx* c, GramPartials* gp) {
+  if (gp->planes) dev_free(c, gp->planes);
+  if (gp->msq) dev_free(c, const_cast<double*>(gp->msq));
+  gp->planes = nullptr; gp->msq = nullptr;
   if (gp->partial) dev_free(c, gp->partial);
   if (gp->pilot) dev_free(c, gp->pilot);
   if (gp->colsum) dev_free(c, gp->colsum);

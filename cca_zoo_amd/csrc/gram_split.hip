@@ -43,11 +43,18 @@
 
 namespace ccz {
 
+constexpr int SP_MAXV = 16;          // views per launch (their base pointers travel as a kernel argument, the tables hold no pointers)
+
 struct SplitPanel {
-  const float* base;     // first column of the panel in its view, row 0 of the view
-  int64_t ld;
+  int32_t view;          // which view
+  int32_t col0;          // first column of the panel in its view
   int32_t width;         // valid columns (<= 256); the rest of the panel is zero
   int32_t gcol0;         // column of G (and of pilot / msq) of the panel's first column
+};
+
+struct SplitViews {
+  const float* data[SP_MAXV];
+  int64_t ld[SP_MAXV];
 };
 
 struct SplitTile {
@@ -65,7 +72,7 @@ struct SplitTile {
 // bytes per plane.  HBM-bound: 4 bytes in, 4 bytes out per element.
 // ---------------------------------------------------------------------------
 template <bool ALIGNED>
-__global__ __launch_bounds__(256) void k_split_bf16x2(const SplitPanel* __restrict__ panels, int64_t r0, int64_t nrows, int64_t ksteps,
+__global__ __launch_bounds__(256) void k_split_bf16x2(const SplitPanel* __restrict__ panels, SplitViews vws, int64_t r0, int64_t nrows, int64_t ksteps,
                                                       const float* __restrict__ pilot, char* __restrict__ planes,
                                                       double* __restrict__ msq, double* __restrict__ csum, int rb) {
   __shared__ float red[4][256];
@@ -82,7 +89,8 @@ __global__ __launch_bounds__(256) void k_split_bf16x2(const SplitPanel* __restri
     cok[e] = c0 + e < pn.width;
     if (pilot && cok[e]) p[e] = pilot[pn.gcol0 + c0 + e];
   }
-  const float* __restrict__ X = pn.base + c0;
+  const float* __restrict__ X = vws.data[pn.view] + pn.col0 + c0;
+  const int64_t pld = vws.ld[pn.view];
   char* out = planes + int64_t(blockIdx.y) * ksteps * SP_PSTEP + (cg >> 3) * 1024 + (cg & 7) * 64;
   sp_v4f32 q = {0.f, 0.f, 0.f, 0.f};
   double cs[4] = {0.0, 0.0, 0.0, 0.0};               // exact column sums of x (not of x - p): the means, and the pilot fix-up's s
@@ -93,7 +101,7 @@ __global__ __launch_bounds__(256) void k_split_bf16x2(const SplitPanel* __restri
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const bool rok = row + k < nrows;
-      const float* src = X + (r0 + (rok ? row + k : 0)) * pn.ld;
+      const float* src = X + (r0 + (rok ? row + k : 0)) * pld;
       if (ALIGNED) {
         v[k] = p;                                          // (whole 4-column groups are inside or outside the panel's width)
         if (cok[0]) v[k] = *reinterpret_cast<const sp_v4f32*>(src);
@@ -280,32 +288,183 @@ static int split_rows_per_block(int64_t rows_pad, int64_t npanels, int ncu) {
   return rb;
 }
 
+// Panel and tile tables of a set of view widths, on the device, kept with the handle: they depend on the widths only (the
+// views' pointers and strides travel as a kernel argument), so a training loop or a fit loop uploads them once.
+struct SplitTables {
+  const SplitPanel* panels;
+  const SplitTile* tiles;
+  const GramTile* gtiles;      // the same tiles for loss.hip's preparation kernel (out_row / out_col / wa / wb / diag; a, b unused)
+  int np, ntiles;
+  std::vector<int32_t> panel_width;    // host copies the planners need
+};
+
+static SplitTables split_tables(ccz_ctx* c, const int64_t* cols, int n_views) {
+  Impl* im = impl(c);
+  uint64_t key = 1469598103934665603ull;
+  auto mix = [&](uint64_t v) { key ^= v; key *= 1099511628211ull; };
+  mix(uint64_t(n_views));
+  for (int v = 0; v < n_views; ++v) mix(uint64_t(cols[v]));
+  std::vector<SplitPanel> panels;
+  int64_t g0 = 0;
+  for (int v = 0; v < n_views; ++v) {
+    for (int64_t c0 = 0; c0 < cols[v]; c0 += SP_T)
+      panels.push_back(SplitPanel{int32_t(v), int32_t(c0), int32_t(std::min<int64_t>(SP_T, cols[v] - c0)), int32_t(g0 + c0)});
+    g0 += cols[v];
+  }
+  SplitTables tb;
+  tb.np = int(panels.size());
+  for (const auto& p : panels) tb.panel_width.push_back(p.width);
+  for (auto& e : im->split_tabs)
+    if (e.key == key && e.np == tb.np) {
+      tb.panels = static_cast<const SplitPanel*>(e.panels);
+      tb.tiles = static_cast<const SplitTile*>(e.tiles);
+      tb.gtiles = static_cast<const GramTile*>(e.gtiles);
+      tb.ntiles = e.ntiles;
+      return tb;
+    }
+  std::vector<SplitTile> tiles;
+  std::vector<GramTile> gt;
+  for (const auto& ij : split_tile_order(tb.np)) {
+    SplitTile t;
+    t.pa = ij.first; t.pb = ij.second;
+    t.out_row = panels[ij.first].gcol0; t.out_col = panels[ij.second].gcol0;
+    t.wa = panels[ij.first].width; t.wb = panels[ij.second].width;
+    t.diag = ij.first == ij.second ? 1 : 0;
+    t.pad_ = 0;
+    tiles.push_back(t);
+    GramTile g{};
+    g.a = nullptr; g.b = nullptr; g.lda = 0; g.ldb = 0;
+    g.out_row = t.out_row; g.out_col = t.out_col; g.wa = t.wa; g.wb = t.wb; g.diag = t.diag; g.pad_ = 0;
+    gt.push_back(g);
+  }
+  tb.ntiles = int(tiles.size());
+  if (im->split_tabs.size() >= 32) {                      // a caller cycling through many shapes: start over
+    CCZ_HIP(hipStreamSynchronize(stream(c)));
+    for (auto& e : im->split_tabs) { (void)hipFree(e.panels); (void)hipFree(e.tiles); (void)hipFree(e.gtiles); }
+    im->split_tabs.clear();
+  }
+  void *dp = nullptr, *dt = nullptr, *dg = nullptr;
+  CCZ_HIP(hipMalloc(&dp, std::max<size_t>(panels.size() * sizeof(SplitPanel), 256)));
+  CCZ_HIP(hipMalloc(&dt, std::max<size_t>(tiles.size() * sizeof(SplitTile), 256)));
+  CCZ_HIP(hipMalloc(&dg, std::max<size_t>(gt.size() * sizeof(GramTile), 256)));
+  h2d_small(c, dp, panels.data(), panels.size() * sizeof(SplitPanel));
+  h2d_small(c, dt, tiles.data(), tiles.size() * sizeof(SplitTile));
+  h2d_small(c, dg, gt.data(), gt.size() * sizeof(GramTile));
+  im->split_tabs.push_back({key, dp, dt, dg, tb.np, tb.ntiles});
+  tb.panels = static_cast<const SplitPanel*>(dp);
+  tb.tiles = static_cast<const SplitTile*>(dt);
+  tb.gtiles = static_cast<const GramTile*>(dg);
+  return tb;
+}
+
+static bool split_views_arg(const ccz_view* views, int n_views, SplitViews* vws) {
+  bool aligned = true;
+  for (int v = 0; v < n_views; ++v) {
+    vws->data[v] = static_cast<const float*>(views[v].data);
+    vws->ld[v] = views[v].ld;
+    if (views[v].cols % 4 != 0 || views[v].ld % 4 != 0 || reinterpret_cast<uintptr_t>(views[v].data) % 16 != 0) aligned = false;
+  }
+  return aligned;
+}
+
+static void launch_split_pass(ccz_ctx* c, const SplitTables& tb, const SplitViews& vws, bool aligned, int64_t r0, int64_t rows, int64_t ksteps,
+                              const float* pilot, char* planes, double* msq, double* colsum) {
+  const int rb = split_rows_per_block(ksteps * SP_K, tb.np, std::max(1, impl(c)->props.multiProcessorCount));
+  const dim3 grid((unsigned)((ksteps * SP_K + rb - 1) / rb), (unsigned)tb.np);
+  if (aligned) hipLaunchKernelGGL(k_split_bf16x2<true>, grid, dim3(256), 0, stream(c), tb.panels, vws, r0, rows, ksteps, pilot, planes, msq, colsum, rb);
+  else hipLaunchKernelGGL(k_split_bf16x2<false>, grid, dim3(256), 0, stream(c), tb.panels, vws, r0, rows, ksteps, pilot, planes, msq, colsum, rb);
+}
+
 // The K1-layout planes of ONE fp32 matrix X (rows x cols, ld): panels of 256 columns, `ksteps` k-steps of 16 rows each (rows past
 // `rows` are zero) -- the B side of gemm_split.hip's product (X = Gamma: its rows are the contraction index).  No pilot, no msq.
 void split_k1_layout(ccz_ctx* c, const float* X, int64_t rows, int64_t cols, int64_t ld, int64_t ksteps, char* planes) {
-  std::vector<SplitPanel> panels;
-  for (int64_t c0 = 0; c0 < cols; c0 += SP_T) {
-    SplitPanel p;
-    p.base = X + c0;
-    p.ld = ld;
-    p.width = int32_t(std::min<int64_t>(SP_T, cols - c0));
-    p.gcol0 = int32_t(c0);
-    panels.push_back(p);
+  const SplitTables tb = split_tables(c, &cols, 1);
+  const ccz_view v{X, cols, ld};
+  SplitViews vws{};
+  const bool aligned = split_views_arg(&v, 1, &vws);
+  launch_split_pass(c, tb, vws, aligned, 0, rows, ksteps, nullptr, planes, nullptr, nullptr);
+  CCZ_LAUNCH_CHECK();
+}
+
+// row chunk per workgroup of the Gram kernel over `ksteps` k-steps: minimise rounds x (steps + fixed cost) like gram.hip::plan_rows;
+// whole multiples of 8 chunks on a chip-filling grid select the chunk-per-XCD walk
+struct SplitRowPlan { int64_t steps_per_wg, ksplit, nblocks; int per_xcd; };
+static SplitRowPlan split_row_plan(int64_t ksteps, int ntiles, int64_t max_steps, int ncu) {
+  int64_t best_k = 1;
+  const int64_t kmin = std::max<int64_t>(1, (ksteps + max_steps - 1) / max_steps);
+  const int64_t kmax = std::max<int64_t>(kmin, std::min<int64_t>(ksteps / 16, 8192));
+  double best = 1e300;
+  for (int64_t ks = kmin; ks <= kmax; ++ks) {
+    const int64_t steps = (ksteps + ks - 1) / ks;
+    const bool big = int64_t(ntiles) * ks >= 16 * int64_t(ncu);
+    int64_t rounds;
+    if (big && ks % 8 == 0) rounds = ((ks / 8) * int64_t(ntiles) + ncu / 8 - 1) / (ncu / 8);
+    else if (big) rounds = (int64_t((ntiles + 7) / 8) * ks + ncu / 8 - 1) / (ncu / 8);
+    else rounds = (int64_t(ntiles) * ks + ncu - 1) / ncu;
+    const double cost = (big && ks % 8 != 0 ? 1.03 : 1.0) * double(rounds) * double(steps + 24);
+    if (cost < best) { best = cost; best_k = ks; }
   }
-  const bool aligned = cols % 4 == 0 && ld % 4 == 0 && reinterpret_cast<uintptr_t>(X) % 16 == 0;
-  SplitPanel* d_panels = static_cast<SplitPanel*>(dev_alloc(c, panels.size() * sizeof(SplitPanel)));
-  try {
-    h2d_small(c, d_panels, panels.data(), panels.size() * sizeof(SplitPanel));
-    const int rb = split_rows_per_block(ksteps * SP_K, int64_t(panels.size()), std::max(1, impl(c)->props.multiProcessorCount));
-    const dim3 grid((unsigned)((ksteps * SP_K + rb - 1) / rb), (unsigned)panels.size());
-    if (aligned) hipLaunchKernelGGL(k_split_bf16x2<true>, grid, dim3(256), 0, stream(c), d_panels, int64_t(0), rows, ksteps, static_cast<const float*>(nullptr), planes, static_cast<double*>(nullptr), static_cast<double*>(nullptr), rb);
-    else hipLaunchKernelGGL(k_split_bf16x2<false>, grid, dim3(256), 0, stream(c), d_panels, int64_t(0), rows, ksteps, static_cast<const float*>(nullptr), planes, static_cast<double*>(nullptr), static_cast<double*>(nullptr), rb);
-    CCZ_LAUNCH_CHECK();
-  } catch (...) {
-    dev_free(c, d_panels);
-    throw;
+  SplitRowPlan rp;
+  rp.steps_per_wg = (ksteps + best_k - 1) / best_k;
+  rp.ksplit = (ksteps + rp.steps_per_wg - 1) / rp.steps_per_wg;
+  const bool sliced = int64_t(ntiles) * rp.ksplit >= 16 * int64_t(ncu);
+  const bool xchunks = sliced && rp.ksplit % 8 == 0;
+  rp.per_xcd = xchunks ? -1 : (sliced ? (ntiles + 7) / 8 : 0);
+  rp.nblocks = xchunks ? int64_t(ntiles) * rp.ksplit : (sliced ? int64_t(8) * rp.per_xcd * rp.ksplit : int64_t(ntiles) * rp.ksplit);
+  if (rp.nblocks > 0x7fffffffLL) fail(CCZ_EUNSUP, "gram (split route): grid too large");
+  if ((rp.steps_per_wg + SP_NST) * SP_PSTEP > 0x7fffffffLL) fail(CCZ_EUNSUP, "gram (split route): row chunk too long");
+  return rp;
+}
+
+// Loss fast path on the split route (loss.hip: pair_core -> k_loss_prep_partials): the pilot-shifted Gram of a DCCA batch as per-(row
+// chunk, tile) fp32 partial tiles -- the layout of gram.hip's staged kernel (slot = chunk * ntiles + tile, full tiles, no plan) --
+// plus the exact column sums, the pilot and sum mid^2 for the diagonal.  Three launches: k_colsum_pilot (which also clears msq),
+// the split pass, the MFMA kernel; nothing is reduced here (the consumer adds the chunks up in fp64 while it forms Ce).
+// From 4096 rows on: a batch's second moments then agree with their float64 values to ~4e-7 (8192 rows: 3.5e-7 against the
+// fp32 kernel's 2.2e-7) -- the reference forms them by a float32 matmul and inverts them through a float32 eigh
+// (cca_zoo/deep/objectives.py:9-21, :86-97), both an order of magnitude looser.  CCZ_LOSS_K1_SPLIT=0 keeps the fp32 kernels.
+bool gram_partials_split_f32(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, GramPartials* out) {
+  const char* e_on = getenv("CCZ_LOSS_K1_SPLIT");
+  if ((e_on && atoi(e_on) == 0) || c->k1_route == CCZ_K1_FP32) return false;
+  if (n_views < 1 || n_views > 8 || n < 4096) return false;
+  int64_t D = 0;
+  std::vector<int64_t> cols(n_views);
+  for (int v = 0; v < n_views; ++v) { cols[v] = views[v].cols; D += views[v].cols; }
+  if (D < 512 || (D + 255) / 256 > 64 || double(n) * double(D) * double(D + 1) < 5e9) return false;
+  Impl* im = impl(c);
+  hipStream_t st = stream(c);
+  const int ncu = std::max(1, im->props.multiProcessorCount);
+  const SplitTables tb = split_tables(c, cols.data(), n_views);
+  const int64_t ksteps = (n + SP_K - 1) / SP_K;
+  const SplitRowPlan rp = split_row_plan(ksteps, tb.ntiles, 16384 / SP_K, ncu);
+  static const int64_t partial_cap = [] { const char* e = getenv("CCZ_GRAM_PARTIAL_MB"); return (e ? atoll(e) : 192LL) << 20; }();
+  const int64_t partial_bytes = rp.ksplit * int64_t(tb.ntiles) * (SP_T * SP_T * 4);
+  if (rp.per_xcd != 0 || partial_bytes > partial_cap) return false;           // a chip-filling grid: the general route through ccz_moments
+  SplitViews vws{};
+  const bool aligned = split_views_arg(views, n_views, &vws);
+  double* msq = static_cast<double*>(dev_alloc(c, size_t(D) * 8));
+  out->msq = msq;
+  out->colsum = static_cast<double*>(dev_alloc(c, size_t(D) * 8));
+  out->pilot = static_cast<float*>(dev_alloc(c, size_t(D) * 4));
+  out->partial = static_cast<float*>(dev_alloc(c, size_t(partial_bytes)));
+  out->planes = static_cast<char*>(dev_alloc(c, size_t(tb.np) * size_t(ksteps) * SP_PSTEP));
+  out->tile_plan = nullptr;
+  if (!colsum_pilot_f32(c, views, n_views, n, D, out->colsum, out->pilot, msq, D)) {
+    gram_partials_release(c, out);
+    return false;
   }
-  dev_free(c, d_panels);
+  launch_split_pass(c, tb, vws, aligned, 0, n, ksteps, out->pilot, out->planes, msq, nullptr);
+  const size_t fifo_bytes = size_t(SP_NST) * SP_STAGE;
+  CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_bf16x2), hipFuncAttributeMaxDynamicSharedMemorySize, int(fifo_bytes)));
+  hipLaunchKernelGGL(k_gram_bf16x2, dim3((unsigned)rp.nblocks), dim3(256), fifo_bytes, st, tb.tiles, tb.ntiles, rp.per_xcd, rp.ksplit, out->planes, ksteps,
+                     rp.steps_per_wg, out->partial);
+  CCZ_LAUNCH_CHECK();
+  out->tiles = tb.gtiles;
+  out->ntiles = tb.ntiles;
+  out->ksplit = rp.ksplit;
+  c->last_pilot = 1;
+  c->last_route = CCZ_K1_BF16X2;
+  return true;
 }
 
 // Does the split route pay for this launch?  (auto mode)  It carries an HBM pass over the rows, a reduce over the partial
@@ -327,38 +486,16 @@ void gram_split_f32(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
                     bool time_it) {
   Impl* im = impl(c);
   hipStream_t st = stream(c);
-  // ---- panels and tiles ----
-  std::vector<SplitPanel> panels;
-  bool aligned = true;
-  int64_t g0 = 0;
-  for (int v = 0; v < n_views; ++v) {
-    const float* base = static_cast<const float*>(views[v].data);
-    for (int64_t c0 = 0; c0 < views[v].cols; c0 += SP_T) {
-      SplitPanel p;
-      p.base = base + c0;
-      p.ld = views[v].ld;
-      p.width = int32_t(std::min<int64_t>(SP_T, views[v].cols - c0));
-      p.gcol0 = int32_t(g0 + c0);
-      panels.push_back(p);
-    }
-    if (views[v].cols % 4 != 0 || views[v].ld % 4 != 0 || reinterpret_cast<uintptr_t>(base) % 16 != 0) aligned = false;
-    g0 += views[v].cols;
-  }
-  const int np = int(panels.size());
+  // ---- panels and tiles (device tables cached with the handle by the views' widths) ----
+  if (n_views > SP_MAXV) fail(CCZ_EUNSUP, "gram (split route): more than %d views", SP_MAXV);
   if (D > 0x7fffffffLL - 256) fail(CCZ_EUNSUP, "gram (split route): stacked width too large");
-  std::vector<SplitTile> tiles;
-  for (const auto& ij : split_tile_order(np)) {
-    SplitTile t;
-    t.pa = ij.first; t.pb = ij.second;
-    t.out_row = panels[ij.first].gcol0; t.out_col = panels[ij.second].gcol0;
-    t.wa = panels[ij.first].width; t.wb = panels[ij.second].width;
-    t.diag = ij.first == ij.second ? 1 : 0;
-    t.pad_ = 0;
-    tiles.push_back(t);
-  }
-  const int ntiles = int(tiles.size());
-  SplitPanel* d_panels = static_cast<SplitPanel*>(dev_alloc(c, panels.size() * sizeof(SplitPanel)));
-  SplitTile* d_tiles = static_cast<SplitTile*>(dev_alloc(c, tiles.size() * sizeof(SplitTile)));
+  std::vector<int64_t> cols(n_views);
+  for (int v = 0; v < n_views; ++v) cols[v] = views[v].cols;
+  const SplitTables tb = split_tables(c, cols.data(), n_views);
+  SplitViews vws{};
+  const bool aligned = split_views_arg(views, n_views, &vws);
+  const int np = tb.np, ntiles = tb.ntiles;
+  const SplitTile* d_tiles = tb.tiles;
   double* msq = static_cast<double*>(dev_alloc(c, size_t(D) * 8));
   char* planes = nullptr;
   float* partial = nullptr;
@@ -366,13 +503,8 @@ void gram_split_f32(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
     if (partial) dev_free(c, partial);
     if (planes) dev_free(c, planes);
     dev_free(c, msq);
-    dev_free(c, d_tiles);
-    dev_free(c, d_panels);
   };
   try {
-    h2d_small(c, d_panels, panels.data(), panels.size() * sizeof(SplitPanel));
-    h2d_small(c, d_tiles, tiles.data(), tiles.size() * sizeof(SplitTile));
-
     // ---- rows per launch (scratch budget) and per workgroup ----
     const int ncu = std::max(1, im->props.multiProcessorCount);
     const char* rows_env = getenv("CCZ_SPLIT_ROWS");       // fp32 accumulation length (rows per workgroup), default 16384
@@ -397,32 +529,9 @@ void gram_split_f32(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
     for (int64_t r0 = 0; r0 < n; r0 += launch_rows) {
       const int64_t rows = std::min(launch_rows, n - r0);
       const int64_t ksteps = (rows + SP_K - 1) / SP_K;
-      // row chunk per workgroup: minimise rounds x (steps + fixed cost) like gram.hip::plan_rows; whole multiples of 8 chunks
-      // on a chip-filling grid select the chunk-per-XCD walk
-      int64_t best_k = 1;
-      {
-        const int64_t kmin = std::max<int64_t>(1, (ksteps + max_steps - 1) / max_steps);
-        const int64_t kmax = std::max<int64_t>(kmin, std::min<int64_t>(ksteps / 16, 8192));
-        double best = 1e300;
-        for (int64_t ks = kmin; ks <= kmax; ++ks) {
-          const int64_t steps = (ksteps + ks - 1) / ks;
-          const bool big = int64_t(ntiles) * ks >= 16 * int64_t(ncu);
-          int64_t rounds;
-          if (big && ks % 8 == 0) rounds = ((ks / 8) * int64_t(ntiles) + ncu / 8 - 1) / (ncu / 8);
-          else if (big) rounds = (int64_t((ntiles + 7) / 8) * ks + ncu / 8 - 1) / (ncu / 8);
-          else rounds = (int64_t(ntiles) * ks + ncu - 1) / ncu;
-          const double cost = (big && ks % 8 != 0 ? 1.03 : 1.0) * double(rounds) * double(steps + 24);
-          if (cost < best) { best = cost; best_k = ks; }
-        }
-      }
-      const int64_t steps_per_wg = (ksteps + best_k - 1) / best_k;
-      const int64_t ksplit = (ksteps + steps_per_wg - 1) / steps_per_wg;
-      const bool sliced = int64_t(ntiles) * ksplit >= 16 * int64_t(ncu);
-      const bool xchunks = sliced && ksplit % 8 == 0;
-      const int per_xcd = xchunks ? -1 : (sliced ? (ntiles + 7) / 8 : 0);
-      const int64_t nblocks = xchunks ? int64_t(ntiles) * ksplit : (sliced ? int64_t(8) * per_xcd * ksplit : int64_t(ntiles) * ksplit);
-      if (nblocks > 0x7fffffffLL) fail(CCZ_EUNSUP, "gram (split route): grid too large");
-      if ((int64_t(steps_per_wg) + SP_NST) * SP_PSTEP > 0x7fffffffLL) fail(CCZ_EUNSUP, "gram (split route): row chunk too long");
+      const SplitRowPlan rp = split_row_plan(ksteps, ntiles, max_steps, ncu);
+      const int64_t steps_per_wg = rp.steps_per_wg, ksplit = rp.ksplit, nblocks = rp.nblocks;
+      const int per_xcd = rp.per_xcd;
       const size_t planes_bytes = size_t(np) * size_t(ksteps) * SP_PSTEP;
       const size_t partial_bytes = size_t(ksplit) * size_t(ntiles) * (SP_T * SP_T * 4);
       if (planes_bytes > planes_cap) { if (planes) dev_free(c, planes); planes = static_cast<char*>(dev_alloc(c, planes_bytes)); planes_cap = planes_bytes; }
@@ -431,10 +540,7 @@ void gram_split_f32(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
       zero(c, msq, size_t(D) * 8);
       if (time_it) CCZ_HIP(hipEventRecord(im->sp_ev[0], st));
       {
-        const int rb = split_rows_per_block(ksteps * SP_K, np, ncu);
-        const dim3 grid((unsigned)((ksteps * SP_K + rb - 1) / rb), (unsigned)np);
-        if (aligned) hipLaunchKernelGGL(k_split_bf16x2<true>, grid, dim3(256), 0, st, d_panels, r0, rows, ksteps, pilot, planes, msq, colsum, rb);
-        else hipLaunchKernelGGL(k_split_bf16x2<false>, grid, dim3(256), 0, st, d_panels, r0, rows, ksteps, pilot, planes, msq, colsum, rb);
+        launch_split_pass(c, tb, vws, aligned, r0, rows, ksteps, pilot, planes, msq, colsum);
       }
       if (time_it) CCZ_HIP(hipEventRecord(im->sp_ev[1], st));
       hipLaunchKernelGGL(k_gram_bf16x2, dim3((unsigned)nblocks), dim3(256), fifo_bytes, st, d_tiles, ntiles, per_xcd, ksplit, planes, ksteps,

@@ -78,6 +78,8 @@ struct Impl {
   struct K1Plan { uint64_t key; void* dev; int wgs; };
   std::vector<K1Plan> k1_plans;          // gram.hip: per-tile row splits of k_gram_f32_fifo_small, by batch shape
   hipEvent_t sp_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // gram_split.hip: stage boundaries of a timed split-route launch
+  struct SplitTab { uint64_t key; void* panels; void* tiles; void* gtiles; int np, ntiles; };
+  std::vector<SplitTab> split_tabs;      // gram_split.hip: panel / tile tables by view widths (pointer-free: uploaded once per shape)
   std::vector<std::pair<void*, void*>> colsum_sync;   // gram.hip: per-stream arrival counters of k_colsum_pilot (64 words each, zero between launches)
   // comm.hip: ccz_moments_exchange -- the packed blocks buffer the handle keeps between fits (grown on demand), the stream its
   // collectives run on and the events that tie it to the handle's stream
@@ -169,6 +171,9 @@ struct GramPartials {
   // null: slot of (chunk, tile) = chunk * ntiles + tile, ksplit chunks per tile, full tiles (k_gram_f32).  Else (k_gram_f32_fifo_small):
   // 3 ints per tile {first slot, slots, rows per slot}, slots of a tile contiguous, diagonal tiles in the FIFO kernel's layout
   int* tile_plan = nullptr;
+  // split route (gram_split.hip: gram_partials_split_f32): full tiles in the (chunk, tile) layout above, tile_plan == null, and
+  const double* msq = nullptr;     // sum_k mid^2 per stacked column: added on the diagonal by the consumer
+  char* planes = nullptr;          // the bf16 planes (pooled scratch, released with the rest)
 };
 // gram_split.hip: the same sums through two bf16 planes per view on the bf16 matrix pipe (hi'hi + hi'mid + mid'hi in one fp32
 // accumulator, the diagonal's mid'mid added back exactly): G (upper tiles) += sum_rows (x - pilot)(x - pilot)'.
@@ -179,13 +184,19 @@ void gram_split_f32(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
 bool gemm_split_pair_eligible(int64_t M, int64_t N, int64_t K, int64_t K1, int64_t nsplit, const void* A1, int64_t lda1, const void* A2,
                               int64_t lda2, const void* C1, int64_t ldc1, const void* C2, int64_t ldc2);
 void gemm_split_pair(ccz_ctx* c, int64_t M, int64_t N, int64_t K, int64_t K1, float alpha, const float* alpha_dev, const float* A1, int64_t lda1,
-                     const float* A2, int64_t lda2, const float* gamma32, const double* gamma64, int64_t ldg, const double* mean, float* C1,
+                     const float* A2, int64_t lda2, const float* gamma32, const double* corr, const double* mean, float* C1,
                      int64_t ldc1, float* C2, int64_t ldc2, int64_t nsplit);
 // project_split.hip: out (n x k <= 64, fp32) = (X - 1 mean') W with the split arithmetic, X converted in registers (no extra pass)
 bool project_split_eligible(ccz_ctx* c, int64_t n, int64_t d, int64_t k, int64_t ld, const void* X, int64_t ldo);
 void project_split(ccz_ctx* c, const float* X, int64_t n, int64_t d, int64_t ld, const double* mean, const double* W, int64_t k, float* out,
                    int64_t ldo);
 bool gram_partials_f32(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, GramPartials* out);
+// gram.hip: exact fp64 column sums of all views + the fp32 pilot (their mean) in ONE launch (k_colsum_pilot); `zero_me` (optional,
+// nzero doubles) is cleared by the same launch.  false: shape not supported (more than 64 column blocks / 8 views), nothing enqueued
+bool colsum_pilot_f32(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, int64_t D, double* colsum, float* pilot, double* zero_me,
+                      int64_t nzero);
+// gram_split.hip: the same partial sums through the split route (DCCA batches from 4096 rows on); false: does not apply
+bool gram_partials_split_f32(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, GramPartials* out);
 void gram_partials_release(ccz_ctx* c, GramPartials* gp);
 
 // gram.hip

@@ -91,7 +91,9 @@ __global__ __launch_bounds__(256) void k_loss_prep_partials(const float* __restr
                                                             const float* __restrict__ pilot,
                                                             int64_t D, double n_rows, double inv_nm1, double eps, double* __restrict__ Ce,
                                                             double* __restrict__ mean, PrepArgs pa, double* __restrict__ acc,
-                                                            double* __restrict__ bias) {
+                                                            double* __restrict__ bias, const double* __restrict__ msq) {
+  // msq (split route, gram_split.hip): sum_k mid_k^2 per column, the one dropped product of the split arithmetic that does not
+  // average out -- added on the diagonal before the shift is undone
   __shared__ double tr[PSB][PSB + 1];
   const int tile = blockIdx.y;
   if (tile == 0) {
@@ -145,7 +147,8 @@ __global__ __launch_bounds__(256) void k_loss_prep_partials(const float* __restr
     double v = 0.0;
     if (r < vi && c < vj) {
       const double di = s[gi0 + r] / n_rows - double(pilot[gi0 + r]);
-      v = (g[k] - n_rows * di * dj) * inv_nm1;
+      const double gk = (msq && gi0 + r == gj0 + c) ? g[k] + msq[gi0 + r] : g[k];
+      v = (gk - n_rows * di * dj) * inv_nm1;
       if (gi0 + r == gj0 + c) v += eps;
       const int64_t e1 = (gi0 + r) * D + gj0 + c;
       Ce[e1] = v;
@@ -221,20 +224,28 @@ __global__ void k_loss_finish(const double* __restrict__ acc, int dtype, void* _
 // grid (D / 64, D / 64) x 256.
 __global__ __launch_bounds__(256) void k_loss_tail(const double* __restrict__ Gm, const double* __restrict__ mean, int64_t D,
                                                    double* __restrict__ bias, float* __restrict__ G32, const double* __restrict__ acc, int dtype,
-                                                   void* __restrict__ out, const int* __restrict__ info, int m, int* __restrict__ status) {
+                                                   void* __restrict__ out, const int* __restrict__ info, int m, int* __restrict__ status,
+                                                   double* __restrict__ corr) {
+  // corr (optional, zeroed by k_state_rows): sum_i (mean_i - fl32(mean_i)) Gamma_ij -- what a backward on operands shifted by the
+  // fp32 pilot fl32(mean) still owes the exact centring (gemm_split.hip)
   __shared__ double red[4][64];
+  __shared__ double redc[4][64];
   const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int64_t j = int64_t(blockIdx.x) * 64 + c, i0 = int64_t(blockIdx.y) * 64;
-  double a = 0.0;
+  double a = 0.0, ac = 0.0;
   if (j < D)
     for (int64_t i = i0 + rg; i < min(D, i0 + 64); i += 4) {
       const double g = Gm[i * D + j];
-      a += mean[i] * g;
+      const double mi = mean[i];
+      a += mi * g;
+      ac += (mi - double(float(mi))) * g;
       if (G32) G32[i * D + j] = float(g);
     }
   red[rg][c] = a;
+  redc[rg][c] = ac;
   __syncthreads();
   if (rg == 0 && j < D) unsafeAtomicAdd(bias + j, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+  if (corr && rg == 1 && j < D) unsafeAtomicAdd(corr + j, redc[0][c] + redc[1][c] + redc[2][c] + redc[3][c]);
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
     double l = -0.5 * acc[0];
     for (int v = 0; v < m; ++v)
@@ -245,6 +256,12 @@ __global__ __launch_bounds__(256) void k_loss_tail(const double* __restrict__ Gm
       }
     if (dtype == CCZ_F32) *static_cast<float*>(out) = float(l); else *static_cast<double*>(out) = l;
   }
+}
+
+// the state's batch-mean row <- mean, its pilot-correction row <- 0 (k_loss_tail accumulates into it)
+__global__ void k_state_rows(const double* __restrict__ mean, int64_t D, double* __restrict__ mean_out, double* __restrict__ corr_out) {
+  const int64_t j = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (j < D) { mean_out[j] = mean[j]; corr_out[j] = 0.0; }
 }
 
 // dst = (*scale) * src, elementwise; scale: one element of `dtype` on the device (the upstream gradient of the loss)
@@ -320,7 +337,8 @@ void pair_core(ccz_ctx* c, const double* mom, int64_t n, const int64_t* dims, in
   }
   if (gp)
     hipLaunchKernelGGL(k_loss_prep_partials, dim3(64, (unsigned)gp->ntiles), dim3(256), 0, st, gp->partial, gp->tiles, gp->ntiles, gp->ksplit,
-                       gp->tile_plan, gp->colsum, gp->pilot, D, double(n), inv, eps, Ce.get(), mean_dev, pa, acc_dev, want_grad ? bias_dev : nullptr);
+                       gp->tile_plan, gp->colsum, gp->pilot, D, double(n), inv, eps, Ce.get(), mean_dev, pa, acc_dev, want_grad ? bias_dev : nullptr,
+                       gp->msq);
   else
     hipLaunchKernelGGL(k_loss_prep, dim3((unsigned)std::min<int64_t>((D * D + 255) / 256, 4096)), dim3(256), 0, st, mom, mom + D * D, D,
                        1.0 / double(n), inv, eps, Ce.get(), mean_dev, pa, acc_dev, want_grad ? bias_dev : nullptr);
@@ -506,7 +524,7 @@ static LossShape loss_shape(const ccz_view* z, int m, int64_t n, int dtype, cons
   return sh;
 }
 
-// state: [Gamma fp64 (D x D) | centring row mean' Gamma (D) | batch mean (D) | Gamma fp32 (D x D)]
+// state: [Gamma fp64 (D x D) | centring row mean' Gamma (D) | batch mean (D) | pilot correction (mean - fl32(mean))' Gamma (D) | Gamma fp32 (D x D)]
 int64_t pair_loss_state_bytes_impl(int dtype, const int64_t* dims, int m) {
   if (!dims || m < 2 || m > LMAXV) return -1;
   int64_t D = 0;
@@ -515,7 +533,7 @@ int64_t pair_loss_state_bytes_impl(int dtype, const int64_t* dims, int m) {
     D += dims[a];
   }
   (void)dtype;
-  return (D + 2) * D * 8 + D * D * 4;
+  return (D + 3) * D * 8 + D * D * 4;
 }
 
 void pair_loss_forward_impl(ccz_ctx* c, int dtype, const ccz_view* z, int m, int64_t n, double eps, void* loss_dev, void* state) {
@@ -527,7 +545,7 @@ void pair_loss_forward_impl(ccz_ctx* c, int dtype, const ccz_view* z, int m, int
   const bool want = state != nullptr;
   double* gamma = static_cast<double*>(state);
   double* bias = want ? gamma + D * D : nullptr;
-  float* g32 = (want && dtype == CCZ_F32) ? reinterpret_cast<float*>(gamma + (D + 2) * D) : nullptr;
+  float* g32 = (want && dtype == CCZ_F32) ? reinterpret_cast<float*>(gamma + (D + 3) * D) : nullptr;
   DBuf mean(c, D), acc(c, 1);
   PoolPtr info(c, LMAXV * sizeof(int));
   // fp32 DCCA batch: K1's partial sums feed the preparation directly (no moments, no gather, no fills, no atomics).
@@ -550,9 +568,10 @@ void pair_loss_forward_impl(ccz_ctx* c, int dtype, const ccz_view* z, int m, int
     pair_core(c, mom, n, sh.dims, m, eps, want, acc, gamma, mean, info.as<int>(), bias, nullptr, narrow);
   }
   if (want) {
-    d2d(c, gamma + (D + 1) * D, mean.get(), size_t(D) * 8);      // the batch mean travels with the state (backward: pilot of the split route)
+    // the batch mean travels with the state (backward: pilot of the split route), and the pilot-correction row is formed with the centring row
+    hipLaunchKernelGGL(k_state_rows, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, st, mean.get(), D, gamma + (D + 1) * D, gamma + (D + 2) * D);
     hipLaunchKernelGGL(k_loss_tail, dim3((unsigned)((D + 63) / 64), (unsigned)((D + 63) / 64)), dim3(256), 0, st, gamma, mean.get(), D, bias, g32,
-                       acc.get(), dtype, loss_dev, info.as<int>(), m, loss_status_dev(c));
+                       acc.get(), dtype, loss_dev, info.as<int>(), m, loss_status_dev(c), gamma + (D + 2) * D);
   } else {
     hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(1), 0, st, acc.get(), dtype, loss_dev, static_cast<double*>(nullptr), info.as<int>(), m,
                        loss_status_dev(c));
@@ -578,15 +597,16 @@ void pair_loss_backward_impl(ccz_ctx* c, int dtype, const ccz_view* z, int m, in
   hipStream_t st = stream(c);
   const double* gamma = static_cast<const double*>(state);
   const double* bias = gamma + D * D;
-  const float* g32 = reinterpret_cast<const float*>(gamma + (D + 2) * D);
+  const float* g32 = reinterpret_cast<const float*>(gamma + (D + 3) * D);
   const double* mean = gamma + (D + 1) * D;
+  const double* corr = gamma + (D + 2) * D;
   // a backward that is a large product (the metric shape: n = 1e6, D = 8192) runs on the bf16 pipe with the split arithmetic of K1
   if (dtype == CCZ_F32 && m == 2 && all && c->k1_route != CCZ_K1_FP32 &&
       gemm_split_pair_eligible(n, D, D, sh.dims[0], sh.dims[0], z[0].data, z[0].ld, z[1].data, z[1].ld, g[0], ldg[0], g[1], ldg[1])) {
     try {
       c->last_bwd_route = CCZ_K1_BF16X2;
       gemm_split_pair(c, n, D, D, sh.dims[0], 1.0f, static_cast<const float*>(grad_out), static_cast<const float*>(z[0].data), z[0].ld,
-                      static_cast<const float*>(z[1].data), z[1].ld, g32, gamma, D, mean, static_cast<float*>(g[0]), ldg[0], static_cast<float*>(g[1]),
+                      static_cast<const float*>(z[1].data), z[1].ld, g32, corr, mean, static_cast<float*>(g[0]), ldg[0], static_cast<float*>(g[1]),
                       ldg[1], sh.dims[0]);
       return;
     } catch (const Error& e) {

@@ -185,7 +185,7 @@ def test_two_phase_abi_against_the_closed_form(H, n, dims, dtype, tol):
     dims_a = (C.c_int64 * m)(*dims)
     nbytes = H.lib.ccz_pair_loss_state_bytes(code, dims_a, m)
     D = sum(dims)
-    assert nbytes == (D + 2) * D * 8 + D * D * 4          # Gamma | centring row | batch mean | Gamma fp32
+    assert nbytes == (D + 3) * D * 8 + D * D * 4          # Gamma | centring row | batch mean | pilot correction | Gamma fp32
     state = torch.empty(nbytes // 8 + 1, dtype=torch.float64, device="cuda")
     loss = torch.empty((), dtype=tdt, device="cuda")
     torch.cuda.synchronize()
