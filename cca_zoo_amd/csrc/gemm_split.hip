@@ -215,7 +215,7 @@ void gemm_split_pair(ccz_ctx* c, int64_t M, int64_t N, int64_t K, int64_t K1, fl
     vw.data[1] = A2; vw.ld[1] = lda2; vw.off[1] = int(K1);
     vw.off[2] = int(K);
     const size_t fifo_bytes = size_t(SP_NST) * SP_STAGE;
-    CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_bf16x2_nn), hipFuncAttributeMaxDynamicSharedMemorySize, int(fifo_bytes)));
+    sp_allow_lds(reinterpret_cast<const void*>(&k_gemm_bf16x2_nn), c->device, int(fifo_bytes));
     for (int64_t t0 = 0; t0 < row_tiles_all; t0 += tiles_per_launch) {
       const int64_t tiles = std::min(tiles_per_launch, row_tiles_all - t0);
       hipLaunchKernelGGL(k_splitT_bf16x2, dim3((unsigned)(S / 4), (unsigned)tiles), dim3(256), 0, st, vw, t0 * 256, M, K, S, mean, planesA);

@@ -295,7 +295,6 @@ struct SplitTables {
   const SplitTile* tiles;
   const GramTile* gtiles;      // the same tiles for loss.hip's preparation kernel (out_row / out_col / wa / wb / diag; a, b unused)
   int np, ntiles;
-  std::vector<int32_t> panel_width;    // host copies the planners need
 };
 
 static SplitTables split_tables(ccz_ctx* c, const int64_t* cols, int n_views) {
@@ -303,7 +302,18 @@ static SplitTables split_tables(ccz_ctx* c, const int64_t* cols, int n_views) {
   uint64_t key = 1469598103934665603ull;
   auto mix = [&](uint64_t v) { key ^= v; key *= 1099511628211ull; };
   mix(uint64_t(n_views));
-  for (int v = 0; v < n_views; ++v) mix(uint64_t(cols[v]));
+  int np = 0;
+  for (int v = 0; v < n_views; ++v) { mix(uint64_t(cols[v])); np += int((cols[v] + SP_T - 1) / SP_T); }
+  SplitTables tb;
+  tb.np = np;
+  for (auto& e : im->split_tabs)
+    if (e.key == key && e.np == np) {                   // the hot path: a lookup, no allocation
+      tb.panels = static_cast<const SplitPanel*>(e.panels);
+      tb.tiles = static_cast<const SplitTile*>(e.tiles);
+      tb.gtiles = static_cast<const GramTile*>(e.gtiles);
+      tb.ntiles = e.ntiles;
+      return tb;
+    }
   std::vector<SplitPanel> panels;
   int64_t g0 = 0;
   for (int v = 0; v < n_views; ++v) {
@@ -311,17 +321,6 @@ static SplitTables split_tables(ccz_ctx* c, const int64_t* cols, int n_views) {
       panels.push_back(SplitPanel{int32_t(v), int32_t(c0), int32_t(std::min<int64_t>(SP_T, cols[v] - c0)), int32_t(g0 + c0)});
     g0 += cols[v];
   }
-  SplitTables tb;
-  tb.np = int(panels.size());
-  for (const auto& p : panels) tb.panel_width.push_back(p.width);
-  for (auto& e : im->split_tabs)
-    if (e.key == key && e.np == tb.np) {
-      tb.panels = static_cast<const SplitPanel*>(e.panels);
-      tb.tiles = static_cast<const SplitTile*>(e.tiles);
-      tb.gtiles = static_cast<const GramTile*>(e.gtiles);
-      tb.ntiles = e.ntiles;
-      return tb;
-    }
   std::vector<SplitTile> tiles;
   std::vector<GramTile> gt;
   for (const auto& ij : split_tile_order(tb.np)) {
@@ -428,13 +427,13 @@ bool gram_partials_split_f32(ccz_ctx* c, const ccz_view* views, int n_views, int
   if ((e_on && atoi(e_on) == 0) || c->k1_route == CCZ_K1_FP32) return false;
   if (n_views < 1 || n_views > 8 || n < 4096) return false;
   int64_t D = 0;
-  std::vector<int64_t> cols(n_views);
+  int64_t cols[8];
   for (int v = 0; v < n_views; ++v) { cols[v] = views[v].cols; D += views[v].cols; }
   if (D < 512 || (D + 255) / 256 > 64 || double(n) * double(D) * double(D + 1) < 5e9) return false;
   Impl* im = impl(c);
   hipStream_t st = stream(c);
   const int ncu = std::max(1, im->props.multiProcessorCount);
-  const SplitTables tb = split_tables(c, cols.data(), n_views);
+  const SplitTables tb = split_tables(c, cols, n_views);
   const int64_t ksteps = (n + SP_K - 1) / SP_K;
   const SplitRowPlan rp = split_row_plan(ksteps, tb.ntiles, 16384 / SP_K, ncu);
   static const int64_t partial_cap = [] { const char* e = getenv("CCZ_GRAM_PARTIAL_MB"); return (e ? atoll(e) : 192LL) << 20; }();
@@ -455,7 +454,7 @@ bool gram_partials_split_f32(ccz_ctx* c, const ccz_view* views, int n_views, int
   }
   launch_split_pass(c, tb, vws, aligned, 0, n, ksteps, out->pilot, out->planes, msq, nullptr);
   const size_t fifo_bytes = size_t(SP_NST) * SP_STAGE;
-  CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_bf16x2), hipFuncAttributeMaxDynamicSharedMemorySize, int(fifo_bytes)));
+  sp_allow_lds(reinterpret_cast<const void*>(&k_gram_bf16x2), c->device, int(fifo_bytes));
   hipLaunchKernelGGL(k_gram_bf16x2, dim3((unsigned)rp.nblocks), dim3(256), fifo_bytes, st, tb.tiles, tb.ntiles, rp.per_xcd, rp.ksplit, out->planes, ksteps,
                      rp.steps_per_wg, out->partial);
   CCZ_LAUNCH_CHECK();
@@ -489,9 +488,9 @@ void gram_split_f32(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
   // ---- panels and tiles (device tables cached with the handle by the views' widths) ----
   if (n_views > SP_MAXV) fail(CCZ_EUNSUP, "gram (split route): more than %d views", SP_MAXV);
   if (D > 0x7fffffffLL - 256) fail(CCZ_EUNSUP, "gram (split route): stacked width too large");
-  std::vector<int64_t> cols(n_views);
+  int64_t cols[SP_MAXV];
   for (int v = 0; v < n_views; ++v) cols[v] = views[v].cols;
-  const SplitTables tb = split_tables(c, cols.data(), n_views);
+  const SplitTables tb = split_tables(c, cols, n_views);
   SplitViews vws{};
   const bool aligned = split_views_arg(views, n_views, &vws);
   const int np = tb.np, ntiles = tb.ntiles;
@@ -516,7 +515,7 @@ void gram_split_f32(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
     const int64_t n_launch = (n + launch_rows - 1) / launch_rows;
     launch_rows = ((n + n_launch - 1) / n_launch + SP_K - 1) / SP_K * SP_K;       // equal super-chunks
     const size_t fifo_bytes = size_t(SP_NST) * SP_STAGE;
-    CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_bf16x2), hipFuncAttributeMaxDynamicSharedMemorySize, int(fifo_bytes)));
+    sp_allow_lds(reinterpret_cast<const void*>(&k_gram_bf16x2), c->device, int(fifo_bytes));
     if (time_it) {
       for (auto& e : im->sp_ev)
         if (!e) CCZ_HIP(hipEventCreate(&e));

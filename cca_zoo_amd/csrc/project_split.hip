@@ -239,11 +239,11 @@ void project_split(ccz_ctx* c, const float* X, int64_t n, int64_t d, int64_t ld,
     const int64_t wgs = (n + 4 * 32 * PJ_MT - 1) / (4 * 32 * PJ_MT);
     if (nplanes == 2) {
       const size_t lds = size_t(4) * PJ<2>::R * PJ<2>::SLOT + size_t(d) * 4;
-      CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project_split<2>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+      sp_allow_lds(reinterpret_cast<const void*>(&k_project_split<2>), c->device, int(lds));
       hipLaunchKernelGGL(k_project_split<2>, dim3((unsigned)wgs), dim3(256), lds, st, X, n, d, ld, pilot, planes, mean ? corr : nullptr, out, ldo, int(k));
     } else {
       const size_t lds = size_t(4) * PJ<3>::R * PJ<3>::SLOT + size_t(d) * 4;
-      CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project_split<3>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+      sp_allow_lds(reinterpret_cast<const void*>(&k_project_split<3>), c->device, int(lds));
       hipLaunchKernelGGL(k_project_split<3>, dim3((unsigned)wgs), dim3(256), lds, st, X, n, d, ld, pilot, planes, mean ? corr : nullptr, out, ldo, int(k));
     }
     CCZ_LAUNCH_CHECK();

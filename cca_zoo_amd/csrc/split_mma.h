@@ -5,6 +5,8 @@
 // bf16 -- 256 indices of the non-contracted dimension x 16 of the contracted one, every 1 KiB run one MFMA operand of one wave.
 #pragma once
 
+#include <mutex>
+
 #include "hip_common.h"
 #include "gram_map.h"
 
@@ -32,6 +34,20 @@ __device__ __forceinline__ unsigned sp_pack2(float a, float b) {
 }
 
 typedef __attribute__((address_space(3))) void* sp_lds_ptr;
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is sticky per function and device: set it once per (kernel, device) instead of in
+// front of every launch (a driver call per launch shows in a training step whose host thread is the bottleneck)
+inline void sp_allow_lds(const void* fn, int device, int bytes) {
+  struct Seen { const void* fn; int device; int bytes; };
+  static Seen seen[64];
+  static int nseen = 0;
+  static std::mutex mu;                       // (handles of different threads share the table)
+  std::lock_guard<std::mutex> lock(mu);
+  for (int i = 0; i < nseen; ++i)
+    if (seen[i].fn == fn && seen[i].device == device && seen[i].bytes >= bytes) return;
+  CCZ_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  if (nseen < 64) seen[nseen++] = Seen{fn, device, bytes};
+}
 
 // one of the eight 1 KiB DMAs of this wave's quarter of a k-step
 #define SP_DMA1(slot, soff, i_)                                                                                     \
