@@ -419,13 +419,17 @@ static SplitRowPlan split_row_plan(int64_t ksteps, int ntiles, int64_t max_steps
 // chunk, tile) fp32 partial tiles -- the layout of gram.hip's staged kernel (slot = chunk * ntiles + tile, full tiles, no plan) --
 // plus the exact column sums, the pilot and sum mid^2 for the diagonal.  Three launches: k_colsum_pilot (which also clears msq),
 // the split pass, the MFMA kernel; nothing is reduced here (the consumer adds the chunks up in fp64 while it forms Ce).
-// From 4096 rows on: a batch's second moments then agree with their float64 values to ~4e-7 (8192 rows: 3.5e-7 against the
-// fp32 kernel's 2.2e-7) -- the reference forms them by a float32 matmul and inverts them through a float32 eigh
-// (cca_zoo/deep/objectives.py:9-21, :86-97), both an order of magnitude looser.  CCZ_LOSS_K1_SPLIT=0 keeps the fp32 kernels.
+// Default: from 32768 rows on (K1's own rule: there the route is at least as accurate as the fp32 kernel).  CCZ_LOSS_K1_SPLIT=2 takes
+// it from 4096 rows on (8192 rows: 3.5e-7 against the fp32 kernel's 2.2e-7 -- the reference forms these moments by a float32 matmul
+// and inverts them through a float32 eigh, cca_zoo/deep/objectives.py:9-21, :86-97, both looser): measured at BASELINE configs[3]
+// (batch 8192, 2 x 512) the loss alone gets faster (0.63 -> 0.56 ms with the split backward) but a TRAINING STEP gets slower
+// (2.50 -> 2.60 ms): the bf16 MFMA bursts pull the chip's clock down and the encoders' GEMMs next to them run ~10 % longer
+// (profiles/r06_loss_c4.md).  So small batches keep the fp32 kernels unless asked.  CCZ_LOSS_K1_SPLIT=0: never.
 bool gram_partials_split_f32(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, GramPartials* out) {
   const char* e_on = getenv("CCZ_LOSS_K1_SPLIT");
-  if ((e_on && atoi(e_on) == 0) || c->k1_route == CCZ_K1_FP32) return false;
-  if (n_views < 1 || n_views > 8 || n < 4096) return false;
+  const int mode = e_on ? atoi(e_on) : 1;
+  if (mode == 0 || c->k1_route == CCZ_K1_FP32) return false;
+  if (n_views < 1 || n_views > 8 || n < (mode >= 2 ? 4096 : 32768)) return false;
   int64_t D = 0;
   int64_t cols[8];
   for (int v = 0; v < n_views; ++v) { cols[v] = views[v].cols; D += views[v].cols; }

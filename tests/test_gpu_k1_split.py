@@ -293,3 +293,32 @@ def test_loss_reports_the_routes_it_took(H):
     fwd, bwd = H.loss_last_route()
     assert bwd == "fp32"                                          # a small batch keeps the fp32 product (and the fast K1 path)
     assert fwd in ("fp32", "none", "bf16x2")
+
+
+def test_split_loss_for_small_batches_is_opt_in(H, monkeypatch):
+    """BASELINE configs[3] (batch 8192, 2 x 512): by default both products of the loss stay on the fp32 pipe (inside a training step
+    the bf16 MFMA bursts cost the neighbouring GEMMs more clock than they save: profiles/r06_loss_c4.md); CCZ_LOSS_K1_SPLIT=2 /
+    CCZ_LOSS_BWD_SPLIT=2 opt in, and the two forms agree far inside the 1e-3 bar."""
+    import torch
+
+    from cca_zoo_amd.deep.objectives import CCALoss
+
+    torch.manual_seed(0)
+    z1 = torch.randn(8192, 512, device="cuda", requires_grad=True)
+    z2 = (0.5 * z1.detach() + torch.randn(8192, 512, device="cuda")).requires_grad_(True)
+
+    def run():
+        z1.grad = z2.grad = None
+        loss = CCALoss(eps=1e-6)([z1, z2])
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss.detach()), z1.grad.clone(), z2.grad.clone(), H.loss_last_route()
+
+    l0, a0, b0, r0 = run()
+    assert r0[1] == "fp32" and r0[0] in ("fp32", "none")
+    monkeypatch.setenv("CCZ_LOSS_K1_SPLIT", "2")
+    monkeypatch.setenv("CCZ_LOSS_BWD_SPLIT", "2")
+    l1, a1, b1, r1 = run()
+    assert r1 == ("bf16x2", "bf16x2")
+    assert abs(l1 - l0) < 1e-5 * abs(l0)
+    assert float((a1 - a0).norm() / a0.norm()) < 5e-5 and float((b1 - b0).norm() / b0.norm()) < 5e-5
