@@ -1544,6 +1544,7 @@ bool gram_partials_f32(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n
   out->ntiles = tt.ntiles;
   out->ksplit = rp.ksplit;
   c->last_pilot = 1;
+  c->last_route = CCZ_K1_FP32;
   return true;
 }
 
