@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define CCZ_VERSION 150 /* 0.1.5: ccz_k1_route (split-bf16 route of K1 and of the loss's large backward), ccz_moments_last_route,
-                          * ccz_loss_last_route, ccz_pool_trim; the loss state grew by D doubles (opaque: ccz_pair_loss_state_bytes).
+                          * ccz_loss_last_route, ccz_pool_trim; the loss state grew by 2 D doubles (opaque: ccz_pair_loss_state_bytes).
                           * 0.1.4: ccz_pair_loss_forward / _backward / _state_bytes (the loss as an autograd node in two phases),
                           * ccz_moments_exchange (the whole exchange step), ccz_solve_defer(h, NULL) = await a pending deferral now */
 
