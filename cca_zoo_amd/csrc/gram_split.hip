@@ -28,7 +28,9 @@
 // step s + 1 from LDS while the 48 MFMAs of step s run.  Three k-steps of loads are always in flight.
 //
 // Output: per (row chunk, tile) fp32 partial tiles with plain 16-byte stores (no atomics); k_split_reduce adds the chunks
-// up in fp64 into G and applies the diagonal correction.
+// up in fp64 into G and applies the diagonal correction.  The loss fast path (gram_partials_split_f32) hands the partial
+// tiles to loss.hip's preparation kernel instead.  The split pass also gathers the exact fp64 column sums of x (the means; s of
+// the pilot fix-up), so the route reads the rows once.  Panel / tile tables hold no pointers and are cached with the handle.
 //
 // Roofline: executed flops = 3 x n Dp (Dp + 256) on the bf16 pipe (2.5 PF dense peak); algorithmic F = n D (D + 1).
 #include <algorithm>
