@@ -1257,7 +1257,19 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         if one_gpu:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            # gloo prints its "[Gloo] Rank r is connected ..." lines on the C stdout: the contract is ONE JSON line there
+            import ctypes
+
+            sys.stdout.flush()
+            saved_fd = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+                dist.barrier()
+                ctypes.CDLL(None).fflush(None)
+            finally:
+                os.dup2(saved_fd, 1)
+                os.close(saved_fd)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 

@@ -124,8 +124,8 @@ def test_bench_two_ranks_on_one_gpu_prints_one_json_line():
            "--no-extras", "--no-cpu-baseline", "--rows", "131072", "--dim", "1024", "--k", "16"]     # (--dim: torch.distributed.run would take "--d" for one of its own options)
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-4000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")]
-    assert len(lines) == 1, p.stdout[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), p.stdout[-2000:]        # ONE line on stdout, and it is the JSON
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["transport"] == "gloo-staged" and rec["ranks_on_one_gpu"] == 2
     assert rec["parity_gate"]["ok"] and rec["value"] > 0
