@@ -322,3 +322,28 @@ def test_split_loss_for_small_batches_is_opt_in(H, monkeypatch):
     assert r1 == ("bf16x2", "bf16x2")
     assert abs(l1 - l0) < 1e-5 * abs(l0)
     assert float((a1 - a0).norm() / a0.norm()) < 5e-5 and float((b1 - b0).norm() / b0.norm()) < 5e-5
+
+
+def test_split_route_random_shapes(H):
+    """Seeded random sweep over row counts, view counts, ragged widths, leading dimensions and offsets (the padding, the k-step
+    tails, the panel tables per shape, the row-chunk planner): every case against float64 NumPy."""
+    rng = np.random.default_rng(2026)
+    for case in range(14):
+        n = int(rng.choice([17, 240, 1000, 4097, 9000, 20011, 50000]))
+        m = int(rng.integers(1, 5))
+        dims = [int(rng.choice([5, 64, 100, 255, 256, 257, 300, 512, 700])) for _ in range(m)]
+        shift = float(rng.choice([0.0, 0.0, 2.0, -30.0]))
+        views = _latent(n, dims, seed=100 + case, shift=shift)
+        if case % 3 == 1:                                       # a strided first view on the host path
+            wide = np.zeros((n, dims[0] + 5), dtype=np.float32)
+            wide[:, 2:2 + dims[0]] = views[0]
+            views[0] = wide[:, 2:2 + dims[0]]
+            on_device = False
+        else:
+            on_device = True
+        Gr, sr = _ref(views)
+        G, s, taken, _ = _moments(H, views, "bf16x2", on_device=on_device)
+        assert taken == "bf16x2"
+        tol = 1.2e-5 if n < 4096 else 2e-6                       # (a few dozen rows: the dropped 2^-16 terms do not average out yet)
+        assert _rel(G, Gr) < tol, (case, n, dims, shift, _rel(G, Gr))
+        np.testing.assert_allclose(s, sr, rtol=1e-11, atol=1e-6)
