@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void k_split_bf16x2(const SplitPanel* __restri
       const float* src = X + (r0 + (rok ? row + k : 0)) * pld;
       if (ALIGNED) {
         v[k] = p;                                          // (whole 4-column groups are inside or outside the panel's width)
-        if (cok[0]) v[k] = *reinterpret_cast<const sp_v4f32*>(src);
+        if (cok[0]) v[k] = __builtin_nontemporal_load(reinterpret_cast<const sp_v4f32*>(src));   // read once: keep L2 / MALL for the planes
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[k][e] = cok[e] ? src[e] : 0.f;
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void k_split_bf16x2(const SplitPanel* __restri
     char* dst = out + (row >> 4) * SP_PSTEP + ((row >> 3) & 1) * 512;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      *reinterpret_cast<sp_v4u32*>(dst + e * 16) = hw[e];
+      *reinterpret_cast<sp_v4u32*>(dst + e * 16) = hw[e];              // (plain stores: non-temporal ones made this pass 3.5x slower)
       *reinterpret_cast<sp_v4u32*>(dst + SP_PLANE + e * 16) = mw[e];
     }
   }
