@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void k_splitT_bf16x2(SplitTViews vw, int64_t r
   for (int it = 0; it < 16; ++it) {
     const int64_t m = m0 + wave * 64 + it * 4 + rr;
     x[it] = p;                                       // d = 0 for padding rows and columns
-    if (cok && m < M) x[it] = *reinterpret_cast<const sp_v4f32*>(X + m * ld);
+    if (cok && m < M) x[it] = __builtin_nontemporal_load(reinterpret_cast<const sp_v4f32*>(X + m * ld));   // read once
   }
   const int s_l = c4 >> 2, h = (c4 >> 1) & 1, khalf = c4 & 1;
   const int swz = (s_l * 2 + h) & 7;

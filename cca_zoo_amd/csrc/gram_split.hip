@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void k_split_reduce(const float* __restrict__ 
   const float* p = partial + int64_t(tile) * (SP_T * SP_T) + e;
   const int64_t stride = int64_t(ntiles) * (SP_T * SP_T);
   for (int64_t c = 0; c < ksplit; ++c) {
-    const sp_v4f32 v = *reinterpret_cast<const sp_v4f32*>(p + c * stride);
+    const sp_v4f32 v = __builtin_nontemporal_load(reinterpret_cast<const sp_v4f32*>(p + c * stride));   // read once
     a0 += double(v[0]); a1 += double(v[1]); a2 += double(v[2]); a3 += double(v[3]);
   }
   const double a[4] = {a0, a1, a2, a3};
