@@ -117,6 +117,7 @@ int ccz_destroy(ccz_handle h) {
     for (int i = 0; i < 4; ++i) (void)hipEventDestroy(im->ev[i]);
     for (int i = 0; i < 4; ++i) if (im->pipe_ev[i]) (void)hipEventDestroy(im->pipe_ev[i]);
     for (auto& e : im->sp_ev) if (e) (void)hipEventDestroy(e);
+    if (im->split_stream) (void)hipStreamDestroy(im->split_stream);
     for (auto& e : im->split_tabs) { (void)hipFree(e.panels); (void)hipFree(e.tiles); (void)hipFree(e.gtiles); }
     for (int i = 0; i < 2; ++i) if (im->pin_buf[i]) (void)hipHostFree(im->pin_buf[i]);
     for (int i = 0; i < Impl::kSmallSlots; ++i) {

@@ -369,11 +369,12 @@ static bool split_views_arg(const ccz_view* views, int n_views, SplitViews* vws)
 }
 
 static void launch_split_pass(ccz_ctx* c, const SplitTables& tb, const SplitViews& vws, bool aligned, int64_t r0, int64_t rows, int64_t ksteps,
-                              const float* pilot, char* planes, double* msq, double* colsum) {
+                              const float* pilot, char* planes, double* msq, double* colsum, hipStream_t st = nullptr) {
+  if (!st) st = stream(c);
   const int rb = split_rows_per_block(ksteps * SP_K, tb.np, std::max(1, impl(c)->props.multiProcessorCount));
   const dim3 grid((unsigned)((ksteps * SP_K + rb - 1) / rb), (unsigned)tb.np);
-  if (aligned) hipLaunchKernelGGL(k_split_bf16x2<true>, grid, dim3(256), 0, stream(c), tb.panels, vws, r0, rows, ksteps, pilot, planes, msq, colsum, rb);
-  else hipLaunchKernelGGL(k_split_bf16x2<false>, grid, dim3(256), 0, stream(c), tb.panels, vws, r0, rows, ksteps, pilot, planes, msq, colsum, rb);
+  if (aligned) hipLaunchKernelGGL(k_split_bf16x2<true>, grid, dim3(256), 0, st, tb.panels, vws, r0, rows, ksteps, pilot, planes, msq, colsum, rb);
+  else hipLaunchKernelGGL(k_split_bf16x2<false>, grid, dim3(256), 0, st, tb.panels, vws, r0, rows, ksteps, pilot, planes, msq, colsum, rb);
 }
 
 // The K1-layout planes of ONE fp32 matrix X (rows x cols, ld): panels of 256 columns, `ksteps` k-steps of 16 rows each (rows past
@@ -483,6 +484,78 @@ bool gram_split_worthwhile(int64_t n, int64_t D) {
   return n >= 32768 && D >= 256 && double(n) * double(D) * double(D + 1) >= min_flop;
 }
 
+// Row pieces of one launch (in rows; whole units of a workgroup's row chunk except the last) -- an A/B switch, OFF by default.
+// The split pass is an HBM pass (13 ms of a 160 ms K1 at the metric shape) in front of a power-bound MFMA kernel, so round 6 tried to
+// hide it: cut the launch into a short leading piece and the rest, and run the split pass of piece p + 1 on a side stream under the
+// MFMA kernel of piece p.  Measured at n = 1e6, 2 x 4096 (profiles/r06_split_pipe_sweep.log): one piece 156.6 - 157.6 ms; piped with
+// the side stream on 32 / 64 / 128 CUs 199.5 / 180.0 / 168.4 ms, unmasked 159.1 ms (the pass's small workgroups fill every CU that
+// frees up and the two kernels serialise).  The MFMA kernel loses MORE than the pass's duration whenever the two really overlap: it
+// scales with the CUs it holds even at the power limit, and the pass's 4.7 TB/s stream evicts the panels it shares through L2.
+// CCZ_SPLIT_PIPE: unset / "0" = one piece; "f0,f1,.." = the leading pieces as fractions of the launch's rows (launches below 8 units =
+// 131072 rows stay whole).
+static std::vector<int64_t> split_pieces(int64_t rows, int64_t unit) {
+  std::vector<double> fr;
+  if (const char* e = getenv("CCZ_SPLIT_PIPE")) {
+    fr.clear();
+    for (const char* q = e; *q;) {
+      char* end = nullptr;
+      const double f = strtod(q, &end);
+      if (end == q) break;
+      if (f > 0.0 && f < 1.0) fr.push_back(f);
+      q = *end == ',' ? end + 1 : end;
+      if (end && *end != ',' ) break;
+    }
+  }
+  std::vector<int64_t> out;
+  const int64_t T = (rows + unit - 1) / unit;
+  int64_t used = 0;
+  if (T >= 8 && fr.size() <= 6) {
+    for (double f : fr) {
+      const int64_t u = std::max<int64_t>(1, int64_t(f * double(T) + 0.5));
+      if (used + u >= T) break;
+      out.push_back(u * unit);
+      used += u;
+    }
+  }
+  out.push_back(rows - used * unit);
+  return out;
+}
+
+// The side stream of the piped launch (CCZ_SPLIT_PIPE), confined to a few CUs of every XCD when the runtime takes a CU mask: the
+// MFMA kernel's workgroups take whole CUs (512 VGPRs per lane, 128 KiB of LDS), so without the mask the small workgroups of the pass
+// fill every CU that frees up and the two kernels run one after the other.
+// CCZ_SPLIT_PIPE_CUS: CUs of the side stream (default 64 = 8 per XCD; 0: no mask).  nullptr: no second stream (one piece then).
+static hipStream_t split_side_stream(ccz_ctx* c) {
+  Impl* im = impl(c);
+  const int ncu = std::max(1, im->props.multiProcessorCount);
+  const char* e = getenv("CCZ_SPLIT_PIPE_CUS");                  // read per call (an A/B switch): a new width makes a new stream
+  const int cus = e ? atoi(e) : 64;
+  if (im->split_stream_tried && cus == im->split_stream_req) return im->split_stream;
+  if (im->split_stream) {
+    (void)hipStreamSynchronize(im->split_stream);
+    (void)hipStreamDestroy(im->split_stream);
+    im->split_stream = nullptr;
+  }
+  im->split_stream_tried = true;
+  im->split_stream_req = cus;
+  im->split_stream_cus = 0;
+  hipStream_t st = nullptr;
+  if (cus > 0 && cus < ncu && ncu % 8 == 0) {
+    // bit i set iff (i / 8) % stride == 0: 8-bit groups, every stride-th one -- uniform over the XCDs whether the runtime deals the
+    // mask's bits round-robin over the XCDs (bit i -> XCD i % 8) or XCD by XCD
+    const int stride = std::max(1, ncu / cus);
+    std::vector<uint32_t> mask(size_t((ncu + 31) / 32), 0u);
+    int set = 0;
+    for (int i = 0; i < ncu; ++i)
+      if ((i / 8) % stride == 0) { mask[size_t(i >> 5)] |= 1u << (i & 31); ++set; }
+    if (hipExtStreamCreateWithCUMask(&st, uint32_t(mask.size()), mask.data()) == hipSuccess) im->split_stream_cus = set;
+    else { (void)hipGetLastError(); st = nullptr; }
+  }
+  if (!st && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); st = nullptr; }
+  im->split_stream = st;
+  return st;
+}
+
 // G (upper tiles) += sum over rows of d d' for d = x - pilot (pilot may be null: d = x), through the split-bf16 route;
 // colsum (may be null) += the exact fp64 column sums of x, gathered by the split pass on its way over the rows.
 // Everything is enqueued on the handle's stream; with time_it the three stages are timed with HIP events (one host wait per
@@ -504,7 +577,10 @@ void gram_split_f32(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
   double* msq = static_cast<double*>(dev_alloc(c, size_t(D) * 8));
   char* planes = nullptr;
   float* partial = nullptr;
+  bool side_busy = false;                  // split passes enqueued on the side stream that the main stream has not waited for yet
   auto release = [&] {
+    // (unwinding between the side stream's launches and the main stream's waits: the pool recycles in the order of the MAIN stream)
+    if (side_busy && im->split_stream) (void)hipStreamSynchronize(im->split_stream);
     if (partial) dev_free(c, partial);
     if (planes) dev_free(c, planes);
     dev_free(c, msq);
@@ -522,10 +598,6 @@ void gram_split_f32(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
     launch_rows = ((n + n_launch - 1) / n_launch + SP_K - 1) / SP_K * SP_K;       // equal super-chunks
     const size_t fifo_bytes = size_t(SP_NST) * SP_STAGE;
     sp_allow_lds(reinterpret_cast<const void*>(&k_gram_bf16x2), c->device, int(fifo_bytes));
-    if (time_it) {
-      for (auto& e : im->sp_ev)
-        if (!e) CCZ_HIP(hipEventCreate(&e));
-    }
     c->last_split_ms = c->last_mfma_ms = c->last_reduce_ms = 0.0;
     size_t planes_cap = 0, partial_cap = 0;
     bool launched = false;
@@ -533,36 +605,89 @@ void gram_split_f32(ccz_ctx* c, const ccz_view* views, int n_views, int64_t n, d
     try {
     for (int64_t r0 = 0; r0 < n; r0 += launch_rows) {
       const int64_t rows = std::min(launch_rows, n - r0);
-      const int64_t ksteps = (rows + SP_K - 1) / SP_K;
-      const SplitRowPlan rp = split_row_plan(ksteps, ntiles, max_steps, ncu);
-      const int64_t steps_per_wg = rp.steps_per_wg, ksplit = rp.ksplit, nblocks = rp.nblocks;
-      const int per_xcd = rp.per_xcd;
-      const size_t planes_bytes = size_t(np) * size_t(ksteps) * SP_PSTEP;
-      const size_t partial_bytes = size_t(ksplit) * size_t(ntiles) * (SP_T * SP_T * 4);
+      // row pieces of this super-chunk: the split pass of piece p + 1 runs on the side stream under the MFMA kernel of piece p
+      std::vector<int64_t> piece_rows = split_pieces(rows, max_steps * SP_K);
+      hipStream_t side = piece_rows.size() > 1 ? split_side_stream(c) : nullptr;
+      if (!side) piece_rows.assign(1, rows);
+      const int npc = int(piece_rows.size());
+      struct Piece { int64_t r0, rows, ksteps, slice0; size_t planes_off; SplitRowPlan rp; };
+      std::vector<Piece> pcs;
+      pcs.resize(size_t(npc));
+      size_t planes_bytes = 0;
+      int64_t slices = 0;
+      {
+        int64_t off = 0;
+        for (int p = 0; p < npc; ++p) {
+          Piece& pc = pcs[size_t(p)];
+          pc.r0 = r0 + off;
+          pc.rows = piece_rows[size_t(p)];
+          pc.ksteps = (pc.rows + SP_K - 1) / SP_K;
+          pc.rp = split_row_plan(pc.ksteps, ntiles, max_steps, ncu);
+          pc.planes_off = planes_bytes;
+          pc.slice0 = slices;
+          planes_bytes += size_t(np) * size_t(pc.ksteps) * SP_PSTEP;
+          slices += pc.rp.ksplit;
+          off += pc.rows;
+        }
+      }
+      const size_t partial_bytes = size_t(slices) * size_t(ntiles) * (SP_T * SP_T * 4);
       if (planes_bytes > planes_cap) { if (planes) dev_free(c, planes); planes = static_cast<char*>(dev_alloc(c, planes_bytes)); planes_cap = planes_bytes; }
       if (partial_bytes > partial_cap) { if (partial) dev_free(c, partial); partial = static_cast<float*>(dev_alloc(c, partial_bytes)); partial_cap = partial_bytes; }
-      launched = true;                     // (from here on the super-chunks are no larger than this one: no further allocation)
-      zero(c, msq, size_t(D) * 8);
-      if (time_it) CCZ_HIP(hipEventRecord(im->sp_ev[0], st));
-      {
-        launch_split_pass(c, tb, vws, aligned, r0, rows, ksteps, pilot, planes, msq, colsum);
+      // events: [0] before split 0, [1] after it (the side stream's go-ahead), [4p + 2] after the MFMA kernel of piece p; per piece
+      // p >= 1: [4p - 1] / [4p] before / after its split (side stream), [4p + 1] after the main stream's wait; [4 npc - 1] after the reduce
+      const size_t nev = size_t(4 * npc);
+      while (im->sp_ev.size() < nev) {
+        hipEvent_t e = nullptr;
+        CCZ_HIP(hipEventCreate(&e));
+        im->sp_ev.push_back(e);
       }
-      if (time_it) CCZ_HIP(hipEventRecord(im->sp_ev[1], st));
-      hipLaunchKernelGGL(k_gram_bf16x2, dim3((unsigned)nblocks), dim3(256), fifo_bytes, st, d_tiles, ntiles, per_xcd, ksplit, planes, ksteps,
-                         steps_per_wg, partial);
-      if (time_it) CCZ_HIP(hipEventRecord(im->sp_ev[2], st));
-      hipLaunchKernelGGL(k_split_reduce, dim3(64, (unsigned)ntiles), dim3(256), 0, st, partial, d_tiles, ntiles, ksplit, G, D, msq);
+      hipEvent_t* ev = im->sp_ev.data();
+      launched = true;                     // (from here on the super-chunks are no larger than this one: no further allocation)
+      side_busy = side != nullptr;
+      zero(c, msq, size_t(D) * 8);
+      if (time_it) CCZ_HIP(hipEventRecord(ev[0], st));
+      launch_split_pass(c, tb, vws, aligned, pcs[0].r0, pcs[0].rows, pcs[0].ksteps, pilot, planes, msq, colsum, st);
+      if (time_it || side) CCZ_HIP(hipEventRecord(ev[1], st));
+      if (side) {
+        // (the go-ahead also orders the side stream behind the zeroing of msq, the pilot and the previous super-chunk's readers of `planes`)
+        CCZ_HIP(hipStreamWaitEvent(side, ev[1], 0));
+        for (int p = 1; p < npc; ++p) {
+          const Piece& pc = pcs[size_t(p)];
+          if (time_it) CCZ_HIP(hipEventRecord(ev[4 * p - 1], side));
+          launch_split_pass(c, tb, vws, aligned, pc.r0, pc.rows, pc.ksteps, pilot, planes + pc.planes_off, msq, colsum, side);
+          CCZ_HIP(hipEventRecord(ev[4 * p], side));
+        }
+      }
+      for (int p = 0; p < npc; ++p) {
+        const Piece& pc = pcs[size_t(p)];
+        if (p > 0) {
+          CCZ_HIP(hipStreamWaitEvent(st, ev[4 * p], 0));
+          if (time_it) CCZ_HIP(hipEventRecord(ev[4 * p + 1], st));
+        }
+        hipLaunchKernelGGL(k_gram_bf16x2, dim3((unsigned)pc.rp.nblocks), dim3(256), fifo_bytes, st, d_tiles, ntiles, pc.rp.per_xcd, pc.rp.ksplit,
+                           planes + pc.planes_off, pc.ksteps, pc.rp.steps_per_wg, partial + pc.slice0 * int64_t(ntiles) * (SP_T * SP_T));
+        if (time_it) CCZ_HIP(hipEventRecord(ev[4 * p + 2], st));
+      }
+      side_busy = false;                   // (the main stream has waited for every split pass of the side stream)
+      hipLaunchKernelGGL(k_split_reduce, dim3(64, (unsigned)ntiles), dim3(256), 0, st, partial, d_tiles, ntiles, slices, G, D, msq);
       CCZ_LAUNCH_CHECK();
       if (time_it) {
-        CCZ_HIP(hipEventRecord(im->sp_ev[3], st));
-        CCZ_HIP(hipEventSynchronize(im->sp_ev[3]));
-        float a = 0.f, b = 0.f, d = 0.f;
-        CCZ_HIP(hipEventElapsedTime(&a, im->sp_ev[0], im->sp_ev[1]));
-        CCZ_HIP(hipEventElapsedTime(&b, im->sp_ev[1], im->sp_ev[2]));
-        CCZ_HIP(hipEventElapsedTime(&d, im->sp_ev[2], im->sp_ev[3]));
+        hipEvent_t last = ev[4 * npc - 1];
+        CCZ_HIP(hipEventRecord(last, st));
+        CCZ_HIP(hipEventSynchronize(last));
+        float a = 0.f;
+        CCZ_HIP(hipEventElapsedTime(&a, ev[0], ev[1]));
         c->last_split_ms += a;
-        c->last_mfma_ms += b;
-        c->last_reduce_ms += d;
+        CCZ_HIP(hipEventElapsedTime(&a, ev[1], ev[2]));
+        c->last_mfma_ms += a;
+        for (int p = 1; p < npc; ++p) {
+          CCZ_HIP(hipEventElapsedTime(&a, ev[4 * p - 1], ev[4 * p]));
+          c->last_split_ms += a;             // (under the previous piece's MFMA kernel: the stage times of a piped launch overlap)
+          CCZ_HIP(hipEventElapsedTime(&a, ev[4 * p + 1], ev[4 * p + 2]));
+          c->last_mfma_ms += a;
+        }
+        CCZ_HIP(hipEventElapsedTime(&a, ev[4 * (npc - 1) + 2], last));
+        c->last_reduce_ms += a;
       }
     }
     } catch (const Error& e) {

@@ -77,7 +77,13 @@ struct Impl {
   void* chain_dbg = nullptr;             // CCZ_CHAIN_DEBUG stamps
   struct K1Plan { uint64_t key; void* dev; int wgs; };
   std::vector<K1Plan> k1_plans;          // gram.hip: per-tile row splits of k_gram_f32_fifo_small, by batch shape
-  hipEvent_t sp_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // gram_split.hip: stage boundaries of a timed split-route launch
+  // gram_split.hip: stage boundaries and hand-overs of a split-route launch (grown on demand), and the side stream the split pass
+  // of the NEXT row piece runs on under the MFMA kernel of the current one (CU-masked when the runtime allows; created on first use)
+  std::vector<hipEvent_t> sp_ev;
+  hipStream_t split_stream = nullptr;
+  bool split_stream_tried = false;
+  int split_stream_req = 0;              // CCZ_SPLIT_PIPE_CUS the side stream was made for
+  int split_stream_cus = 0;              // CUs the side stream is confined to (0: no mask)
   struct SplitTab { uint64_t key; void* panels; void* tiles; void* gtiles; int np, ntiles; };
   std::vector<SplitTab> split_tabs;      // gram_split.hip: panel / tile tables by view widths (pointer-free: uploaded once per shape)
   std::vector<std::pair<void*, void*>> colsum_sync;   // gram.hip: per-stream arrival counters of k_colsum_pilot (64 words each, zero between launches)

@@ -142,6 +142,28 @@ def test_split_route_row_super_chunks_and_accumulate(H, monkeypatch):
     np.testing.assert_allclose(s, sa + sb, rtol=1e-12, atol=1e-7)
 
 
+@pytest.mark.parametrize("cus", ["64", "0"])
+@pytest.mark.parametrize("scratch_gb", [None, "0.02"])
+def test_split_route_piped_launch_is_opt_in_and_matches(H, monkeypatch, cus, scratch_gb):
+    """CCZ_SPLIT_PIPE (an A/B switch, off by default: DESIGN section 7 item 2): the launch cut into row pieces, the split pass of the
+    next piece on the (CU-masked or plain) side stream under the MFMA kernel of the current one -- same moments and column sums as the
+    one-piece launch, also across row super-chunks."""
+    monkeypatch.setenv("CCZ_SPLIT_ROWS", "256")
+    if scratch_gb:
+        monkeypatch.setenv("CCZ_SPLIT_SCRATCH_GB", scratch_gb)
+    views = _latent(9000, [300, 200], seed=31, shift=2.0)
+    Gr, sr = _ref(views)
+    G1, s1, taken, _ = _moments(H, views, "bf16x2")
+    assert taken == "bf16x2" and _rel(G1, Gr) < 2e-6
+    monkeypatch.setenv("CCZ_SPLIT_PIPE", "0.1,0.3")
+    monkeypatch.setenv("CCZ_SPLIT_PIPE_CUS", cus)
+    G2, s2, taken, _ = _moments(H, views, "bf16x2")
+    assert taken == "bf16x2" and _rel(G2, Gr) < 2e-6
+    iu = np.triu_indices(G1.shape[0])
+    np.testing.assert_allclose(G2[iu], G1[iu], rtol=0, atol=2e-6 * np.abs(np.diag(Gr)).max())
+    np.testing.assert_allclose(s2, sr, rtol=1e-12, atol=1e-7)
+
+
 def test_split_route_host_views_streamed(H, monkeypatch):
     """Pageable host inputs: every streamed chunk takes the split route (its own pilot), strided view included."""
     monkeypatch.setenv("CCZ_H2D_CHUNK_MB", "8")
