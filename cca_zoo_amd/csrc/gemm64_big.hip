@@ -305,6 +305,179 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64_half(int64_t M, int64_t N, 
     }
 }
 
+// ---------------------------------------------------------------------------
+// Round 6: both tiles on ONE software-pipelined loop (k_gemm_f64_pipe<TA, TB, TM>, TM = 128 or 64).  The kernels above keep a
+// k-block's MFMA stream apart from its staging: loads at the top, 64 (32) MFMAs, `s_waitcnt vmcnt(0)`, transposing ds_writes,
+// `s_waitcnt lgkmcnt(0)`, barrier, and the next block starts with the latency of its first fragment reads -- 400 - 500 idle
+// cycles per 4096 (2048) MFMA cycles with one workgroup per CU, and two workgroups per CU fall into step.  Measured with
+// tools/gemm64_probe.py (profiles/r06_gemm64_probe.log): steady state 77 % (one workgroup per CU) / 84 % (two) of the fp64 matrix
+// peak against rocBLAS' 92 / 98 %.  Here the staging rides INSIDE the MFMA stream (an fp64 MFMA holds the pipe for 64 cycles: every
+// one of them hides a few other instructions):
+//   kk = 0:  fragments of kk = 1 from LDS                                              | 16 (8) MFMAs of kk = 0
+//   kk = 1:  fragments of kk = 2; registers (block kb + 1) -> the other LDS buffer;     | MFMAs of kk = 1
+//            global loads of block kb + 2 into the same registers (a whole block of latency budget)
+//   kk = 2:  fragments of kk = 3                                                       | MFMAs of kk = 2
+//            s_waitcnt lgkmcnt(0); s_barrier   (everybody's writes have landed; nobody reads this block's buffer any more)
+//   kk = 3:  fragments of kk = 0 of block kb + 1 from the other buffer                 | MFMAs of kk = 3
+// One barrier per k-block, never followed by a latency the MFMA pipe has to wait out; global loads stay in flight across it.
+// ---------------------------------------------------------------------------
+template <bool TA, bool TB, int TM>
+__global__ __launch_bounds__(256, 2) void k_gemm_f64_pipe(int64_t M, int64_t N, int64_t K, double alpha,
+                                                          const double* __restrict__ A, int64_t lda,
+                                                          const double* __restrict__ B, int64_t ldb, double beta,
+                                                          double* __restrict__ C, int64_t ldc, int lower_only,
+                                                          int64_t k_per_split) {
+  constexpr int WN = TM == 128 ? 64 : 32;     // columns of a wave
+  constexpr int NB = WN / 16;                 // its MFMA tiles along N (4 or 2); along M always 4
+  constexpr int SA = TM + 2;                  // row stride of the A image (doubles)
+  constexpr int BUF = DK * (SA + DS);
+  constexpr int NSTG = TM / 32 + DT / 32;     // 16-byte global loads (and LDS write instructions) of a thread per k-block: 8 or 6
+  extern __shared__ __attribute__((aligned(16))) char smem_p[];
+  double* lds = reinterpret_cast<double*>(smem_p);   // [2 buffers][A: 16 x SA | B: 16 x DS]
+  const int64_t m0 = int64_t(blockIdx.y) * TM, n0 = int64_t(blockIdx.x) * DT;
+  if (lower_only && n0 > m0 + (TM - 1)) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int a_off = TM == 128 ? (wave >> 1) * 64 : 0;
+  const int b_off = TM == 128 ? (wave & 1) * 64 : wave * 32;
+
+  v4f64 acc[4][NB];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
+
+  StagerW<TA, TM> sa;
+  StagerW<!TB, DT> sb;
+  const bool split = gridDim.z > 1;
+  const int64_t kz0 = int64_t(blockIdx.z) * k_per_split;
+  const int64_t nkb = (min(K, kz0 + k_per_split) - kz0) / DK;
+  if (nkb <= 0) return;
+
+  // fragment of k-group kk: 4 consecutive rows of A (MFMA tile ti owns the rows == ti mod 4 of the wave's 64), NB consecutive
+  // columns of B, at k = 4 kk + lane / 16
+  auto rd = [&](const double* as, int kk, double (&a4)[4], double (&b4)[NB]) {
+    const int krow = 4 * kk + (lane >> 4);
+    const double* ap = as + krow * SA + a_off + 4 * (lane & 15);
+    const v2f64 a01 = *reinterpret_cast<const v2f64*>(ap), a23 = *reinterpret_cast<const v2f64*>(ap + 2);
+    a4[0] = a01[0]; a4[1] = a01[1]; a4[2] = a23[0]; a4[3] = a23[1];
+    const double* bp = as + DK * SA + krow * DS + b_off + NB * (lane & 15);
+    const v2f64 b01 = *reinterpret_cast<const v2f64*>(bp);
+    b4[0] = b01[0]; b4[1] = b01[1];
+    if constexpr (NB == 4) {
+      const v2f64 b23 = *reinterpret_cast<const v2f64*>(bp + 2);
+      b4[2] = b23[0]; b4[3] = b23[1];
+    }
+  };
+  auto mm = [&](const double (&a4)[4], const double (&b4)[NB]) {
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < NB; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[ti], b4[tj], acc[ti][tj], 0, 0, 0);
+  };
+
+  sa.load(A, lda, m0, M, kz0, tid);
+  sb.load(B, ldb, n0, N, kz0, tid);
+  sa.store(lds, SA, tid);
+  sb.store(lds + DK * SA, DS, tid);
+  if (nkb > 1) {
+    sa.load(A, lda, m0, M, kz0 + DK, tid);
+    sb.load(B, ldb, n0, N, kz0 + DK, tid);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  double fa[2][4], fb[2][NB];
+  rd(lds, 0, fa[0], fb[0]);
+  for (int64_t kb = 0; kb < nkb; ++kb) {
+    const double* as = lds + int(kb & 1) * BUF;
+    double* nx = lds + int((kb + 1) & 1) * BUF;
+    // kk = 0
+    rd(as, 1, fa[1], fb[1]);
+    mm(fa[0], fb[0]);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // (the next group's fragment reads right behind the first MFMA)
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 4 * NB - 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // kk = 1
+    rd(as, 2, fa[0], fb[0]);
+    // (branch-free, so that the staging stays inside the MFMA stream: past the end the registers are stored once more into a
+    // buffer nobody reads again, and the last block is loaded once more)
+    sa.store(nx, SA, tid);
+    sb.store(nx + DK * SA, DS, tid);
+    {
+      const int64_t kl = kz0 + min(kb + 2, nkb - 1) * DK;
+      sa.load(A, lda, m0, M, kl, tid);
+      sb.load(B, ldb, n0, N, kl, tid);
+    }
+    mm(fa[1], fb[1]);
+    // issue order of this group: the fragment reads, then one ds_write behind each of the first MFMAs, then the global loads behind
+    // the following ones (the scheduler would otherwise issue all of the staging in one run in front of the 16 MFMAs)
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+    for (int i = 0; i < 4 * NB; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (i < NSTG) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      else if (NB == 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      else __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // kk = 2
+    rd(as, 3, fa[1], fb[1]);
+    mm(fa[0], fb[0]);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 4 * NB - 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // kk = 3
+    rd(nx, 0, fa[0], fb[0]);                 // (after the last block: stale fragments, never used)
+    mm(fa[1], fb[1]);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 4 * NB - 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  // f64 16x16 C/D layout: col (B side) = lane & 15, row (A side) = (lane >> 4) + 4 * reg
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t m = m0 + a_off + 4 * ((lane >> 4) + 4 * r) + ti;
+      if (m >= M) continue;
+      const int64_t nb = n0 + b_off + NB * (lane & 15);
+      double* cp = C + m * ldc + nb;
+      if (split) {
+#pragma unroll
+        for (int tj = 0; tj < NB; ++tj)
+          if (nb + tj < N) unsafeAtomicAdd(cp + tj, alpha * acc[ti][tj][r]);
+      } else if (nb + NB - 1 < N) {
+        double v[NB];
+#pragma unroll
+        for (int tj = 0; tj < NB; ++tj) v[tj] = alpha * acc[ti][tj][r];
+        if (beta != 0.0) {
+#pragma unroll
+          for (int q = 0; q < NB; q += 2) {
+            const v2f64 c01 = *reinterpret_cast<const v2f64*>(cp + q);
+            v[q] += beta * c01[0];
+            v[q + 1] += beta * c01[1];
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < NB; q += 2) *reinterpret_cast<v2f64*>(cp + q) = v2f64{v[q], v[q + 1]};
+      } else {
+#pragma unroll
+        for (int tj = 0; tj < NB; ++tj)
+          if (nb + tj < N) {
+            double v = alpha * acc[ti][tj][r];
+            if (beta != 0.0) v += beta * cp[tj];
+            cp[tj] = v;
+          }
+      }
+    }
+}
+
 // Round 3 tried the wave-private LDS-DMA FIFO of K1 on the A B' shape of the Cholesky updates and forward triangular
 // solves (lane l of a 16-row MFMA tile loads X[16 t + (l & 15)][k0 + 2 (l >> 4) .. + 1] as one 16-byte
 // buffer_load ... lds; no barriers, no transposing scatter, 8 DMA + 8 ds_read_b128 per 32 MFMAs).  Correct, and SLOWER than
@@ -349,12 +522,50 @@ void gemm_f64_big(ccz_ctx* c, bool tA, bool tB, int64_t M, int64_t N, int64_t K,
   const int64_t tm = (M + DT - 1) / DT, tn = (N + DT - 1) / DT;
   const int ncu = std::max(1, impl(c)->props.multiProcessorCount);
   int splits = 1;
-  if (!lower_only && tm * tn < 2 * int64_t(ncu) && K >= 2048) {
+  // (split-K with an fp64-atomic epilogue only where the tiles leave at least half of the chip idle: at one workgroup per CU the
+  // pipelined kernel runs at 0.89 of the peak, and a 256-tile product measured 541 us split four ways against 272 us for rocBLAS)
+  static const int64_t pipe_sel = env_ll("CCZ_GEMM64_PIPE", 1);
+  if (!lower_only && tm * tn * (pipe_sel ? 2 : 1) < 2 * int64_t(ncu) && K >= 2048) {
     splits = int(std::min<int64_t>({int64_t(16), (4 * ncu) / (tm * tn), K / 512}));
     if (splits < 2) splits = 1;
   }
   static const int64_t half_on = env_ll("CCZ_GEMM_HALF_TILE", 1);
-  if (half_on && splits == 1 && !lower_only && tm * tn < int64_t(ncu) && M > HM) {
+  static const int64_t pipe_on = env_ll("CCZ_GEMM64_PIPE", 1);      // 0: the round-2 kernels (A/B)
+  const bool use_half = half_on && splits == 1 && !lower_only && tm * tn < int64_t(ncu) && M > HM;
+  if (pipe_on) {
+    int64_t kps = K;
+    if (splits > 1) {
+      kps = ((K + splits - 1) / splits + DK - 1) / DK * DK;
+      splits = int((K + kps - 1) / kps);
+      const int64_t total = M * N;
+      hipLaunchKernelGGL(k_scale2d_f64, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 1 << 20)), dim3(256), 0, st,
+                         total, N, C, ldc, beta);
+    }
+    const int lo = lower_only ? 1 : 0;
+#define CCZ_LAUNCH_PIPE(TA_, TB_, TM_)                                                                                  \
+  do {                                                                                                                  \
+    const size_t lds_p = size_t(2) * DK * ((TM_) + 2 + DS) * 8;                                                         \
+    const dim3 gridp((unsigned)tn, (unsigned)((M + (TM_) - 1) / (TM_)), (unsigned)splits);                              \
+    CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_f64_pipe<TA_, TB_, TM_>),                         \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_p)));                               \
+    hipLaunchKernelGGL((k_gemm_f64_pipe<TA_, TB_, TM_>), gridp, dim3(256), lds_p, st, M, N, K, alpha, A, lda, B, ldb,   \
+                       beta, C, ldc, lo, kps);                                                                          \
+  } while (0)
+#define CCZ_LAUNCH_PIPE_T(TM_)                              \
+  do {                                                      \
+    if (!tA && !tB) CCZ_LAUNCH_PIPE(false, false, TM_);     \
+    else if (tA && !tB) CCZ_LAUNCH_PIPE(true, false, TM_);  \
+    else if (!tA && tB) CCZ_LAUNCH_PIPE(false, true, TM_);  \
+    else CCZ_LAUNCH_PIPE(true, true, TM_);                  \
+  } while (0)
+    if (use_half) CCZ_LAUNCH_PIPE_T(64);
+    else CCZ_LAUNCH_PIPE_T(128);
+#undef CCZ_LAUNCH_PIPE_T
+#undef CCZ_LAUNCH_PIPE
+    CCZ_LAUNCH_CHECK();
+    return;
+  }
+  if (use_half) {
     const size_t lds_h = size_t(2) * DK * (HSA + DS) * 8;    // 49 KiB
     dim3 gridh((unsigned)tn, (unsigned)((M + HM - 1) / HM), 1);
 #define CCZ_LAUNCH_HALF(TA_, TB_)                                                                                     \

@@ -410,7 +410,8 @@ static SplitRowPlan split_row_plan(int64_t ksteps, int ntiles, int64_t max_steps
   rp.steps_per_wg = (ksteps + best_k - 1) / best_k;
   rp.ksplit = (ksteps + rp.steps_per_wg - 1) / rp.steps_per_wg;
   const bool sliced = int64_t(ntiles) * rp.ksplit >= 16 * int64_t(ncu);
-  const bool xchunks = sliced && rp.ksplit % 8 == 0;
+  const char* e_walk = getenv("CCZ_SPLIT_WALK");          // A/B: 1 = every XCD on the SAME row chunk (slices of the tile list) also when ksplit % 8 == 0
+  const bool xchunks = sliced && rp.ksplit % 8 == 0 && !(e_walk && atoi(e_walk) == 1);
   rp.per_xcd = xchunks ? -1 : (sliced ? (ntiles + 7) / 8 : 0);
   rp.nblocks = xchunks ? int64_t(ntiles) * rp.ksplit : (sliced ? int64_t(8) * rp.per_xcd * rp.ksplit : int64_t(ntiles) * rp.ksplit);
   if (rp.nblocks > 0x7fffffffLL) fail(CCZ_EUNSUP, "gram (split route): grid too large");

@@ -48,6 +48,11 @@ def one(M, N, K, tA=False, tB=True, iters=20):
 
 
 if __name__ == "__main__":
+    # ragged edges, all four transposition pairs, one and three k-blocks (correctness of the tile loop's ends)
+    for tA in (False, True):
+        for tB in (False, True):
+            for M, N, K in [(1111, 999, 16), (1111, 999, 48), (1400, 1290, 144), (4001, 515, 512), (130, 4097, 64)]:
+                one(M, N, K, tA, tB, iters=3)
     # triangular-solve / Cholesky-update shapes of the 2 x 4096 rCCA solve and the D = 16384 GCCA solve
     for M, N, K in [(4096, 512, 512), (4096, 3584, 512), (4096, 2048, 512), (4096, 1024, 512), (3584, 3584, 512), (2048, 2048, 512),
                     (16384, 512, 512), (16384, 8192, 512), (16384, 15872, 512), (4096, 4096, 4096)]:
