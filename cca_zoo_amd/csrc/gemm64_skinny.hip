@@ -13,6 +13,11 @@
 //   * LDS images chosen for conflict-free 8-byte fragment reads (k-major: row stride == 16 mod 32 doubles;
 //     m-major: [m][18]), fragments of k-step kk+1 fetched under the MFMAs of step kk.
 // Measured 52 TFLOP/s at 16384^2 x 160 (a pure-MFMA loop sustains 72-75 on this part; tools/mfma_probe.hip).
+// Round 6 built the loop of k_gemm_f64_pipe (gemm64_big.hip) for this shape too -- 128-row stripes, two MFMA row tiles per wave
+// sharing every B fragment, register stage -> LDS and the buffer loads interleaved into the MFMA stream, one barrier per k-block --
+// and measured it against this kernel (tools/gemm64_probe.py skinny): 4096^2 x 80 67.9 vs 69.9 us, 8192^2 x 80 227 vs 225 us,
+// 16384^2 x 160 1556 vs 1558 us (1355 vs 1327 transposed), and SLOWER on ragged or short products (5000 x 80 x 4096: 98 vs 74 us --
+// half as many stripes to spread).  The barrier bubble is not what holds this kernel: it was dropped again (not in the tree).
 #include <algorithm>
 #include <cstdlib>
 

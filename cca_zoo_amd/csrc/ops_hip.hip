@@ -2099,9 +2099,14 @@ __global__ __launch_bounds__(1024) void k_syev_small_wide(int d, const double* _
 // with a global store in flight (the rotation log) every wave would wait for its acknowledgement (~1 us) at every
 // barrier of the round loop.  The log is consumed by a later kernel, so only this wave's LDS operations must have
 // completed before the barrier.
+// sync (may be null): two agent-scope words for the replaying workgroups of the SAME launch (k_syev_chase below) --
+//   sync[0] = rounds whose parameters are complete in the log (moved every JR_CHUNK rounds), sync[1] = 1 + rounds to replay once the
+//   solve has ended (any way it ends).  The log is stored write-through (st_shared2) so that another XCD's workgroup can read it.
+constexpr int JR_CHUNK = 16;                                  // rounds of parameters staged through LDS at a time
 template <int NB_>
 __device__ __forceinline__ void syev_packed_body(char* smem, int d, const double* __restrict__ A, int64_t lda, double* __restrict__ w,
-                                                 jac_cs* __restrict__ log, double tol, int max_sweeps, int* __restrict__ status) {
+                                                 jac_cs* __restrict__ log, double tol, int max_sweeps, int* __restrict__ status,
+                                                 unsigned* __restrict__ sync = nullptr) {
   const int pe = (d + 1) & ~1, m1 = pe - 1, np = pe >> 1;
   const int nH = pe * (pe + 1) / 2, nHp = (nH + 1) & ~1;
   double* Hs = reinterpret_cast<double*>(smem);
@@ -2129,12 +2134,18 @@ __device__ __forceinline__ void syev_packed_body(char* smem, int d, const double
   double hmax = 0.0;
   for (int i = 0; i < (nt + 63) >> 6; ++i) hmax = fmax(hmax, red[i]);
   if (!(hmax < __builtin_inf())) {
-    if (tid == 0) { status[0] = -2; status[1] = 0; }
+    if (tid == 0) {
+      status[0] = -2; status[1] = 0;
+      if (sync) __hip_atomic_store((gu32_ptr)(reinterpret_cast<uintptr_t>(sync + 1)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     return;
   }
   if (hmax == 0.0) {
     for (int i = tid; i < d; i += nt) w[i] = 0.0;
-    if (tid == 0) { status[0] = 1; status[1] = 0; }
+    if (tid == 0) {
+      status[0] = 1; status[1] = 0;
+      if (sync) __hip_atomic_store((gu32_ptr)(reinterpret_cast<uintptr_t>(sync + 1)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     return;
   }
   const double thr = tol * hmax, ih = 1.0 / hmax;
@@ -2159,7 +2170,7 @@ __device__ __forceinline__ void syev_packed_body(char* smem, int d, const double
       atomicAdd(rot + sweep_parity, 1);
     }
     csn[buf * np + k] = r;
-    log[int64_t(glog) * np + k] = r;
+    st_shared2(reinterpret_cast<double*>(log + int64_t(glog) * np + k), r.x, r.y);
   };
   if (tid < np) params(0, 0, 1, 0);
   __syncthreads();
@@ -2201,18 +2212,28 @@ __device__ __forceinline__ void syev_packed_body(char* smem, int d, const double
         }
       }
       lds_barrier();
+      const bool publish = sync && ((g + 2) & (JR_CHUNK - 1)) == 0;      // rounds 0 .. g + 1 are in the log after this step
       if (tid < np) {
         const bool last = round + 1 == m1;
         params(last ? 0 : round + 1, (g & 1) ^ 1, last ? (par ^ 1) : par, g + 1);
+        if (publish) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the writing lanes drain their write-through stores)
       }
       lds_barrier();
+      if (publish && tid == 0)
+        __hip_atomic_store((gu32_ptr)(reinterpret_cast<uintptr_t>(sync)), unsigned(g + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     done = (rot[par] == 0);
     lds_barrier();
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int i = tid; i < d; i += nt) w[i] = Hs[tri_off(i, i)];
-  if (tid == 0) { status[0] = done ? sweep : -1; status[1] = g; }
+  if (tid == 0) {
+    status[0] = done ? sweep : -1; status[1] = g;
+    // the last sweep of a converged run rotated nothing: the log's first (sweeps - 1) * m1 rounds are all of V
+    if (sync) __hip_atomic_store((gu32_ptr)(reinterpret_cast<uintptr_t>(sync + 1)), 1u + unsigned(done ? (sweep - 1) * m1 : 0), __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 __global__ __launch_bounds__(1024) void k_syev_packed1(int d, const double* __restrict__ A, int64_t lda, double* __restrict__ w,
@@ -2232,7 +2253,6 @@ __global__ __launch_bounds__(1024) void k_syev_packed4(int d, const double* __re
 }
 
 constexpr int JR_COLS = 16, JR_SLOTS = 16, JR_MAXK = 5;      // 256 threads: 16 columns x 16 pair slots, np <= 80
-constexpr int JR_CHUNK = 16;                                  // rounds of parameters staged through LDS at a time
 __global__ __launch_bounds__(256) void k_jacobi_replay(int d, const jac_cs* __restrict__ log, int rounds, double* __restrict__ Vt,
                                                        int64_t ldv) {
   __shared__ double Vs[160 * (JR_COLS + 1)];
@@ -2302,6 +2322,105 @@ __global__ __launch_bounds__(256) void k_jacobi_replay(int d, const jac_cs* __re
     for (int r = slot; r < d; r += JR_SLOTS) Vt[int64_t(r) * ldv + col0 + col] = Vs[r * (JR_COLS + 1) + col];
 }
 
+// ---------------------------------------------------------------------------
+// Round 6: eigen-solve and replay as ONE launch (k_syev_chase).  The replay above starts when the solve has ended (and after a host
+// round trip for the sweep count): 367 + 294 us behind the 800 + 661 us of the two Rayleigh-Ritz solves of an rCCA fit.  A round of
+// the replay takes half the time of a round of the solve, so here the replaying workgroups run NEXT to the solving one and chase
+// its log chunk by chunk: workgroup 0 = syev_packed_body (log stored write-through, a progress word every 16 rounds), workgroups
+// 1 .. d / 16 = the replay on 16 columns of V' each (their first 256 threads; the rest retire at once), polling the progress word
+// and reading the log past their XCD's L2 (ld_shared).  V' is complete one chunk (~15 us) after the solve.  Every exit of the
+// solving workgroup publishes the end word; a poller that sees nothing for ~2 s gives up and reports -3.
+// ---------------------------------------------------------------------------
+constexpr int SC_WATCHDOG = 1 << 24;
+__device__ __forceinline__ void replay_chase_body(char* smem, int d, const jac_cs* __restrict__ log, unsigned* __restrict__ sync,
+                                                  double* __restrict__ Vt, int64_t ldv, int blk, int* __restrict__ status) {
+  double* Vs = reinterpret_cast<double*>(smem);                                  // [pe][JR_COLS + 1]
+  jac_cs* Ps = reinterpret_cast<jac_cs*>(Vs + 160 * (JR_COLS + 1));             // one chunk of (c, s)
+  int* ctl = reinterpret_cast<int*>(Ps + JR_CHUNK * 80);                         // [0] rounds of this chunk, [1] 1 = last chunk, 2 = gave up
+  const int pe = (d + 1) & ~1, m1 = pe - 1, np = pe >> 1;
+  const int tid = threadIdx.x, col = tid & (JR_COLS - 1), slot = tid >> 4;
+  const int col0 = blk * JR_COLS;
+  for (int e = tid; e < pe * JR_COLS; e += 256) {
+    const int r = e >> 4, cc = e & 15;
+    Vs[r * (JR_COLS + 1) + cc] = (r == col0 + cc && r < d) ? 1.0 : 0.0;
+  }
+  const gu32_ptr wP = (gu32_ptr)(reinterpret_cast<uintptr_t>(sync)), wF = (gu32_ptr)(reinterpret_cast<uintptr_t>(sync + 1));
+  int round = 0;
+  bool gave_up = false;
+  for (int ch = 0;; ++ch) {
+    const int base = ch * JR_CHUNK;
+    if (tid == 0) {
+      int n = 0, last = 0, spins = 0;
+      for (;;) {
+        const unsigned F = __hip_atomic_load(wF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (F != 0u) {
+          const int fin = int(F - 1u);
+          n = max(0, min(JR_CHUNK, fin - base));
+          last = base + JR_CHUNK >= fin ? 1 : 0;
+          break;
+        }
+        if (int(__hip_atomic_load(wP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= base + JR_CHUNK) { n = JR_CHUNK; break; }
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > SC_WATCHDOG) { n = 0; last = 2; break; }
+      }
+      ctl[0] = n;
+      ctl[1] = last;
+    }
+    __syncthreads();
+    const int n = ctl[0], last = ctl[1];
+    for (int e = tid; e < n * np; e += 256) {
+      const double* src = reinterpret_cast<const double*>(log + int64_t(base) * np + e);
+      jac_cs r;
+      r.x = ld_shared(src);
+      r.y = ld_shared(src + 1);
+      Ps[e] = r;
+    }
+    __syncthreads();
+    for (int rr = 0; rr < n; ++rr) {
+      int op[JR_MAXK], oq[JR_MAXK];
+      double x[JR_MAXK], y[JR_MAXK];
+      jac_cs cs[JR_MAXK];
+#pragma unroll
+      for (int j = 0; j < JR_MAXK; ++j) {
+        const int k = min(slot + JR_SLOTS * j, np - 1);
+        int p, q;
+        pair_of(round, k, m1, p, q);
+        op[j] = p * (JR_COLS + 1) + col;
+        oq[j] = q * (JR_COLS + 1) + col;
+        cs[j] = Ps[rr * np + k];
+        x[j] = Vs[op[j]];
+        y[j] = Vs[oq[j]];
+      }
+#pragma unroll
+      for (int j = 0; j < JR_MAXK; ++j)
+        if (slot + JR_SLOTS * j < np) {
+          Vs[op[j]] = cs[j].x * x[j] - cs[j].y * y[j];
+          Vs[oq[j]] = cs[j].y * x[j] + cs[j].x * y[j];
+        }
+      lds_barrier();
+      if (++round == m1) round = 0;
+    }
+    __syncthreads();                                           // (ctl and Ps are rewritten by the next chunk)
+    if (last) { gave_up = last == 2; break; }
+  }
+  if (gave_up) { if (tid == 0) status[0] = -3; return; }
+  if (col0 + col < d)
+    for (int r = slot; r < d; r += JR_SLOTS) Vt[int64_t(r) * ldv + col0 + col] = Vs[r * (JR_COLS + 1) + col];
+}
+
+template <int NB_>
+__global__ __launch_bounds__(1024) void k_syev_chase(int d, const double* __restrict__ A, int64_t lda, double* __restrict__ w,
+                                                     jac_cs* __restrict__ log, double tol, int max_sweeps, int* __restrict__ status,
+                                                     unsigned* __restrict__ sync, double* __restrict__ Vt, int64_t ldv) {
+  extern __shared__ __attribute__((aligned(16))) char jac_smem[];
+  if (blockIdx.x == 0) {
+    syev_packed_body<NB_>(jac_smem, d, A, lda, w, log, tol, max_sweeps, status, sync);
+    return;
+  }
+  if (threadIdx.x >= 256) return;                              // (retired waves do not take part in the barriers of the rest)
+  replay_chase_body(jac_smem, d, log, sync, Vt, ldv, int(blockIdx.x) - 1, status);
+}
+
 static size_t syev_small_lds(int64_t d) {
   const int64_t pe = (d + 1) & ~int64_t(1), np = pe / 2, sd = pe | 1;
   return size_t(2 * pe * sd + 18 + 4 * np) * 8;          // H, V', 16 maxima, 2 counters (+ pad), 2 x np (c, s)
@@ -2330,6 +2449,30 @@ int syev_small(ccz_ctx* c, const double* A, int64_t d, int64_t lda, double* w_de
       hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds_need, stream(c), int(d), A, lda, w_dev, log, 2.220446049250313e-16,
                          max_sweeps, im->d_flag + 2);
     };
+    static const int chase_on = [] { const char* e = getenv("CCZ_SYEV_CHASE"); return e ? atoi(e) : 1; }();
+    if (chase_on && Vrows) {
+      // one launch: the solve and, next to it, the replay chasing its log (k_syev_chase)
+      unsigned* sync = reinterpret_cast<unsigned*>(im->d_flag + 8);
+      CCZ_HIP(hipMemsetAsync(sync, 0, 2 * sizeof(unsigned), stream(c)));
+      const size_t lds_chase = std::max(lds_need, size_t(160 * (JR_COLS + 1) * 8 + JR_CHUNK * 80 * 16 + 16));
+      const dim3 grid(1u + unsigned((d + JR_COLS - 1) / JR_COLS));
+      auto launch2 = [&](auto kern) {
+        CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_chase)));
+        hipLaunchKernelGGL(kern, grid, dim3(1024), lds_chase, stream(c), int(d), A, lda, w_dev, log, 2.220446049250313e-16, max_sweeps,
+                           im->d_flag + 2, sync, Vrows, ldv);
+      };
+      if (nblk <= 1024) launch2(&k_syev_chase<1>);
+      else if (nblk <= 2048) launch2(&k_syev_chase<2>);
+      else launch2(&k_syev_chase<4>);
+      CCZ_LAUNCH_CHECK();
+      int st[2] = {0, 0};
+      d2h(c, st, im->d_flag + 2, sizeof(st));
+      sw = st[0];
+      if (sw == -3) fail(CCZ_EHIP, "syev: the replaying workgroups lost the solving one");
+      if (sw == -2) fail(CCZ_EINVAL, "syev: matrix has non-finite entries");
+      if (sw < 0) fail(CCZ_ENOCONV, "Jacobi did not converge in %d sweeps (d=%lld)", max_sweeps, (long long)d);
+      return sw;
+    }
     if (nblk <= 1024) launch(&k_syev_packed1);
     else if (nblk <= 2048) launch(&k_syev_packed2);
     else launch(&k_syev_packed4);

@@ -47,7 +47,18 @@ def one(M, N, K, tA=False, tB=True, iters=20):
     print(json.dumps(rec), flush=True)
 
 
+def skinny():
+    """tall-times-skinny products of the subspace iteration (k_gemm_f64_skinny / _skinny2): S X and S' X at the solver's shapes"""
+    for M, N, K in [(4096, 80, 4096), (8192, 80, 8192), (16384, 160, 16384), (4096, 64, 4096), (4096, 96, 4096), (4096, 128, 4096),
+                    (5000, 80, 4096), (4096, 160, 2048), (4098, 72, 1024), (16384, 176, 16384)]:
+        for tA in (False, True):
+            one(M, N, K, tA, False, iters=10)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "skinny":
+        skinny()
+        sys.exit(0)
     # ragged edges, all four transposition pairs, one and three k-blocks (correctness of the tile loop's ends)
     for tA in (False, True):
         for tB in (False, True):
