@@ -768,20 +768,25 @@ static void mcca_solve_impl(ccz_ctx* c, const double* mom, int64_t n, const int6
   std::vector<Whitener> F = make_whiteners(c, R, dimv, false);
   wait_deferred(c);
   // S = L^-1 (C - blockdiag C) L^-T,  zero diagonal blocks
+  // Whole block columns / block rows at a time (round 6): the m (m - 1) / 2 off-diagonal blocks used to be whitened one by one
+  // -- two triangular solves of d_i x d_j each, 84 launches of 40 - 78 us at 4 x 2048 that filled a quarter of the chip
+  // (profiles/r06_solve_timeline_mcca.md: 4.7 ms of a 21 ms solve).  All blocks above the diagonal of block column j share L_j, all
+  // blocks right of the diagonal of block row i share L_i: m - 1 solves with off[j] rows in place in S, then m - 1 with D - off[i + 1].
   DBuf S(c, D * D);
   fill2d(c, D, D, S, D, 0.0);
-  for (int i = 0; i < m; ++i) {
-    for (int j = i + 1; j < m; ++j) {
-      const int64_t di = dims[i], dj = dims[j];
-      DBuf Cij(c, di * dj);
-      cov_block(c, G, D, s, n, true, inv, off[i], di, off[j], dj, Cij, dj);
-      F[j].right_apply(c, di, Cij, dj, Cij, dj);                 // C_ij L_j^-T
-      DBuf Ct(c, dj * di);
-      transpose(c, di, dj, Cij, dj, Ct, di);
-      F[i].right_apply(c, dj, Ct, di, Ct, di);                   // (L_i^-1 C_ij L_j^-T)' = S_ji
-      copy2d(c, dj, di, Ct, di, S.get() + off[j] * D + off[i], D);
-      transpose(c, dj, di, Ct, di, S.get() + off[i] * D + off[j], D);
-    }
+  for (int j = 1; j < m; ++j) {
+    double* Uj = S.get() + off[j];                               // rows [0, off[j]) x columns of view j
+    cov_block(c, G, D, s, n, true, inv, 0, off[j], off[j], dims[j], Uj, D);
+    F[j].right_apply(c, off[j], Uj, D, Uj, D);                   // C_ij L_j^-T for every i < j
+  }
+  for (int i = 0; i + 1 < m; ++i) {
+    const int64_t di = dims[i], rest = D - off[i + 1];
+    double* Ri = S.get() + off[i] * D + off[i + 1];              // block row i right of the diagonal: d_i x rest
+    DBuf Ct(c, rest * di);
+    transpose(c, di, rest, Ri, D, Ct, di);
+    F[i].right_apply(c, rest, Ct, di, Ct, di);                   // (L_i^-1 [C_ij L_j^-T]_{j > i})' = S_ji for every j > i
+    copy2d(c, rest, di, Ct, di, S.get() + off[i + 1] * D + off[i], D);
+    transpose(c, rest, di, Ct, di, Ri, D);
   }
   const int kk = int(std::min<int64_t>(k, D));
   std::vector<double> lam;
