@@ -1279,7 +1279,12 @@ static void trsm_right_lower_iter(ccz_ctx* c, bool trans, int64_t r, int64_t d, 
 //    inverse rows) -- 8 x (r x 512 x 512 product + rank-512 trailing update) at the big-GEMM rate instead of 64
 //    rank-64 updates that were bound by HBM.
 // ---------------------------------------------------------------------------
-constexpr int64_t SB = 512;
+// (CCZ_POTRF_SB: a measurement switch, read once -- 256 / 512 / 1024; every user of the kept inverses sees the same value)
+static const int64_t SB = [] {
+  const char* e = getenv("CCZ_POTRF_SB");
+  const int64_t v = e ? atoll(e) : 512;
+  return (v == 256 || v == 1024) ? v : int64_t(512);
+}();
 
 static void potrf_lower_batched_steps(ccz_ctx* c, int count, double* const* A, const int64_t* d, const int64_t* lda, int* info) {
   for (int b0 = 0; b0 < count; b0 += 8) {
@@ -2452,7 +2457,7 @@ int syev_small(ccz_ctx* c, const double* A, int64_t d, int64_t lda, double* w_de
     static const int chase_on = [] { const char* e = getenv("CCZ_SYEV_CHASE"); return e ? atoi(e) : 1; }();
     if (chase_on && Vrows) {
       // one launch: the solve and, next to it, the replay chasing its log (k_syev_chase)
-      unsigned* sync = reinterpret_cast<unsigned*>(im->d_flag + 8);
+      unsigned* sync = reinterpret_cast<unsigned*>(im->d_flag + 32);      // (words 8 .. 15 are the pivot flags of the factorizations)
       CCZ_HIP(hipMemsetAsync(sync, 0, 2 * sizeof(unsigned), stream(c)));
       const size_t lds_chase = std::max(lds_need, size_t(160 * (JR_COLS + 1) * 8 + JR_CHUNK * 80 * 16 + 16));
       const dim3 grid(1u + unsigned((d + JR_COLS - 1) / JR_COLS));
