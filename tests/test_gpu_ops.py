@@ -37,6 +37,24 @@ def test_gemm_f64(H, tA, tB, M, N, K):
     np.testing.assert_allclose(out, ref, rtol=1e-12, atol=1e-12 * K)
 
 
+@pytest.mark.parametrize("tA,tB", [(0, 0), (1, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("M,N,K,beta", [(1111, 999, 16, 0.0), (1111, 999, 48, -1.3), (1400, 1290, 144, 0.5), (4001, 515, 512, 0.0),
+                                        (130, 4098, 64, 1.0), (1024, 768, 2048, -0.25)])
+def test_gemm_f64_large_tiles(H, tA, tB, M, N, K, beta):
+    """The solver's 128- / 64-row-tile kernel (gemm64_big.hip: k_gemm_f64_pipe, software-pipelined k-blocks): ragged edges in both
+    dimensions, one / three / many k-blocks, all four transposition pairs, accumulate, and the deep-K few-tile shape that runs
+    split-K with the atomic epilogue."""
+    rng = np.random.default_rng(M + 3 * N + 7 * K + 2 * tA + tB)
+    A = rng.standard_normal((K, M) if tA else (M, K))
+    B = rng.standard_normal((N, K) if tB else (K, N))
+    Cm = rng.standard_normal((M, N))
+    ref = 0.7 * (A.T if tA else A) @ (B.T if tB else B) + beta * Cm
+    Ad, Bd, Cd = H.to_device(A), H.to_device(B), H.to_device(Cm)
+    call(H, "ccz_gemm_f64", tA, tB, M, N, K, 0.7, vp(Ad), A.shape[1], vp(Bd), B.shape[1], beta, vp(Cd), N)
+    out = H.to_host(Cd, (M, N))
+    np.testing.assert_allclose(out, ref, rtol=1e-12, atol=1e-12 * K)
+
+
 @pytest.mark.parametrize("tA", [0, 1])
 @pytest.mark.parametrize("M,N,K,beta", [(2048, 160, 2048, 0.0), (1100, 77, 1024, -1.3), (1537, 192, 4096, 0.5),
                                         (1024, 49, 1040, 0.0), (4096, 80, 8192, 1.0)])
