@@ -102,6 +102,10 @@ void gemm_ex(ccz_ctx* c, bool tA, bool tB, int64_t M, int64_t N, int64_t K, doub
 // in-place lower Cholesky of the d x d leading block (upper part left untouched).
 // returns 0, or j+1 if pivot j was not positive (matrix content then undefined).
 int potrf_lower(ccz_ctx* c, double* A, int64_t d, int64_t lda);
+// Cholesky factor AND its inverse in one go (small d: the Gram of a Cholesky-QR pass):  A = L L' (lower triangle of A authoritative;
+// A is destroyed), Linv (d x d, ld ldi) <- L^-1 as a FULL matrix (zeros above the diagonal).  Returns 0, or 1 + the index of
+// the first non-positive pivot (Linv undefined then).
+int potrf_lower_inv(ccz_ctx* c, double* A, int64_t d, int64_t lda, double* Linv, int64_t ldi);
 // the same for `count` independent matrices at once: the 64-column panel factorisations (the
 // sequential critical path) of all matrices share one launch per panel step.  info[b] as above.
 void potrf_lower_batched(ccz_ctx* c, int count, double* const* A, const int64_t* d, const int64_t* lda,

@@ -1622,6 +1622,33 @@ void potrf_lower_batched(ccz_ctx* c, int count, double* const* A, const int64_t*
   else potrf_lower_batched_iter(c, count, A, d, lda, info);
 }
 
+// Factor and inverse of ONE small SPD matrix (ops.h): the chain kernel produces L^-1 next to L (cholinv_batched with X), so the
+// Cholesky-QR passes of the subspace iteration need no triangular solve -- X <- X L^-T is one product with the explicit inverse.
+int potrf_lower_inv(ccz_ctx* c, double* A, int64_t d, int64_t lda, double* Linv, int64_t ldi) {
+  if (d < 1) fail(CCZ_EINVAL, "potrf_lower_inv: d >= 1 required");
+  if (solver_legacy() || d > 4096) {
+    // (no chain kernel: factor, then L^-1 = I L^-1 by the triangular solve)
+    const int info = potrf_lower(c, A, d, lda);
+    if (info != 0) return info;
+    fill2d(c, d, d, Linv, ldi, 0.0);
+    add_diag(c, d, Linv, ldi, 1.0);
+    trsm_right_lower(c, false, d, d, A, lda, Linv, ldi);
+    return 0;
+  }
+  DBuf Lb(c, d * d), Tb(c, (d + NB - 1) / NB * NB * NB);
+  double* Ap[1] = {A};
+  double* Lp[1] = {Lb.get()};
+  double* Xp[1] = {Linv};
+  double* Tp[1] = {Tb.get()};
+  const int64_t dd[1] = {d}, la[1] = {lda}, ll[1] = {d}, lx[1] = {ldi};
+  fill2d(c, d, d, Linv, ldi, 0.0);                     // (the chain writes the lower triangle only)
+  int* info_dev = impl(c)->d_flag + 8;
+  cholinv_batched(c, 1, Ap, la, dd, Lp, ll, Xp, lx, Tp, info_dev);
+  int got = 0;
+  d2h(c, &got, info_dev, sizeof(int));
+  return got == 0x7fffffff ? 0 : got;
+}
+
 int64_t trsm_aux_size(ccz_ctx*, int64_t d) {
   if (solver_legacy() || d <= 1024) return 0;
   return (d + SB - 1) / SB * SB * SB;

@@ -77,6 +77,20 @@ void potrf_lower_batched(ccz_ctx* c, int count, double* const* A, const int64_t*
   for (int b = 0; b < count; ++b) info[b] = potrf_lower(c, A[b], d[b], lda[b]);
 }
 
+int potrf_lower_inv(ccz_ctx* c, double* A, int64_t d, int64_t lda, double* Linv, int64_t ldi) {
+  const int info = potrf_lower(c, A, d, lda);
+  if (info != 0) return info;
+  for (int64_t j = 0; j < d; ++j) {              // column j of L^-1 by forward substitution on e_j
+    for (int64_t i = 0; i < d; ++i) {
+      if (i < j) { Linv[i * ldi + j] = 0.0; continue; }
+      double v = i == j ? 1.0 : 0.0;
+      for (int64_t t = j; t < i; ++t) v -= A[i * lda + t] * Linv[t * ldi + j];
+      Linv[i * ldi + j] = v / A[i * lda + i];
+    }
+  }
+  return 0;
+}
+
 void trsm_right_lower(ccz_ctx*, bool trans, int64_t r, int64_t d, const double* L, int64_t ldl,
                       double* X, int64_t ldx) {
   for (int64_t row = 0; row < r; ++row) {
