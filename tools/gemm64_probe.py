@@ -59,6 +59,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "skinny":
         skinny()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "one":          # one M N K tA tB   (for a counter pass over ONE shape)
+        one(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), bool(int(sys.argv[5])), bool(int(sys.argv[6])), iters=3)
+        sys.exit(0)
     # ragged edges, all four transposition pairs, one and three k-blocks (correctness of the tile loop's ends)
     for tA in (False, True):
         for tB in (False, True):
