@@ -301,6 +301,9 @@ void topk_symmetric(ccz_ctx* c, const SymOp& op, int k, std::vector<double>& the
     double worst = 0.0;
     for (int i = 0; i < k; ++i) worst = std::max(worst, st.resid[i]);
     if (worst <= tol * scale) {
+      static const bool trace_done = getenv("CCZ_TRACE_SOLVER") != nullptr;
+      if (trace_done)
+        fprintf(stderr, "[ccz] topk p=%lld k=%d b=%lld done after %d cycle(s): worst/scale %.3e\n", (long long)p, k, (long long)b, cycle, worst / scale);
       theta.assign(st.theta.begin(), st.theta.begin() + k);
       copy2d(c, p, k, X, b, Xout, k);
       return;
@@ -321,10 +324,19 @@ void topk_symmetric(ccz_ctx* c, const SymOp& op, int k, std::vector<double>& the
     if (x > 1.0 + 1e-12) {
       // x1000 margin: the cosh estimate is optimistic by ~10x in practice, and landing a hair above the tolerance
       // costs a whole extra filter + orthonormalise + Rayleigh-Ritz cycle (one more degree costs two GEMMs)
-      const double need = std::max(worst / (tol * scale), 2.0) * 1e3;
+      static const double margin = [] { const char* e = getenv("CCZ_CHEB_MARGIN"); return e ? atof(e) : 1e3; }();
+      const double need = std::max(worst / (tol * scale), 2.0) * margin;
       degree = int(std::ceil(std::acosh(need) / std::acosh(x)));
     }
-    degree = std::min(40, std::max(2, degree) + boost);
+    static const int max_degree = [] { const char* e = getenv("CCZ_CHEB_MAXDEG"); return e ? atoi(e) : 40; }();
+    // The FIRST filter is sized from the Ritz values of two power steps: where the wanted end of the spectrum is dense (x close to
+    // 1: MCCA 4 x 2048 x = 1.13, GCCA D = 16384 x = 1.09) those underestimate the gap badly -- the estimate asked for 63 / 70 degrees,
+    // the cap of 40 converged both to 4e-14 / 9e-14 in one cycle, and so did 22 (MCCA) and 26 (GCCA: 9e-12), measured in round 6
+    // (tools/solve_probe.py with CCZ_TRACE_SOLVER=1 and CCZ_CHEB_MAXDEG).  A filter that falls short costs one more, cheap cycle
+    // (accurate Ritz values then: degree 7 at GCCA's shape, 157 ms against 166 with the old cap) -- so the first cycle is capped lower.
+    static const int first_cap = [] { const char* e = getenv("CCZ_CHEB_FIRSTCAP"); return e ? atoi(e) : 28; }();
+    const int cap = cycle == 0 ? std::min(max_degree, std::max(2, first_cap)) : max_degree;
+    degree = std::min(cap, std::max(2, degree) + boost);
     static const bool trace = getenv("CCZ_TRACE_SOLVER") != nullptr;
     if (trace)
       fprintf(stderr, "[ccz] topk p=%lld k=%d b=%lld cycle %d: worst/scale %.3e  x %.6f  degree %d\n", (long long)p, k,
