@@ -867,22 +867,29 @@ static void gcca_solve_impl(ccz_ctx* c, const double* mom, int64_t n, const int6
   }
   std::vector<Whitener> F = make_whiteners(c, R, dimv, false);
   wait_deferred(c);
-  // Z[:, j] = sqrt(mu_j) Gx[:, j] L_j^-T      (Gx: second moments of the data as fitted)
+  // K = F' Gx F,  F = blockdiag(sqrt(mu_i) L_i^-T),  Gx: second moments of the data as fitted.  K is symmetric, so only its blocks on
+  // and above the diagonal are formed (round 6: the two whitening passes were 3.3e12 flops of a 16384 x 16384 problem with all D rows
+  // in every triangular solve -- 42 ms of a 162 ms solve; the block-upper form is 2.3e12) and mirrored:
+  //   pass 1:  Z_ij = sqrt(mu_j) Gx_ij L_j^-T  for i <= j   -- rows [0, off[j + 1]) of block column j, in place
+  //   pass 2:  K_ji = sqrt(mu_i) (L_i^-1 Z_ij)' for j >= i  -- block row i from the diagonal on, transposed, whitened by L_i;
+  //            written as block column i below the diagonal and mirrored into block row i; the diagonal block is averaged with its
+  //            transpose (symmetric up to round-off)
   DBuf Z(c, D * D), K(c, D * D);
   for (int j = 0; j < m; ++j) {
-    cov_block(c, G, D, s, n, ctr, rmu[j], 0, D, off[j], dims[j], Z.get() + off[j], D);
-    F[j].right_apply(c, D, Z.get() + off[j], D, Z.get() + off[j], D);
+    cov_block(c, G, D, s, n, ctr, rmu[j], 0, off[j + 1], off[j], dims[j], Z.get() + off[j], D);
+    F[j].right_apply(c, off[j + 1], Z.get() + off[j], D, Z.get() + off[j], D);
   }
-  // K[:, i] = ( sqrt(mu_i) L_i^-1 Z[i, :] )' = sqrt(mu_i) Z[i, :]' L_i^-T
   for (int i = 0; i < m; ++i) {
-    transpose(c, dims[i], D, Z.get() + off[i] * D, D, K.get() + off[i], D);
-    F[i].right_apply(c, D, K.get() + off[i], D, K.get() + off[i], D);
-    axpby2d(c, D, dims[i], rmu[i], K.get() + off[i], D, 0.0, nullptr, 0);
-  }
-  {  // symmetrise (K is symmetric up to round-off)
-    DBuf Kt(c, D * D);
-    transpose(c, D, D, K, D, Kt, D);
-    axpby2d(c, D, D, 0.5, K, D, 0.5, Kt, D);
+    const int64_t di = dims[i], rest = D - off[i];
+    double* Ri = Z.get() + off[i] * D + off[i];                  // d_i x rest
+    DBuf T(c, rest * di);
+    transpose(c, di, rest, Ri, D, T, di);
+    F[i].right_apply(c, rest, T, di, T, di);
+    axpby2d(c, rest, di, rmu[i], T, di, 0.0, nullptr, 0);
+    double* Kii = K.get() + off[i] * D + off[i];
+    copy2d(c, rest, di, T, di, Kii, D);                          // block column i from the diagonal down
+    transpose(c, rest, di, T, di, Kii, D);                       // block row i from the diagonal on (the diagonal block: T_ii')
+    axpby2d(c, di, di, 0.5, Kii, D, 0.5, T, di);                 // K_ii = (T_ii' + T_ii) / 2
   }
   const int kk = int(std::min<int64_t>({int64_t(k), D, n}));
   std::vector<double> lam;
@@ -893,9 +900,19 @@ static void gcca_solve_impl(ccz_ctx* c, const double* mom, int64_t n, const int6
   K.reset();
   for (int i = 0; i < kk; ++i)
     if (!(lam[i] > 0.0)) fail(CCZ_ENOCONV, "GCCA eigenvalue %d is not positive (%g); fewer than k shared directions", i, lam[i]);
-  // rhs = Z U / sqrt(lam)   (D x k)  == X' T stacked by view
+  // rhs = Gx F U / sqrt(lam)   (D x k)  == X' T stacked by view.  (Z = Gx F is only half formed now: F U first -- k rows through
+  // every view's factor, one batched back-projection -- then ONE skinny product with Gx, which takes Z's place.)
   DBuf U(c, D * kk), rhs(c, D * kk), lamd(c, kk);
+  {
+    std::vector<const Whitener*> Fp;
+    std::vector<double*> Yp;
+    std::vector<int64_t> ldy;
+    for (int i = 0; i < m; ++i) { Fp.push_back(&F[i]); Yp.push_back(Ut.get() + off[i]); ldy.push_back(D); }
+    back_project_rows_multi(c, Fp, kk, Yp, ldy);                 // Ut_i <- (L_i^-T U_i)'
+    for (int i = 0; i < m; ++i) axpby2d(c, kk, dims[i], rmu[i], Ut.get() + off[i], D, 0.0, nullptr, 0);
+  }
   transpose(c, kk, D, Ut, D, U, kk);
+  cov_block(c, G, D, s, n, ctr, 1.0, 0, D, 0, D, Z, D);          // Gx (symmetric, full)
   gemm(c, false, false, D, kk, D, 1.0, Z, D, U, kk, 0.0, rhs, kk);
   h2d(c, lamd, lam.data(), size_t(kk) * 8);
   scale_cols(c, D, kk, rhs, kk, lamd, 2);
