@@ -463,6 +463,122 @@ __global__ __launch_bounds__(256, 3) void k_gemm_f32_nn_tall(int64_t M, int64_t 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Round 6: the same projection with WHOLE-LINE loads.  k_gemm_f32_nn_tall above gives every lane
+// its own sample row and fetches 64 bytes of it per k-block: each wave-level b128 load touches 64 different 128-byte
+// lines and uses 16 bytes of each, and the second half of a line is asked for one k-block later, when 12 waves x 64 rows
+// x 128 B = 96 KB per CU have gone through a 32 KB L1 in between.  Here eight consecutive lanes fetch the 128 bytes
+// (32 k) of ONE row -- a wave-level load is eight whole lines -- and the transpose into the [k][m] image happens in the
+// LDS store (row stride 258 floats: the 64 lanes of a store land on every bank twice, the minimum for 64 x 4 bytes).
+// k-block 32 -> 64 MFMAs per wave between barriers; ONE LDS buffer (41 KB: three workgroups per CU) with the next block
+// held in registers while the current one is multiplied.  Same fragment reads, MFMA order and epilogue as above.
+// ---------------------------------------------------------------------------------------------------
+constexpr int BK2 = 32;
+constexpr int BTP = BT + 2;
+
+__global__ __launch_bounds__(256, 3) void k_gemm_f32_nn_tall2(int64_t M, int64_t N, int64_t K, float alpha,
+                                                              const float* __restrict__ A, int64_t lda,
+                                                              const float* __restrict__ B /* K x 64, padded */, float beta,
+                                                              float* __restrict__ C, int64_t ldc,
+                                                              const float* __restrict__ bias /* 64, padded */) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* as = reinterpret_cast<float*>(smem);    // A^T [32][258]
+  float* bs = as + BK2 * BTP;                    // B   [32][64]
+  const int64_t m0 = int64_t(blockIdx.x) * BT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t rows_valid = min<int64_t>(BT, M - m0);
+  const __amdgpu_buffer_rsrc_t srcA = make_rsrc(A + m0 * lda, ((rows_valid - 1) * lda + K) * 4);
+  const __amdgpu_buffer_rsrc_t srcB = make_rsrc(B, K * TN * 4);
+  const int rl = wave * 64 + (lane >> 3), pc = lane & 7;               // load i: row rl + 8 i, 16-byte piece pc of the 128
+  const int voffA = int((int64_t(rl) * lda + 4 * pc) * 4);
+  const int rstep = int(int64_t(8) * lda * 4);
+  const int voffB = tid * 16;                                          // 512 float4 per k-block, two per thread
+
+  v16f32 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  v4f32 ra[8], rb[2];
+  auto gload = [&](int64_t k0) {
+    const int soffA = __builtin_amdgcn_readfirstlane(int(k0 * 4));
+    const int soffB = __builtin_amdgcn_readfirstlane(int(k0 * TN * 4));
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      ra[i] = __builtin_bit_cast(v4f32, __builtin_amdgcn_raw_buffer_load_b128(srcA, voffA + i * rstep, soffA, 0));
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      rb[j] = __builtin_bit_cast(v4f32, __builtin_amdgcn_raw_buffer_load_b128(srcB, voffB + j * 4096, soffB, 0));
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) as[(4 * pc + e) * BTP + rl + 8 * i] = ra[i][e];   // transpose: [k][m]
+#pragma unroll
+    for (int j = 0; j < 2; ++j) *reinterpret_cast<v4f32*>(bs + (tid + 256 * j) * 4) = rb[j];
+  };
+
+  const int64_t nkb = K / BK2;
+  gload(0);
+  lstore();
+  __syncthreads();
+  const float* ap = as + (lane >> 5) * BTP + wave * 64 + 2 * (lane & 31);
+  const float* bp = bs + (lane >> 5) * TN + 2 * (lane & 31);
+  for (int64_t kb = 0; kb < nkb; ++kb) {
+    const bool more = kb + 1 < nkb;
+    if (more) gload((kb + 1) * BK2);
+    v2f32 af[2], bf[2];
+    af[0] = *reinterpret_cast<const v2f32*>(ap);
+    bf[0] = *reinterpret_cast<const v2f32*>(bp);
+#pragma unroll
+    for (int kk = 0; kk < BK2 / 2; ++kk) {
+      if (kk + 1 < BK2 / 2) {
+        af[(kk + 1) & 1] = *reinterpret_cast<const v2f32*>(ap + 2 * (kk + 1) * BTP);
+        bf[(kk + 1) & 1] = *reinterpret_cast<const v2f32*>(bp + 2 * (kk + 1) * TN);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const v2f32 a2 = af[kk & 1], b2 = bf[kk & 1];
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+          acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[ti], b2[tj], acc[ti][tj], 0, 0, 0);
+    }
+    __syncthreads();                       // every wave has read the block
+    if (more) {
+      lstore();
+      __syncthreads();
+    }
+  }
+
+  const int nb = 2 * (lane & 31);
+  v2f32 b2 = {0.f, 0.f};
+  if (bias) b2 = *reinterpret_cast<const v2f32*>(bias + nb);
+  const bool pair_ok = (ldc & 1) == 0 && nb + 1 < N;
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int trow = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int64_t m = m0 + wave * 64 + 2 * trow + ti;
+      if (m >= M || nb >= N) continue;
+      float* cp = C + m * ldc + nb;
+      v2f32 v = {acc[ti][0][r], acc[ti][1][r]};
+      v = (v - b2) * alpha;
+      if (pair_ok) {
+        if (beta != 0.f) v += beta * *reinterpret_cast<const v2f32*>(cp);
+        *reinterpret_cast<v2f32*>(cp) = v;
+      } else {
+        cp[0] = beta != 0.f ? v[0] + beta * cp[0] : v[0];
+        if (nb + 1 < N) cp[1] = beta != 0.f ? v[1] + beta * cp[1] : v[1];
+      }
+    }
+}
+
 // fp64 (rows x cols, ld ldi) -> fp32 (rows x cols_pad, zero-padded columns)
 __global__ void k_f64_to_f32_pad(int64_t rows, int64_t cols, int64_t cols_pad, const double* __restrict__ in, int64_t ldi,
                                  float* __restrict__ out) {
@@ -513,9 +629,17 @@ void gemm_f32_big(ccz_ctx* c, int64_t M, int64_t N, int64_t K, double alpha, con
                        N, int64_t(TN), B, ldb, B32);
     if (bias_row)
       hipLaunchKernelGGL(k_f64_to_f32_pad, dim3(1), dim3(256), 0, st, int64_t(1), N, int64_t(TN), bias_row, N, bias32);
-    const size_t lds_bytes = size_t(2) * BKK * (BT + TN) * 4;
-    hipLaunchKernelGGL(k_gemm_f32_nn_tall, dim3((unsigned)((M + BT - 1) / BT)), dim3(256), lds_bytes, st, M, N, K, float(alpha),
-                       A, lda, B32, float(beta), C, ldc, bias32);
+    const char* tall_env = getenv("CCZ_TALL_IMPL");                   // 2: whole-line loads (default), 1: a row per lane
+    const int tall_impl = tall_env ? atoi(tall_env) : 2;
+    if (tall_impl == 2 && K % BK2 == 0) {
+      const size_t lds_bytes = size_t(BK2) * (BTP + TN) * 4;
+      hipLaunchKernelGGL(k_gemm_f32_nn_tall2, dim3((unsigned)((M + BT - 1) / BT)), dim3(256), lds_bytes, st, M, N, K, float(alpha),
+                         A, lda, B32, float(beta), C, ldc, bias32);
+    } else {
+      const size_t lds_bytes = size_t(2) * BKK * (BT + TN) * 4;
+      hipLaunchKernelGGL(k_gemm_f32_nn_tall, dim3((unsigned)((M + BT - 1) / BT)), dim3(256), lds_bytes, st, M, N, K, float(alpha),
+                         A, lda, B32, float(beta), C, ldc, bias32);
+    }
     CCZ_LAUNCH_CHECK();
     dev_free(c, B32);                    // pooled scratch is recycled in stream order: no host wait
     return;
