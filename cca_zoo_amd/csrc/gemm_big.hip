@@ -474,79 +474,97 @@ __global__ __launch_bounds__(256, 3) void k_gemm_f32_nn_tall(int64_t M, int64_t 
 // held in registers while the current one is multiplied.  Same fragment reads, MFMA order and epilogue as above.
 // ---------------------------------------------------------------------------------------------------
 constexpr int BK2 = 32;
-constexpr int BTP = BT + 2;
 
-__global__ __launch_bounds__(256, 3) void k_gemm_f32_nn_tall2(int64_t M, int64_t N, int64_t K, float alpha,
-                                                              const float* __restrict__ A, int64_t lda,
-                                                              const float* __restrict__ B /* K x 64, padded */, float beta,
-                                                              float* __restrict__ C, int64_t ldc,
-                                                              const float* __restrict__ bias /* 64, padded */) {
+// TI = 2: 256 rows per workgroup (a wave owns 64 rows = 2 x 2 MFMA tiles); TI = 1: 128 rows (a wave owns 32 rows = 1 x 2 tiles):
+// half the work per workgroup and twice the workgroups per CU -- the last, partly filled round of workgroups (3907 on 768
+// slots at n = 1e6) costs half as much, and more workgroups in different phases keep the matrix pipe fed across the barriers.
+// NJ = 2: 64 output columns (two 32-wide MFMA tiles, a lane's two fragments are consecutive n); NJ = 1: N <= 32 -- one tile, half the
+// MFMA work (k <= 32 directions are the common case of the linear models), only the first 32 columns of B staged.
+template <int TI, int NJ>
+__global__ __launch_bounds__(256, TI == 2 ? 3 : 5) void k_gemm_f32_nn_tall2(int64_t M, int64_t N, int64_t K, float alpha,
+                                                                            const float* __restrict__ A, int64_t lda,
+                                                                            const float* __restrict__ B /* K x 64, padded */,
+                                                                            float beta, float* __restrict__ C, int64_t ldc,
+                                                                            const float* __restrict__ bias /* 64, padded */) {
+  constexpr int ROWS = 128 * TI, RW = 32 * TI, RP = ROWS + 2, NL = 4 * TI, BW = 32 * NJ;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* as = reinterpret_cast<float*>(smem);    // A^T [32][258]
-  float* bs = as + BK2 * BTP;                    // B   [32][64]
-  const int64_t m0 = int64_t(blockIdx.x) * BT;
+  float* as = reinterpret_cast<float*>(smem);    // A^T [32][ROWS + 2]
+  float* bs = as + BK2 * RP;                     // B   [32][BW]
+  const int64_t m0 = int64_t(blockIdx.x) * ROWS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t rows_valid = min<int64_t>(BT, M - m0);
+  const int64_t rows_valid = min<int64_t>(ROWS, M - m0);
   const __amdgpu_buffer_rsrc_t srcA = make_rsrc(A + m0 * lda, ((rows_valid - 1) * lda + K) * 4);
   const __amdgpu_buffer_rsrc_t srcB = make_rsrc(B, K * TN * 4);
-  const int rl = wave * 64 + (lane >> 3), pc = lane & 7;               // load i: row rl + 8 i, 16-byte piece pc of the 128
+  const int rl = wave * RW + (lane >> 3), pc = lane & 7;               // load i: row rl + 8 i, 16-byte piece pc of the 128
   const int voffA = int((int64_t(rl) * lda + 4 * pc) * 4);
   const int rstep = int(int64_t(8) * lda * 4);
-  const int voffB = tid * 16;                                          // 512 float4 per k-block, two per thread
+  // B: 32 x BW floats per k-block = 256 NJ float4, NJ per thread (NJ = 2: the padded rows as they lie; NJ = 1: their first half)
+  const int voffB = NJ == 2 ? tid * 16 : (tid >> 3) * (TN * 4) + (tid & 7) * 16;
 
-  v16f32 acc[2][2];
+  v16f32 acc[TI][NJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  v4f32 ra[8], rb[2];
+  v4f32 ra[NL], rb[NJ];
   auto gload = [&](int64_t k0) {
     const int soffA = __builtin_amdgcn_readfirstlane(int(k0 * 4));
     const int soffB = __builtin_amdgcn_readfirstlane(int(k0 * TN * 4));
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < NL; ++i)
       ra[i] = __builtin_bit_cast(v4f32, __builtin_amdgcn_raw_buffer_load_b128(srcA, voffA + i * rstep, soffA, 0));
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
       rb[j] = __builtin_bit_cast(v4f32, __builtin_amdgcn_raw_buffer_load_b128(srcB, voffB + j * 4096, soffB, 0));
   };
   auto lstore = [&]() {
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < NL; ++i)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) as[(4 * pc + e) * BTP + rl + 8 * i] = ra[i][e];   // transpose: [k][m]
+      for (int e = 0; e < 4; ++e) as[(4 * pc + e) * RP + rl + 8 * i] = ra[i][e];   // transpose: [k][m]
 #pragma unroll
-    for (int j = 0; j < 2; ++j) *reinterpret_cast<v4f32*>(bs + (tid + 256 * j) * 4) = rb[j];
+    for (int j = 0; j < NJ; ++j) *reinterpret_cast<v4f32*>(bs + (tid + 256 * j) * 4) = rb[j];
   };
 
   const int64_t nkb = K / BK2;
   gload(0);
   lstore();
   __syncthreads();
-  const float* ap = as + (lane >> 5) * BTP + wave * 64 + 2 * (lane & 31);
-  const float* bp = bs + (lane >> 5) * TN + 2 * (lane & 31);
+  const float* ap = as + (lane >> 5) * RP + wave * RW + TI * (lane & 31);
+  const float* bp = bs + (lane >> 5) * BW + NJ * (lane & 31);
   for (int64_t kb = 0; kb < nkb; ++kb) {
     const bool more = kb + 1 < nkb;
     if (more) gload((kb + 1) * BK2);
-    v2f32 af[2], bf[2];
-    af[0] = *reinterpret_cast<const v2f32*>(ap);
-    bf[0] = *reinterpret_cast<const v2f32*>(bp);
+    float af[2][TI], bf[2][NJ];
+    auto fread = [&](int slot, int kk) {
+      if constexpr (TI == 2) {
+        const v2f32 t = *reinterpret_cast<const v2f32*>(ap + 2 * kk * RP);
+        af[slot][0] = t[0];
+        af[slot][1] = t[1];
+      } else {
+        af[slot][0] = ap[2 * kk * RP];
+      }
+      if constexpr (NJ == 2) {
+        const v2f32 t = *reinterpret_cast<const v2f32*>(bp + 2 * kk * BW);
+        bf[slot][0] = t[0];
+        bf[slot][1] = t[1];
+      } else {
+        bf[slot][0] = bp[2 * kk * BW];
+      }
+    };
+    fread(0, 0);
 #pragma unroll
     for (int kk = 0; kk < BK2 / 2; ++kk) {
-      if (kk + 1 < BK2 / 2) {
-        af[(kk + 1) & 1] = *reinterpret_cast<const v2f32*>(ap + 2 * (kk + 1) * BTP);
-        bf[(kk + 1) & 1] = *reinterpret_cast<const v2f32*>(bp + 2 * (kk + 1) * TN);
-      }
+      if (kk + 1 < BK2 / 2) fread((kk + 1) & 1, kk + 1);
       __builtin_amdgcn_sched_barrier(0);
-      const v2f32 a2 = af[kk & 1], b2 = bf[kk & 1];
 #pragma unroll
-      for (int ti = 0; ti < 2; ++ti)
+      for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
-        for (int tj = 0; tj < 2; ++tj)
-          acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[ti], b2[tj], acc[ti][tj], 0, 0, 0);
+        for (int tj = 0; tj < NJ; ++tj)
+          acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk & 1][ti], bf[kk & 1][tj], acc[ti][tj], 0, 0, 0);
     }
     __syncthreads();                       // every wave has read the block
     if (more) {
@@ -555,26 +573,34 @@ __global__ __launch_bounds__(256, 3) void k_gemm_f32_nn_tall2(int64_t M, int64_t
     }
   }
 
-  const int nb = 2 * (lane & 31);
-  v2f32 b2 = {0.f, 0.f};
-  if (bias) b2 = *reinterpret_cast<const v2f32*>(bias + nb);
-  const bool pair_ok = (ldc & 1) == 0 && nb + 1 < N;
+  // NJ = 2: a lane holds, for every (ti, r), two consecutive n (tj = 0, 1) of sample row m; NJ = 1: one n
+  const int nb = NJ * (lane & 31);
+  float bv[NJ];
 #pragma unroll
-  for (int ti = 0; ti < 2; ++ti)
+  for (int j = 0; j < NJ; ++j) bv[j] = bias ? bias[nb + j] : 0.f;
+  const bool pair_ok = NJ == 2 && (ldc & 1) == 0 && nb + 1 < N;
+#pragma unroll
+  for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int trow = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      const int64_t m = m0 + wave * 64 + 2 * trow + ti;
+      const int64_t m = m0 + wave * RW + TI * trow + ti;
       if (m >= M || nb >= N) continue;
       float* cp = C + m * ldc + nb;
-      v2f32 v = {acc[ti][0][r], acc[ti][1][r]};
-      v = (v - b2) * alpha;
-      if (pair_ok) {
-        if (beta != 0.f) v += beta * *reinterpret_cast<const v2f32*>(cp);
-        *reinterpret_cast<v2f32*>(cp) = v;
+      if constexpr (NJ == 2) {
+        v2f32 v = {acc[ti][0][r], acc[ti][1][r]};
+        const v2f32 b2 = {bv[0], bv[1]};
+        v = (v - b2) * alpha;
+        if (pair_ok) {
+          if (beta != 0.f) v += beta * *reinterpret_cast<const v2f32*>(cp);
+          *reinterpret_cast<v2f32*>(cp) = v;
+        } else {
+          cp[0] = beta != 0.f ? v[0] + beta * cp[0] : v[0];
+          if (nb + 1 < N) cp[1] = beta != 0.f ? v[1] + beta * cp[1] : v[1];
+        }
       } else {
-        cp[0] = beta != 0.f ? v[0] + beta * cp[0] : v[0];
-        if (nb + 1 < N) cp[1] = beta != 0.f ? v[1] + beta * cp[1] : v[1];
+        const float v = (acc[ti][0][r] - bv[0]) * alpha;
+        cp[0] = beta != 0.f ? v + beta * cp[0] : v;
       }
     }
 }
@@ -629,11 +655,18 @@ void gemm_f32_big(ccz_ctx* c, int64_t M, int64_t N, int64_t K, double alpha, con
                        N, int64_t(TN), B, ldb, B32);
     if (bias_row)
       hipLaunchKernelGGL(k_f64_to_f32_pad, dim3(1), dim3(256), 0, st, int64_t(1), N, int64_t(TN), bias_row, N, bias32);
-    const char* tall_env = getenv("CCZ_TALL_IMPL");                   // 2: whole-line loads (default), 1: a row per lane
-    const int tall_impl = tall_env ? atoi(tall_env) : 2;
-    if (tall_impl == 2 && K % BK2 == 0) {
-      const size_t lds_bytes = size_t(BK2) * (BTP + TN) * 4;
-      hipLaunchKernelGGL(k_gemm_f32_nn_tall2, dim3((unsigned)((M + BT - 1) / BT)), dim3(256), lds_bytes, st, M, N, K, float(alpha),
+    const char* tall_env = getenv("CCZ_TALL_IMPL");     // 3: whole-line loads, 128 rows per workgroup (default); 2: 256 rows; 1: a row per lane
+    const int tall_impl = tall_env ? atoi(tall_env) : 3;
+    const char* nj_env = getenv("CCZ_TALL_NJ1");         // 0: always two column tiles (A/B switch of the N <= 32 form)
+    const bool nj1 = N <= 32 && !(nj_env && atoi(nj_env) == 0);
+    if (tall_impl == 3 && K % BK2 == 0 && (M + 127) / 128 < (int64_t(1) << 31)) {
+      const size_t lds_bytes = size_t(BK2) * (128 + 2 + (nj1 ? 32 : TN)) * 4;
+      auto kern = nj1 ? &k_gemm_f32_nn_tall2<1, 1> : &k_gemm_f32_nn_tall2<1, 2>;
+      hipLaunchKernelGGL(kern, dim3((unsigned)((M + 127) / 128)), dim3(256), lds_bytes, st, M, N, K, float(alpha), A, lda, B32, float(beta),
+                         C, ldc, bias32);
+    } else if (tall_impl >= 2 && K % BK2 == 0) {
+      const size_t lds_bytes = size_t(BK2) * (256 + 2 + TN) * 4;
+      hipLaunchKernelGGL((k_gemm_f32_nn_tall2<2, 2>), dim3((unsigned)((M + BT - 1) / BT)), dim3(256), lds_bytes, st, M, N, K, float(alpha),
                          A, lda, B32, float(beta), C, ldc, bias32);
     } else {
       const size_t lds_bytes = size_t(2) * BKK * (BT + TN) * 4;

@@ -251,6 +251,33 @@ def test_transform_f32_projection_kernel(H, n, d, k, ld_extra, ldo_extra):
         assert np.all(got[:, k:] == 7.0)                  # padding columns untouched
 
 
+@pytest.mark.parametrize("impl,nj1", [("1", "1"), ("2", "1"), ("3", "0")])
+@pytest.mark.parametrize("n,d,k,ld_extra", [(8321, 512, 64, 0), (16500, 320, 20, 4)])
+def test_transform_f32_projection_kernel_forms(H, monkeypatch, impl, nj1, n, d, k, ld_extra):
+    """The A/B forms of the projection kernel behind ``CCZ_TALL_IMPL`` (1: a row per lane, rounds 2-5; 2: whole-line loads with
+    256 rows per workgroup; 3, the default: 128 rows) and ``CCZ_TALL_NJ1=0`` (two column tiles also for k <= 32) give the
+    default form's result to fp32 rounding (same products, same order of accumulation per output)."""
+    from cca_zoo_amd import _backend
+
+    rng = np.random.default_rng(n + d + k)
+    ld = d + ld_extra
+    Xp = (rng.standard_normal((n, ld)) + 0.3).astype(np.float32)
+    mean, W = rng.standard_normal(d), rng.standard_normal((d, k))
+    Xd, md, Wd = H.to_device(Xp), H.to_device(mean), H.to_device(W)
+    outs = []
+    for env in (None, (impl, nj1)):
+        if env is not None:
+            monkeypatch.setenv("CCZ_TALL_IMPL", env[0])
+            monkeypatch.setenv("CCZ_TALL_NJ1", env[1])
+        od = H.to_device(np.zeros((n, k), dtype=np.float32))
+        call(H, "ccz_transform", _backend.F32, vp(Xd), n, d, ld, vp(md), vp(Wd), k, vp(od), k)
+        outs.append(H.to_host(od, (n, k), dtype=np.float32))
+    ref = (Xp[:, :d].astype(np.float64) - mean) @ W
+    scale = np.abs(ref).max()
+    assert np.abs(outs[1] - ref).max() < 2e-5 * scale * np.sqrt(d)
+    assert np.abs(outs[1] - outs[0]).max() < 1e-5 * scale
+
+
 @pytest.mark.parametrize("n,d,k,impl", [(65536, 288, 256, "1"), (65600, 512, 512, "1"), (65536, 256, 256, "0")])
 def test_transform_f32_wide_output_kernels(H, n, d, k, impl, monkeypatch):
     """(X - mean) W with k a multiple of 256 and >= 256 output tiles: the 256 x 256-tile kernels (wave-private

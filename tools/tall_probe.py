@@ -36,7 +36,8 @@ def call():
 
 
 for impl in (os.environ.get("TALL_IMPLS", "1,2,2,1")).split(","):
-    os.environ["CCZ_TALL_IMPL"] = impl
+    os.environ["CCZ_TALL_IMPL"] = impl.rstrip("w")
+    os.environ["CCZ_TALL_NJ1"] = "0" if impl.endswith("w") else "1"      # "3w": two column tiles also for k <= 32
     out.zero_()
     call()
     h.sync()
