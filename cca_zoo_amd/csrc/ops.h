@@ -186,8 +186,11 @@ int jacobi_rows(ccz_ctx* c, int64_t p, int64_t q, double* W, int64_t ldw, double
 // shift.  Returns sweeps; throws EINVAL on non-finite input, ENOCONV beyond max_sweeps.  syev_small_max: largest
 // supported d (0: the backend has no such kernel).
 int syev_small_max(ccz_ctx* c);
+// tol: a rotation is applied while |h_pq| > tol max|A| (the default is a full-accuracy solve; a caller that only needs an orthogonal
+// basis and Ritz VALUES -- the first Rayleigh-Ritz of the subspace iteration -- passes a larger one and saves the last sweeps;
+// V stays orthogonal to rounding whatever tol is: it is a product of exact rotations).
 int syev_small(ccz_ctx* c, const double* A, int64_t d, int64_t lda, double* w_dev, double* Vrows, int64_t ldv,
-               int max_sweeps);
+               int max_sweeps, double tol = 2.220446049250313e-16);
 // Two-sided BLOCK Jacobi EVD for the sizes above syev_small_max (HIP backend: evd_block.hip -- 32-wide column blocks,
 // the pair sub-problems in LDS, every O(d^3) update as 64-wide tiles on the fp64 matrix pipe).  A (d x d) is only read
 // and symmetrised on load; w_dev[i] = eigenvalue i (unsorted), row i of Vrows (ld ldv) = its eigenvector.  Returns

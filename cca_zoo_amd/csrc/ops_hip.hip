@@ -2465,7 +2465,7 @@ static int syev_mode() {   // 0: one-sided rows (round 1), 1: fused two-sided LD
 
 int syev_small_max(ccz_ctx*) { return syev_mode() == 2 ? 160 : (syev_mode() == 1 ? 96 : 0); }
 
-int syev_small(ccz_ctx* c, const double* A, int64_t d, int64_t lda, double* w_dev, double* Vrows, int64_t ldv, int max_sweeps) {
+int syev_small(ccz_ctx* c, const double* A, int64_t d, int64_t lda, double* w_dev, double* Vrows, int64_t ldv, int max_sweeps, double tol) {
   const int dmax = syev_small_max(c);
   if (d < 1 || d > dmax) fail(CCZ_EINVAL, "syev_small: 1 <= d <= %d required, got %lld", dmax, (long long)d);
   Impl* im = impl(c);
@@ -2478,7 +2478,7 @@ int syev_small(ccz_ctx* c, const double* A, int64_t d, int64_t lda, double* w_de
     jac_cs* log = reinterpret_cast<jac_cs*>(logb.get());
     auto launch = [&](auto kern) {
       CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_need)));
-      hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds_need, stream(c), int(d), A, lda, w_dev, log, 2.220446049250313e-16,
+      hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds_need, stream(c), int(d), A, lda, w_dev, log, tol,
                          max_sweeps, im->d_flag + 2);
     };
     static const int chase_on = [] { const char* e = getenv("CCZ_SYEV_CHASE"); return e ? atoi(e) : 1; }();
@@ -2490,7 +2490,7 @@ int syev_small(ccz_ctx* c, const double* A, int64_t d, int64_t lda, double* w_de
       const dim3 grid(1u + unsigned((d + JR_COLS - 1) / JR_COLS));
       auto launch2 = [&](auto kern) {
         CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_chase)));
-        hipLaunchKernelGGL(kern, grid, dim3(1024), lds_chase, stream(c), int(d), A, lda, w_dev, log, 2.220446049250313e-16, max_sweeps,
+        hipLaunchKernelGGL(kern, grid, dim3(1024), lds_chase, stream(c), int(d), A, lda, w_dev, log, tol, max_sweeps,
                            im->d_flag + 2, sync, Vrows, ldv);
       };
       if (nblk <= 1024) launch2(&k_syev_chase<1>);
@@ -2524,11 +2524,11 @@ int syev_small(ccz_ctx* c, const double* A, int64_t d, int64_t lda, double* w_de
     if (d <= 80) {
       CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_syev_small), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_need)));
       hipLaunchKernelGGL(k_syev_small, dim3(1), dim3(1024), lds_need, stream(c), int(d), A, lda, w_dev, Vrows, ldv,
-                         2.220446049250313e-16, max_sweeps, im->d_flag + 1);
+                         tol, max_sweeps, im->d_flag + 1);
     } else {
       CCZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_syev_small_wide), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_need)));
       hipLaunchKernelGGL(k_syev_small_wide, dim3(1), dim3(1024), lds_need, stream(c), int(d), A, lda, w_dev, Vrows, ldv,
-                         2.220446049250313e-16, max_sweeps, im->d_flag + 1);
+                         tol, max_sweeps, im->d_flag + 1);
     }
     CCZ_LAUNCH_CHECK();
     d2h(c, &sw, im->d_flag + 1, sizeof(int));

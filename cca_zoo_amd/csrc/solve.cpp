@@ -68,11 +68,11 @@ static bool legacy_evd() {   // CCZ_EVD_LEGACY=1: rounds 1-3's launch-per-round 
   return v;
 }
 static int syev_full_impl(ccz_ctx* c, double* A, int64_t d, bool psd, std::vector<double>& w,
-                          double* Vrows, int64_t ldv) {
+                          double* Vrows, int64_t ldv, double small_tol = 2.220446049250313e-16) {
   if (!psd && d >= 2 && d <= syev_small_max(c)) {
     // Rayleigh-Ritz sized problems: two-sided Jacobi in one workgroup (no shift needed, no definiteness assumed)
     DBuf wd(c, d), V(c, d * d);
-    const int sweeps = syev_small(c, A, d, d, wd, V, d, kMaxSweeps);
+    const int sweeps = syev_small(c, A, d, d, wd, V, d, kMaxSweeps, small_tol);
     std::vector<double> lh(d);
     d2h(c, lh.data(), wd, size_t(d) * 8);
     std::vector<int64_t> perm(d);
@@ -219,15 +219,20 @@ struct RitzState {
 
 // Rayleigh-Ritz on span(X): X <- X C, Y <- (S X) C, theta, residual norms.  The three block pointers rotate (the
 // products land in scratch blocks that then become X / Y): no block copies.
+// jac_tol: the Jacobi threshold of the b x b eigen-solve (see syev_small).  The FIRST Rayleigh-Ritz of a subspace iteration only
+// sizes the filter (Ritz values: their error is the SQUARE of what is left off the diagonal) and rotates the basis (orthogonal
+// whatever the threshold); the residuals below are those of the pairs actually formed, so acceptance never rests on it.
 void rayleigh_ritz(ccz_ctx* c, const SymOp& op, int64_t b, double*& X, double*& Y, double*& tmp,
-                   RitzState& st) {
+                   RitzState& st, double jac_tol = 2.220446049250313e-16) {
   const int64_t p = op.p;
   op.apply(X, b, b, Y, b);
   DBuf H(c, b * b), Hs(c, b * b), Vr(c, b * b);
   gemm(c, true, false, b, b, p, 1.0, X, b, Y, b, 0.0, H, b);
   transpose(c, b, b, H, b, Hs, b);
   axpby2d(c, b, b, 0.5, H, b, 0.5, Hs, b);            // symmetrise
-  syev_full_impl(c, H, b, false, st.theta, Vr, b);      // rows of Vr = Ritz coefficient vectors
+  const int jsw = syev_full_impl(c, H, b, false, st.theta, Vr, b, jac_tol);      // rows of Vr = Ritz coefficient vectors
+  static const bool trace_rr = getenv("CCZ_TRACE_SOLVER") != nullptr;
+  if (trace_rr) fprintf(stderr, "[ccz] rayleigh_ritz b=%lld: %d Jacobi sweeps at threshold %.1e\n", (long long)b, jsw, jac_tol);
   gemm(c, false, true, p, b, b, 1.0, X, b, Vr, b, 0.0, tmp, b);
   std::swap(X, tmp);                                    // X = X C ; tmp = old X (free)
   gemm(c, false, true, p, b, b, 1.0, Y, b, Vr, b, 0.0, tmp, b);
@@ -291,7 +296,10 @@ void topk_symmetric(ccz_ctx* c, const SymOp& op, int k, std::vector<double>& the
     orthonormalize(c, p, b, X, b);
   }
   RitzState st;
-  rayleigh_ritz(c, op, b, X, Y, Z, st);
+  // the first Rayleigh-Ritz feeds the filter design, not the answer (unless the block spans everything): a Jacobi threshold of
+  // 1e-9 leaves Ritz values good to 1e-18 of the scale and saves the last one or two of its ~8 sweeps (CCZ_RR1_TOL; 0 = full)
+  static const double rr1_tol = [] { const char* e = getenv("CCZ_RR1_TOL"); return e ? atof(e) : 1e-9; }();
+  rayleigh_ritz(c, op, b, X, Y, Z, st, (b < p && rr1_tol > 2.220446049250313e-16) ? rr1_tol : 2.220446049250313e-16);
   const double tol = 1e-11;
   const int max_cycles = 200;
   double prev_worst = 1e300;

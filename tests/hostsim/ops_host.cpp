@@ -248,7 +248,7 @@ void trsm_right_lower_aux_multi(ccz_ctx* c, int count, bool trans, const int64_t
 // Two-sided Jacobi in the device kernel's own formulation (k_syev_small, ops_hip.hip): round-robin tournament,
 // all rotation parameters of a round from the current H, then every 2 x 2 block R_a' M R_b and the rows of V'.
 int syev_small_max(ccz_ctx*) { return 160; }
-int syev_small(ccz_ctx*, const double* A, int64_t d, int64_t lda, double* w, double* Vt, int64_t ldv, int max_sweeps) {
+int syev_small(ccz_ctx*, const double* A, int64_t d, int64_t lda, double* w, double* Vt, int64_t ldv, int max_sweeps, double tol) {
   if (d < 1 || d > 160) fail(CCZ_EINVAL, "syev_small: 1 <= d <= 160 required, got %lld", (long long)d);
   const int64_t pe = (d + 1) & ~int64_t(1), m1 = pe - 1, np = pe / 2;
   std::vector<double> H(size_t(pe) * pe, 0.0), V(size_t(pe) * pe, 0.0), cs(np), sn(np), tn(np);
@@ -263,7 +263,7 @@ int syev_small(ccz_ctx*, const double* A, int64_t d, int64_t lda, double* w, dou
       hmax = std::max(hmax, std::fabs(h));
     }
   }
-  const double thr = 2.220446049250313e-16 * hmax;
+  const double thr = tol * hmax;
   for (int sweep = 1; sweep <= max_sweeps; ++sweep) {
     int64_t rot = 0;
     for (int64_t round = 0; round < m1; ++round) {
