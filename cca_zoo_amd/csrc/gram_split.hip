@@ -73,16 +73,31 @@ struct SplitTile {
 // pass, the 8 rows of one k half: its 8 float4 loads are one 1 KiB-per-wave row segment each, its stores 64 contiguous
 // bytes per plane.  HBM-bound: 4 bytes in, 4 bytes out per element.
 // ---------------------------------------------------------------------------
-template <bool ALIGNED>
+__device__ __forceinline__ void sp_wave_lds_sync() {    // lanes of ONE wave exchange data through LDS (see cholinv.hip::wave_lds_sync)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// XCH (default; CCZ_SPLIT_XCH=0 restores the direct stores): the 64 bytes a thread produces per plane are FOUR 16-byte pieces of a
+// 512-byte run, so a wave-level store of one piece per lane is 64 separate 16-byte writes at a stride of 64 bytes -- the PMC pass
+// (profiles/r06_split_pass_pmc_raw.md) counts 6.05e8 L2 requests per 262144 rows, 5.4e8 of them these partial writes, i.e. 80
+// requests per clock on 128 L2 channels.  With XCH the eight lanes of a column tile swap pieces through a wave-private 4 KB of LDS
+// (no workgroup barrier) so that store e of lane j is piece 8 e + j: every wave-level store is eight whole 128-byte lines.
+template <bool ALIGNED, bool XCH>
 __global__ __launch_bounds__(256) void k_split_bf16x2(const SplitPanel* __restrict__ panels, SplitViews vws, int64_t r0, int64_t nrows, int64_t ksteps,
                                                       const float* __restrict__ pilot, char* __restrict__ planes,
-                                                      double* __restrict__ msq, double* __restrict__ csum, int rb) {
+                                                      double* __restrict__ msq, double* __restrict__ csum, int rb, int panel_fast) {
   __shared__ float red[4][256];
   __shared__ double redc[4][256];
-  const SplitPanel pn = panels[blockIdx.y];
+  __shared__ sp_v4u32 xch[XCH ? 4 : 1][XCH ? 256 : 1];      // per wave: 8 column tiles x 32 pieces of 16 bytes (one plane, one k half)
+  // panel_fast: consecutive workgroups take the panels of ONE row block (together they read whole rows) instead of the row blocks
+  // of one panel (a 1 KiB stripe of every 16 KiB row: the same few HBM channels for everybody) -- CCZ_SPLIT_ORDER
+  const unsigned pidx = panel_fast ? blockIdx.x : blockIdx.y, ridx = panel_fast ? blockIdx.y : blockIdx.x;
+  const SplitPanel pn = panels[pidx];
   const int tid = threadIdx.x, cg = tid & 63, rg = tid >> 6;
   const int64_t rows_pad = ksteps * SP_K;
-  const int64_t rb0 = int64_t(blockIdx.x) * rb;             // rb rows per workgroup (a multiple of 32, <= SP_RB)
+  const int64_t rb0 = int64_t(ridx) * rb;                   // rb rows per workgroup (a multiple of 32, <= SP_RB)
   const int c0 = 4 * cg;
   sp_v4f32 p = {0.f, 0.f, 0.f, 0.f};
   bool cok[4];
@@ -93,7 +108,7 @@ __global__ __launch_bounds__(256) void k_split_bf16x2(const SplitPanel* __restri
   }
   const float* __restrict__ X = vws.data[pn.view] + pn.col0 + c0;
   const int64_t pld = vws.ld[pn.view];
-  char* out = planes + int64_t(blockIdx.y) * ksteps * SP_PSTEP + (cg >> 3) * 1024 + (cg & 7) * 64;
+  char* out = planes + int64_t(pidx) * ksteps * SP_PSTEP + (cg >> 3) * 1024 + (cg & 7) * 64;
   sp_v4f32 q = {0.f, 0.f, 0.f, 0.f};
   double cs[4] = {0.0, 0.0, 0.0, 0.0};               // exact column sums of x (not of x - p): the means, and the pilot fix-up's s
   for (int pass = 0; pass < rb / 32; ++pass) {
@@ -136,10 +151,38 @@ __global__ __launch_bounds__(256) void k_split_bf16x2(const SplitPanel* __restri
       }
     }
     char* dst = out + (row >> 4) * SP_PSTEP + ((row >> 3) & 1) * 512;
+    if constexpr (XCH) {
+      // piece (tile t, column c) sits at xw[32 t + (c ^ ((c >> 3) & 3) ^ ((t & 1) << 3))]: the 8 lanes of a ds_write_b128 group
+      // (c = 4 j + e) then cover all eight 16-byte bank quads, and the 16 lanes of a ds_read_b128 group (c = 8 e + j over four
+      // tiles) all sixteen of a 256-byte row (MI355X_MICROARCH.md, LDS service groups) -- plain [32 t + c] is 4-way / 2-way
+      sp_v4u32* xw = xch[rg];
+      char* dst2 = dst - (cg & 7) * 48;                                // tile base + (cg & 7) * 16
+      const int t8 = ((cg >> 3) & 1) << 3, j = cg & 7;
+      const int wr = (cg >> 3) * 32 + ((4 * j) ^ t8), wx = j >> 1;     // + (e ^ wx)
+      const int rd = (cg >> 3) * 32;                                   // + ((8 e) ^ t8) + (j ^ e)
+      sp_wave_lds_sync();                                              // the previous pass's reads are done
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      *reinterpret_cast<sp_v4u32*>(dst + e * 16) = hw[e];              // (plain stores: non-temporal ones made this pass 3.5x slower)
-      *reinterpret_cast<sp_v4u32*>(dst + SP_PLANE + e * 16) = mw[e];
+      for (int e = 0; e < 4; ++e) xw[wr + (e ^ wx)] = hw[e];
+      sp_wave_lds_sync();
+#pragma unroll
+      for (int e = 0; e < 4; ++e) hw[e] = xw[rd + ((8 * e) ^ t8) + (j ^ e)];
+      sp_wave_lds_sync();
+#pragma unroll
+      for (int e = 0; e < 4; ++e) xw[wr + (e ^ wx)] = mw[e];
+      sp_wave_lds_sync();
+#pragma unroll
+      for (int e = 0; e < 4; ++e) mw[e] = xw[rd + ((8 * e) ^ t8) + (j ^ e)];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        *reinterpret_cast<sp_v4u32*>(dst2 + e * 128) = hw[e];
+        *reinterpret_cast<sp_v4u32*>(dst2 + SP_PLANE + e * 128) = mw[e];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        *reinterpret_cast<sp_v4u32*>(dst + e * 16) = hw[e];              // (plain stores: non-temporal ones made this pass 3.5x slower)
+        *reinterpret_cast<sp_v4u32*>(dst + SP_PLANE + e * 16) = mw[e];
+      }
     }
   }
   // msq: the four row groups of the workgroup -> one fp64 atomic per column
@@ -372,9 +415,17 @@ static void launch_split_pass(ccz_ctx* c, const SplitTables& tb, const SplitView
                               const float* pilot, char* planes, double* msq, double* colsum, hipStream_t st = nullptr) {
   if (!st) st = stream(c);
   const int rb = split_rows_per_block(ksteps * SP_K, tb.np, std::max(1, impl(c)->props.multiProcessorCount));
-  const dim3 grid((unsigned)((ksteps * SP_K + rb - 1) / rb), (unsigned)tb.np);
-  if (aligned) hipLaunchKernelGGL(k_split_bf16x2<true>, grid, dim3(256), 0, st, tb.panels, vws, r0, rows, ksteps, pilot, planes, msq, colsum, rb);
-  else hipLaunchKernelGGL(k_split_bf16x2<false>, grid, dim3(256), 0, st, tb.panels, vws, r0, rows, ksteps, pilot, planes, msq, colsum, rb);
+  const unsigned nrb = (unsigned)((ksteps * SP_K + rb - 1) / rb);
+  // panels fastest in the grid (default; CCZ_SPLIT_ORDER=0: row blocks fastest, the first form; read per call).  Measured at the
+  // metric shape, alternating runs (tools/r6_split_order.sh): 12.1 / 10.7 / 10.6 ms against 12.6 / 12.3 / 11.9 -- never slower.
+  const char* oe = getenv("CCZ_SPLIT_ORDER");
+  const int panel_fast = (!(oe && atoi(oe) == 0) && nrb <= 65535u) ? 1 : 0;
+  const dim3 grid = panel_fast ? dim3((unsigned)tb.np, nrb) : dim3(nrb, (unsigned)tb.np);
+  const char* xe = getenv("CCZ_SPLIT_XCH");                  // 0: direct 16-byte stores at a stride of 64 bytes (the first form); read per call
+  const bool xch = !(xe && atoi(xe) == 0);
+  auto kern = aligned ? (xch ? &k_split_bf16x2<true, true> : &k_split_bf16x2<true, false>)
+                      : (xch ? &k_split_bf16x2<false, true> : &k_split_bf16x2<false, false>);
+  hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, tb.panels, vws, r0, rows, ksteps, pilot, planes, msq, colsum, rb, panel_fast);
 }
 
 // The K1-layout planes of ONE fp32 matrix X (rows x cols, ld): panels of 256 columns, `ksteps` k-steps of 16 rows each (rows past
